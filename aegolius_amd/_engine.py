@@ -1,0 +1,201 @@
+"""ctypes binding of libsdfk.so (C-ABI declared in include/sdfk.h).
+
+This is the only place the Python layer touches native code. There is no CPU fallback: if the
+shared library is missing or no MI355X is visible, evaluation raises.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsdfk.so")
+
+MODE_AUTO, MODE_INTERPRET, MODE_SPECIALIZED = 0, 1, 2
+
+_c = ctypes
+_vp, _i64, _int, _sz = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t
+_fp = _c.POINTER(_c.c_float)
+
+# name -> (restype, argtypes); every symbol declared in include/sdfk.h
+SIGNATURES = {
+    "sdfk_abi_version": (_int, []),
+    "sdfk_device_count": (_int, []),
+    "sdfk_last_error": (_c.c_char_p, []),
+    "sdfk_program_create": (_vp, [_vp, _sz, _vp, _sz, _vp, _sz, _int]),
+    "sdfk_program_destroy": (None, [_vp]),
+    "sdfk_program_set_params": (_int, [_vp, _vp, _sz]),
+    "sdfk_program_source": (_c.c_char_p, [_vp]),
+    "sdfk_program_compile_check": (_int, [_vp, _c.POINTER(_sz)]),
+    "sdfk_eval_device": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _int]),
+    "sdfk_eval_host": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _int, _int]),
+    "sdfk_eval_grid": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _int]),
+    "sdfk_set_default_mode": (None, [_int]),
+    "sdfk_linspace_f32": (_int, [_c.c_double, _c.c_double, _i64, _vp]),
+    "sdfk_grid_fill": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp]),
+    "sdfk_set_device": (_int, [_int]),
+    "sdfk_malloc": (_vp, [_sz]),
+    "sdfk_free": (_int, [_vp]),
+    "sdfk_memcpy_h2d": (_int, [_vp, _vp, _sz]),
+    "sdfk_memcpy_d2h": (_int, [_vp, _vp, _sz]),
+    "sdfk_sync": (_int, [_vp]),
+    "sdfk_event_create": (_vp, []),
+    "sdfk_event_destroy": (_int, [_vp]),
+    "sdfk_event_record": (_int, [_vp, _vp]),
+    "sdfk_event_elapsed_ms": (_int, [_vp, _vp, _fp]),
+    "sdfk_stream_probe": (_int, [_vp, _i64, _i64, _vp, _vp]),
+}
+
+
+class SdfkError(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Load libsdfk.so once. Raises (never falls back) when the extension has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise SdfkError(
+                        "aegolius_amd: %s is missing - build it with "
+                        "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc, gfx950). "
+                        "There is no CPU path." % LIB_PATH)
+                handle = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(handle, name)
+                    fn.restype, fn.argtypes = res, args
+                if handle.sdfk_abi_version() != 1:
+                    raise SdfkError("libsdfk.so ABI version mismatch")
+                _lib = handle
+    return _lib
+
+
+def last_error():
+    msg = lib().sdfk_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SdfkError("%s failed (%d): %s" % (what, rc, last_error()))
+
+
+def device_count():
+    return lib().sdfk_device_count()
+
+
+def require_gpu():
+    if device_count() < 1:
+        raise SdfkError("aegolius_amd: no HIP device visible - SDF evaluation runs on an MI355X only "
+                        "(there is no CPU path)")
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_vp) if a is not None and a.size else None
+
+
+class Program:
+    """Owning wrapper of an `sdfk_program*` (a lowered expression tree)."""
+
+    def __init__(self, code, params, tables, result_reg):
+        self.code = np.ascontiguousarray(code, dtype=np.uint32).reshape(-1, 2)
+        self.params = np.ascontiguousarray(params, dtype=np.float32).ravel()
+        self.tables = np.ascontiguousarray(tables, dtype=np.float32).ravel()
+        self.result_reg = int(result_reg)
+        self._h = lib().sdfk_program_create(_ptr(self.code), self.code.shape[0], _ptr(self.params), self.params.size,
+                                            _ptr(self.tables), self.tables.size, self.result_reg)
+        if not self._h:
+            raise SdfkError("sdfk_program_create rejected the program: " + last_error())
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_params(self, params):
+        p = np.ascontiguousarray(params, dtype=np.float32).ravel()
+        check(lib().sdfk_program_set_params(self._h, _ptr(p), p.size), "sdfk_program_set_params")
+        self.params = p
+
+    def source(self):
+        s = lib().sdfk_program_source(self._h)
+        return s.decode() if s else None
+
+    def compile_check(self):
+        n = _sz(0)
+        check(lib().sdfk_program_compile_check(self._h, ctypes.byref(n)), "sdfk_program_compile_check")
+        return n.value
+
+    def eval_host(self, co, device=0, mode=MODE_AUTO):
+        """co: (3, N) float32/float64 host array -> (N,) float32 field."""
+        require_gpu()
+        co = np.asarray(co)
+        if co.ndim != 2 or co.shape[0] != 3:
+            raise ValueError("coordinates must have shape (3, N); got %r" % (co.shape,))
+        if co.dtype not in (np.float32, np.float64):
+            co = co.astype(np.float64)
+        co = np.ascontiguousarray(co)
+        n = co.shape[1]
+        out = np.empty(n, dtype=np.float32)
+        check(lib().sdfk_eval_host(self._h, _ptr(co), 0 if co.dtype == np.float32 else 1, n, n, _ptr(out), device,
+                                   mode), "sdfk_eval_host")
+        return out
+
+    def eval_device(self, d_co, n, row_stride, d_out, stream=None, mode=MODE_AUTO):
+        """Device pointers (ints). Asynchronous on `stream` (a hipStream_t as int, None = default)."""
+        check(lib().sdfk_eval_device(self._h, _vp(d_co), n, row_stride, _vp(d_out), _vp(stream or 0), mode),
+              "sdfk_eval_device")
+
+    def eval_grid(self, axes, start, count, d_out, stream=None, mode=MODE_AUTO):
+        ax = [np.ascontiguousarray(a, dtype=np.float32) for a in axes]
+        check(lib().sdfk_eval_grid(self._h, _ptr(ax[0]), ax[0].size, _ptr(ax[1]), ax[1].size, _ptr(ax[2]),
+                                   ax[2].size, start, count, _vp(d_out), _vp(stream or 0), mode), "sdfk_eval_grid")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            try:
+                _lib.sdfk_program_destroy(h)
+            except Exception:
+                pass
+
+
+def linspace_f32(lo, hi, n):
+    out = np.empty(int(n), dtype=np.float32)
+    check(lib().sdfk_linspace_f32(float(lo), float(hi), int(n), _ptr(out)), "sdfk_linspace_f32")
+    return out
+
+
+def grid_fill(d_co, row_stride, axes, start, count, stream=None):
+    ax = [np.ascontiguousarray(a, dtype=np.float32) for a in axes]
+    check(lib().sdfk_grid_fill(_vp(d_co), row_stride, _ptr(ax[0]), ax[0].size, _ptr(ax[1]), ax[1].size, _ptr(ax[2]),
+                               ax[2].size, start, count, _vp(stream or 0)), "sdfk_grid_fill")
+
+
+class Event:
+    def __init__(self):
+        self._h = lib().sdfk_event_create()
+        if not self._h:
+            raise SdfkError("sdfk_event_create: " + last_error())
+
+    def record(self, stream=None):
+        check(lib().sdfk_event_record(self._h, _vp(stream or 0)), "sdfk_event_record")
+
+    def elapsed_ms(self, stop):
+        ms = _c.c_float(0)
+        check(lib().sdfk_event_elapsed_ms(self._h, stop._h, ctypes.byref(ms)), "sdfk_event_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            try:
+                _lib.sdfk_event_destroy(h)
+            except Exception:
+                pass

@@ -1,0 +1,254 @@
+"""Lowering: expression tree -> sdfk register-machine program.
+
+Everything that does not depend on the point is computed HERE, in float64, and rounded once to
+fp32 (R^T/s, R^T t, reciprocals, sin/cos of fixed angles, instancing frames ...). The kernels only
+see fp32 constants in SGPRs.
+
+Coordinate registers and the reference's array aliasing
+-------------------------------------------------------
+The reference passes NumPy arrays between closures; three modifications overwrite the array they
+were given (`symmetry` cores/modifications.py:951, `rotational_symmetry` :1022-1028,
+`axis_revolution` :459) and that mutation is visible to a sibling evaluated later by an enclosing
+`displacement` / `recover_volume` / `define_volume` (:798, :343, :366). A coordinate register is
+therefore lowered under one of three modes:
+
+  OWNED    nobody reads this register afterwards: any op may overwrite it in place
+  ALIASED  an enclosing two-field modification re-reads it afterwards AND, in the reference, it is
+           the very same array: in-place modifications write through (visible), array-creating
+           modifications take a fresh register
+  FROZEN   somebody re-reads it afterwards but the reference would have made a private copy (the
+           skipped identity transform of a node): any writer must first move to a fresh register
+"""
+import numpy as np
+
+from . import _ops
+from ._ir import CombineSDF, ModSDF, NodeSDF, PrimSDF, SDFExpr, UnsupportedSDF
+
+OWNED, ALIASED, FROZEN = 0, 1, 2
+
+
+class LoweringError(Exception):
+    pass
+
+
+class LoweredProgram:
+    __slots__ = ("code", "params", "tables", "result_reg", "n_creg", "n_vreg")
+
+    def __init__(self, code, params, tables, result_reg, n_creg, n_vreg):
+        self.code, self.params, self.tables = code, params, tables
+        self.result_reg, self.n_creg, self.n_vreg = result_reg, n_creg, n_vreg
+
+    def key(self):
+        return (self.code.tobytes(), self.params.tobytes(), self.tables.tobytes(), self.result_reg)
+
+    @property
+    def fits_interpreter(self):
+        return self.n_creg <= _ops.INTERP_NC and self.n_vreg <= _ops.INTERP_NV
+
+
+class Lowerer:
+    def __init__(self):
+        self.code = []
+        self.params = []
+        self.tables = []
+        self._c_used = {0}
+        self._v_used = set()
+        self.n_creg = 1
+        self.n_vreg = 0
+
+    # ---- registers ----
+    def new_c(self):
+        i = 1
+        while i in self._c_used:
+            i += 1
+        if i > 255:
+            raise LoweringError("expression needs more than 256 coordinate registers")
+        self._c_used.add(i)
+        self.n_creg = max(self.n_creg, i + 1)
+        return i
+
+    def free_c(self, i):
+        self._c_used.discard(i)
+
+    def new_v(self):
+        i = 0
+        while i in self._v_used:
+            i += 1
+        if i > 255:
+            raise LoweringError("expression needs more than 256 value registers")
+        self._v_used.add(i)
+        self.n_vreg = max(self.n_vreg, i + 1)
+        return i
+
+    def free_v(self, i):
+        self._v_used.discard(i)
+
+    # ---- emission ----
+    def emit(self, opname, a, b=0, c=0, params=()):
+        info = _ops.BY_NAME[opname]
+        params = [float(x) for x in np.asarray(params, dtype=np.float64).ravel()]
+        if len(params) != info.nparams:
+            raise LoweringError("%s expects %d parameters, got %d" % (opname, info.nparams, len(params)))
+        poff = len(self.params)
+        self.params.extend(params)
+        self.code.append((info.code | (a << 8) | (b << 16) | (c << 24), poff))
+
+    def add_table(self, values):
+        off = len(self.tables)
+        self.tables.extend(float(x) for x in np.asarray(values, dtype=np.float64).ravel())
+        if len(self.tables) >= (1 << 24):
+            raise LoweringError("tables exceed 2^24 floats (offsets are carried as fp32)")
+        return off
+
+    def finish(self, vreg):
+        with np.errstate(over="ignore"):
+            params = np.asarray(self.params, dtype=np.float64).astype(np.float32)
+            tables = np.asarray(self.tables, dtype=np.float64).astype(np.float32)
+        return LoweredProgram(np.asarray(self.code, dtype=np.uint32).reshape(-1, 2), params, tables, vreg,
+                              self.n_creg, self.n_vreg)
+
+    # ---- coordinate helpers ----
+    def writable(self, creg, mode):
+        """Destination register for an op that produces a NEW array from `creg`."""
+        return creg if mode == OWNED else self.new_c()
+
+    def release(self, dst, creg):
+        if dst != creg:
+            self.free_c(dst)
+
+    # ---- nodes: Euclidean transform around an expression (reference transformations.py:232-242) ----
+    def lower_node(self, node, creg, mode):
+        if not _is_geometry(node):
+            raise LoweringError("object %r is not an aegolius_amd geometry (needs the symbolic node protocol)"
+                                % (node,))
+        R = np.asarray(node.rotation_matrix, dtype=np.float64)
+        if R.shape != (3, 3):
+            raise ValueError("rotation matrix must have shape (3, 3); got %r" % (R.shape,))
+        t = np.asarray(node.center, dtype=np.float64).reshape(3)
+        s = node.scale
+        ident_r = np.array_equal(R, np.eye(3))
+        unit_s = (s == 1)
+        if ident_r and unit_s and not np.any(t):
+            # (I·co)/1.0 - 0 is a bit-exact copy in the reference: alias the register instead
+            c, inner_mode = creg, (OWNED if mode == OWNED else FROZEN)
+        else:
+            c = self.writable(creg, mode)
+            rt = R.T
+            if ident_r and unit_s:
+                self.emit("XLATE", c, creg, params=rt.dot(t))
+            else:
+                self.emit("XFORM", c, creg, params=np.concatenate([(rt / s).ravel(), rt.dot(t)]))
+            inner_mode = OWNED
+        v = self.lower_expr(node.modified_object, c, inner_mode, node._geo_parameters)
+        self.release(c, creg)
+        if not unit_s:
+            self.emit("VSCALE", v, v, params=[s])
+        return v
+
+    # ---- expressions ----
+    def lower_expr(self, expr, creg, mode, params):
+        if isinstance(expr, PrimSDF):
+            v = self.new_v()
+            expr.lower(self, v, creg, params)
+            return v
+        if isinstance(expr, ModSDF):
+            from ._mods import MOD_LOWER
+            return MOD_LOWER[expr.name](self, expr, creg, mode, params)
+        if isinstance(expr, CombineSDF):
+            return self._lower_combine(expr, creg, mode)
+        if isinstance(expr, NodeSDF):
+            return self.lower_node(expr.obj, creg, OWNED if mode == OWNED else FROZEN)
+        if isinstance(expr, UnsupportedSDF):
+            raise NotImplementedError(expr.why)
+        raise NotImplementedError(
+            "aegolius_amd cannot fuse the opaque Python callable %r into the GPU evaluation; build the field "
+            "from aegolius_amd primitives / geometry objects (obj.propagate, obj.sign(direct=True), ...)" % (expr,))
+
+    def lower_callable(self, fn, creg, mode, params):
+        """Second-field argument of displacement / define_volume / recover_volume."""
+        return self.lower_expr(as_expr(fn), creg, mode, params)
+
+    # ---- combiners (reference combine.py:51-78, 129-135, 154-160) ----
+    def _lower_combine(self, expr, creg, mode):
+        from .cores.combine import BINARY_OPS, NARY_OPS, PARAMETRIC_OPS
+        op = expr.owner.operation_type
+        kids = expr.children
+        if expr.parametric:
+            if op not in PARAMETRIC_OPS:
+                raise KeyError(op)
+            opcode = PARAMETRIC_OPS[op]
+            w = expr.parameters
+            if isinstance(w, (tuple, list, np.ndarray)):
+                raise TypeError("unsupported operand type(s) for the parametric operation %s: parameters must be "
+                                "a scalar" % op)
+            w = float(w)
+            if opcode in ("BOLTZ", "BOLTZSUB"):
+                prm = [1.0 / w] if w != 0 else [np.inf]
+            else:
+                inv = (1.0 / w) if w != 0 else 0.0
+                prm = [w, inv, w / (4.0 if opcode == "SMIN2" else 6.0)]
+            if len(kids) != 2:
+                raise TypeError("%s takes exactly 2 objects (%d given)" % (op, len(kids)))
+        else:
+            if op in NARY_OPS:
+                opcode, prm = NARY_OPS[op], []
+                if len(kids) < 1:
+                    raise ValueError("zero-size array to reduction operation which has no identity")
+            elif op in BINARY_OPS:
+                opcode, prm = BINARY_OPS[op], []
+                if len(kids) != 2:
+                    raise TypeError("%s takes exactly 2 objects (%d given)" % (op, len(kids)))
+            else:
+                raise KeyError(op)
+        acc = None
+        for i, kid in enumerate(kids):
+            last = (i == len(kids) - 1)
+            v = self.lower_node(kid, creg, OWNED if (last and mode == OWNED) else FROZEN)
+            if acc is None:
+                acc = v
+            else:
+                self.emit(opcode, acc, acc, v, params=prm)
+                self.free_v(v)
+        return acc
+
+
+def _is_geometry(obj):
+    return hasattr(obj, "_geo_parameters") and hasattr(obj, "modified_object") and hasattr(obj, "rotation_matrix")
+
+
+def as_expr(fn):
+    """Map a user-supplied callable onto the symbolic world."""
+    if isinstance(fn, SDFExpr):
+        return fn
+    owner = getattr(fn, "__self__", None)
+    if owner is not None and _is_geometry(owner) and getattr(fn, "__name__", "") in ("propagate", "create"):
+        return NodeSDF(owner)
+    return UnsupportedSDF(fn, "aegolius_amd cannot fuse the opaque Python callable %r into the GPU evaluation; "
+                              "pass an aegolius_amd sdf_* function, a modification closure returned by an "
+                              "aegolius_amd geometry, or obj.propagate" % (fn,))
+
+
+def lower_geometry(node):
+    """Lower `node.create(co)` to a program."""
+    L = Lowerer()
+    v = L.lower_node(node, 0, OWNED)
+    return L.finish(v)
+
+
+class _ExprNode:
+    """Adapter: evaluate a bare expression `expr(co, *params)` (identity transform)."""
+    rotation_matrix = np.eye(3)
+    center = np.zeros(3)
+    scale = 1.0
+
+    def __init__(self, expr, params):
+        self.modified_object = expr
+        self._geo_parameters = tuple(params)
+
+
+def lower_expression(expr, params):
+    # a bare closure call gets the caller's array itself (no private copy): OWNED is safe because the
+    # register is loaded from memory and the caller's array is never written
+    L = Lowerer()
+    v = L.lower_expr(expr, 0, OWNED, tuple(params))
+    return L.finish(v)

@@ -1,0 +1,47 @@
+"""`GenericGeometry` — the drop-in boundary (reference cores/geom.py:15-74).
+
+`GenericGeometry(geo_sdf, *geo_parameters)`, `.create(co)`, `.propagate(co, *ignored)` and
+`.point_cloud(co)` keep the reference's signatures. `create` lowers the whole expression tree that
+hangs off this object (its modifications, its Euclidean transform, and — through CombineGeometry —
+every child object) to ONE fused GPU program and runs it through libsdfk.so.
+"""
+import numpy as np
+
+from .._eval import evaluate_geometry
+from .modifications import ModifyObject
+from .transformations import EuclideanTransform
+
+
+class GenericGeometry(EuclideanTransform, ModifyObject):
+    """Constructs geometry based on an SDF.
+
+    Args:
+        geo_sdf: SDF of a geometry - geo_sdf(co, *geo_parameters): an aegolius_amd `sdf_*` function, a
+            modification/combination closure returned by this package, or `other.propagate`.
+        geo_parameters: Parameters of the SDF.
+    """
+
+    def __init__(self, geo_sdf, *geo_parameters):
+        EuclideanTransform.__init__(self)
+        ModifyObject.__init__(self, geo_sdf)
+        self._geo_parameters = geo_parameters
+        self._sdf = self.geo_object
+
+    def create(self, co):
+        """Signed distance field of shape (N,) on the (3, N) point cloud `co` (modifications first,
+        then the Euclidean transform — reference cores/geom.py:29-43)."""
+        self._sdf = self.modified_object
+        return evaluate_geometry(self, co)
+
+    def propagate(self, co, *parameters_):
+        """Same as create(); extra arguments are ignored (reference cores/geom.py:45-60). Pass
+        `obj.propagate` wherever an SDF function is expected to use this object as a sub-tree."""
+        self._sdf = self.modified_object
+        return evaluate_geometry(self, co)
+
+    def point_cloud(self, co):
+        """Interior points (field <= 0) as a (3, M) cloud with z = 0 (reference cores/geom.py:62-74)."""
+        mask = self.create(co) <= 0
+        pts = np.zeros((3, np.count_nonzero(mask)))
+        pts[:2, :] = np.asarray(co)[:2, mask]
+        return pts

@@ -1,0 +1,722 @@
+// sdfk.hip — kernels and C-ABI of libsdfk.so (gfx950 only).
+//
+//   * sdfk_interp_kernel<VEC,SRC> : generic register-machine interpreter. The program and its
+//     parameters are wave-uniform, so the dispatch runs on the scalar unit (s_load of the
+//     instruction word, scalar branch) and parameters arrive in SGPRs through the scalar cache.
+//   * specialised kernels        : the same per-point functions (sdfk_device.h) called in
+//     straight-line order, generated per tree TOPOLOGY (parameters stay runtime data) by
+//     sdfk_codegen.cpp, compiled with hiprtc on first use and cached per (device, topology).
+//   * access pattern             : one thread owns 4 consecutive points — three 16-byte loads
+//     (x, y, z rows of the (3,N) array), one 16-byte store; a wave covers 1 KiB per row per
+//     instruction, fully coalesced. Algorithmic traffic 16 B/point.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see __graft_entry__.build()).
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/sdfk.h"
+#include "sdfk_device.h"
+#include "sdfk_access.h"
+#include "sdfk_codegen.h"
+
+// ------------------------------------------------------------------------------------------------
+// opcode tables from the single source of truth
+// ------------------------------------------------------------------------------------------------
+enum {
+#define SDFK_OP(NAME, KIND, NP, FUNC) SDFK_OP_##NAME,
+#include "sdfk_ops.def"
+#undef SDFK_OP
+    SDFK_OP_COUNT
+};
+
+static const sdfk_opinfo g_ops[] = {
+#define SDFK_OP(NAME, KIND, NP, FUNC) {#NAME, SDFK_KIND_##KIND, NP, #FUNC},
+#include "sdfk_ops.def"
+#undef SDFK_OP
+};
+
+extern "C" const sdfk_opinfo* sdfk_op_table(int* count) {
+    if (count) *count = SDFK_OP_COUNT;
+    return g_ops;
+}
+
+// interpreter register-file limits (the specialised path has none beyond the 8-bit operand fields)
+#define SDFK_NC 8
+#define SDFK_NV 8
+
+// ------------------------------------------------------------------------------------------------
+// interpreter kernel
+// ------------------------------------------------------------------------------------------------
+template <int VEC, typename SRC>
+__global__ __launch_bounds__(SDFK_BLOCK) void sdfk_interp_kernel(const uint2* __restrict__ code, int n_instr,
+                                                                const float* __restrict__ prm,
+                                                                const float* __restrict__ tab, SRC src, long long off,
+                                                                long long n, float* __restrict__ out, int result_reg) {
+    const long long block_base = (long long)blockIdx.x * (SDFK_BLOCK * VEC);
+    const unsigned lane_off = threadIdx.x * VEC;
+    if (block_base + lane_off >= n) return;
+    V3 C[SDFK_NC][VEC];
+    float V[SDFK_NV][VEC];
+    sdfk_load<VEC>(src, off + block_base, lane_off, C[0]);
+    for (int pc = 0; pc < n_instr; ++pc) {
+        const uint2 ins = code[pc];  // wave-uniform -> scalar load
+        const unsigned op = ins.x & 255u, a = (ins.x >> 8) & 255u, b = (ins.x >> 16) & 255u, c = ins.x >> 24;
+        const float* __restrict__ P = prm + ins.y;
+        switch (op) {
+#define SDFK_EXEC_C_C(F) \
+    _Pragma("unroll") for (int v = 0; v < VEC; ++v) C[a][v] = F(C[b][v], P, tab, (int)c)
+#define SDFK_EXEC_V_C(F) \
+    _Pragma("unroll") for (int v = 0; v < VEC; ++v) V[a][v] = F(C[b][v], P, tab)
+#define SDFK_EXEC_V_V(F) \
+    _Pragma("unroll") for (int v = 0; v < VEC; ++v) V[a][v] = F(V[b][v], P)
+#define SDFK_EXEC_V_VV(F) \
+    _Pragma("unroll") for (int v = 0; v < VEC; ++v) V[a][v] = F(V[b][v], V[c][v], P)
+#define SDFK_OP(NAME, KIND, NP, FUNC) \
+    case SDFK_OP_##NAME:              \
+        SDFK_EXEC_##KIND(FUNC);       \
+        break;
+#include "sdfk_ops.def"
+#undef SDFK_OP
+            default:
+                break;
+        }
+    }
+    sdfk_store<VEC>(out, off + block_base + lane_off, V[result_reg]);
+}
+
+// (3,n) -> (n) streaming probe with the evaluation kernels' access pattern
+__global__ __launch_bounds__(SDFK_BLOCK) void sdfk_probe_kernel(SrcArray src, long long n, float* __restrict__ out) {
+    const long long block_base = (long long)blockIdx.x * (SDFK_BLOCK * 4);
+    const unsigned lane_off = threadIdx.x * 4;
+    if (block_base + lane_off >= n) return;
+    V3 p[4];
+    sdfk_load<4>(src, block_base, lane_off, p);
+    float v[4] = {p[0].x + p[0].y + p[0].z, p[1].x + p[1].y + p[1].z, p[2].x + p[2].y + p[2].z,
+                  p[3].x + p[3].y + p[3].z};
+    sdfk_store<4>(out, block_base + lane_off, v);
+}
+
+__global__ __launch_bounds__(SDFK_BLOCK) void sdfk_gridfill_kernel(SrcGrid src, long long n, float* __restrict__ co,
+                                                                  long long stride) {
+    const long long block_base = (long long)blockIdx.x * (SDFK_BLOCK * 4);
+    const unsigned lane_off = threadIdx.x * 4;
+    const long long i = block_base + lane_off;
+    if (i >= n) return;
+    V3 p[4];
+    sdfk_load<4>(src, block_base, lane_off, p);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        if (i + v < n) {
+            co[i + v] = p[v].x;
+            co[stride + i + v] = p[v].y;
+            co[2 * stride + i + v] = p[v].z;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int g_default_mode = SDFK_MODE_AUTO;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(-100 - (int)e_, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+struct DevState {
+    uint2* d_code = nullptr;
+    float* d_params = nullptr;
+    float* d_tables = nullptr;
+    unsigned long long params_version = 0;
+};
+
+struct SpecKernel {
+    hipModule_t mod = nullptr;
+    hipFunction_t v4 = nullptr, v1 = nullptr, g4 = nullptr, g1 = nullptr;
+    bool failed = false;
+    std::string error;
+};
+
+struct sdfk_program {
+    std::vector<uint32_t> code;  // 2 words / instruction
+    std::vector<float> params, tables;
+    int result_reg = 0;
+    bool interp_ok = true;  // fits the interpreter's register file
+    unsigned long long params_version = 1;
+    std::string key;
+    std::string source;
+    std::mutex mu;
+    std::map<int, DevState> dev;
+};
+
+static std::mutex g_spec_mu;
+static std::map<std::pair<int, std::string>, std::shared_ptr<SpecKernel>> g_spec;
+
+extern "C" int sdfk_abi_version(void) { return SDFK_ABI_VERSION; }
+
+extern "C" int sdfk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+extern "C" const char* sdfk_last_error(void) { return g_err.c_str(); }
+extern "C" void sdfk_set_default_mode(int mode) { g_default_mode = mode; }
+
+// ---- validation -------------------------------------------------------------------------------
+static int table_rows_ok(const sdfk_program* p, int op, const float* P, std::string* why) {
+    auto bad = [&](const char* m) {
+        *why = m;
+        return 0;
+    };
+    long long cnt = (long long)P[0], off = (long long)P[1];
+    if (!(P[0] >= 0.0f) || !(P[1] >= 0.0f) || (float)cnt != P[0] || (float)off != P[1]) return bad("table count/offset not integral");
+    long long nt = (long long)p->tables.size();
+    long long row = 0;
+    switch (op) {
+        case SDFK_OP_P_SEGLINE3: row = 7; break;
+        case SDFK_OP_P_NEAREST3: row = 3; break;
+        case SDFK_OP_P_SEGLINE2: row = 5; break;
+        case SDFK_OP_P_NEAREST2: row = 2; break;
+        case SDFK_OP_P_SHAPESIGN: row = 6; break;
+        case SDFK_OP_CURVEINST: row = (P[2] != 0.0f) ? 12 : 3; break;
+        case SDFK_OP_P_POLYSIGN: {
+            long long pos = off;
+            for (long long j = 0; j < cnt; ++j) {
+                if (pos >= nt) return bad("polygon piece header out of range");
+                float kf = p->tables[pos];
+                long long k = (long long)kf;
+                if (!(kf >= 0.0f) || (float)k != kf) return bad("polygon piece size not integral");
+                pos += 1 + 4 * k;
+                if (pos > nt) return bad("polygon piece out of range");
+            }
+            return 1;
+        }
+        default: return 1;
+    }
+    if (off + cnt * row > nt) return bad("table rows out of range");
+    if (op == SDFK_OP_CURVEINST && cnt < 1) return bad("curve instancing needs at least one instance");
+    return 1;
+}
+
+static bool is_table_op(int op) {
+    return op == SDFK_OP_P_SEGLINE3 || op == SDFK_OP_P_NEAREST3 || op == SDFK_OP_P_SEGLINE2 ||
+           op == SDFK_OP_P_NEAREST2 || op == SDFK_OP_CURVEINST || op == SDFK_OP_P_POLYSIGN ||
+           op == SDFK_OP_P_SHAPESIGN;
+}
+
+static int validate(sdfk_program* p, std::string* why) {
+    const size_t n_instr = p->code.size() / 2;
+    std::vector<char> cdef(256, 0), vdef(256, 0);
+    cdef[0] = 1;  // C0 = input point
+    unsigned max_c = 0, max_v = 0;
+    char buf[160];
+    for (size_t i = 0; i < n_instr; ++i) {
+        const uint32_t w = p->code[2 * i], poff = p->code[2 * i + 1];
+        const unsigned op = w & 255u, a = (w >> 8) & 255u, b = (w >> 16) & 255u, c = w >> 24;
+        if (op >= SDFK_OP_COUNT) {
+            snprintf(buf, sizeof buf, "instruction %zu: unknown opcode %u", i, op);
+            *why = buf;
+            return 0;
+        }
+        const sdfk_opinfo& info = g_ops[op];
+        if ((size_t)poff + (size_t)info.nparams > p->params.size()) {
+            snprintf(buf, sizeof buf, "instruction %zu (%s): parameters out of range", i, info.name);
+            *why = buf;
+            return 0;
+        }
+        bool ok = true;
+        switch (info.kind) {
+            case SDFK_KIND_C_C: ok = cdef[b]; cdef[a] = 1; max_c = std::max(max_c, std::max(a, b)); break;
+            case SDFK_KIND_V_C: ok = cdef[b]; vdef[a] = 1; max_c = std::max(max_c, b); max_v = std::max(max_v, a); break;
+            case SDFK_KIND_V_V: ok = vdef[b]; vdef[a] = 1; max_v = std::max(max_v, std::max(a, b)); break;
+            case SDFK_KIND_V_VV:
+                ok = vdef[b] && vdef[c];
+                vdef[a] = 1;
+                max_v = std::max(max_v, std::max(a, std::max(b, c)));
+                break;
+        }
+        if (!ok) {
+            snprintf(buf, sizeof buf, "instruction %zu (%s): reads a register that was never written", i, info.name);
+            *why = buf;
+            return 0;
+        }
+        if (op == SDFK_OP_SYMMETRY && c > 2) {
+            snprintf(buf, sizeof buf, "instruction %zu: symmetry axis %u out of range", i, c);
+            *why = buf;
+            return 0;
+        }
+        if (is_table_op((int)op)) {
+            std::string w2;
+            if (!table_rows_ok(p, (int)op, p->params.data() + poff, &w2)) {
+                snprintf(buf, sizeof buf, "instruction %zu (%s): %s", i, info.name, w2.c_str());
+                *why = buf;
+                return 0;
+            }
+        }
+    }
+    if (p->result_reg < 0 || p->result_reg > 255 || !vdef[p->result_reg]) {
+        *why = "result register is never written";
+        return 0;
+    }
+    p->interp_ok = (max_c < SDFK_NC) && (max_v < SDFK_NV) && (p->result_reg < SDFK_NV);
+    return 1;
+}
+
+extern "C" sdfk_program* sdfk_program_create(const uint32_t* code, size_t n_instr, const float* params,
+                                             size_t n_params, const float* tables, size_t n_tables, int result_reg) {
+    if (!code || n_instr == 0 || n_instr > (1u << 20)) {
+        fail(-1, "sdfk_program_create: empty or oversized program");
+        return nullptr;
+    }
+    std::unique_ptr<sdfk_program> p(new sdfk_program);
+    p->code.assign(code, code + 2 * n_instr);
+    if (params && n_params) p->params.assign(params, params + n_params);
+    if (tables && n_tables) p->tables.assign(tables, tables + n_tables);
+    p->result_reg = result_reg;
+    std::string why;
+    if (!validate(p.get(), &why)) {
+        fail(-2, "sdfk_program_create: " + why);
+        return nullptr;
+    }
+    p->key.assign(reinterpret_cast<const char*>(p->code.data()), p->code.size() * sizeof(uint32_t));
+    p->key.push_back((char)result_reg);
+    return p.release();
+}
+
+static void free_dev_state(sdfk_program* p) {
+    int cur = 0;
+    bool have = hipGetDevice(&cur) == hipSuccess;
+    for (auto& kv : p->dev) {
+        if (hipSetDevice(kv.first) != hipSuccess) continue;
+        if (kv.second.d_code) (void)hipFree(kv.second.d_code);
+        if (kv.second.d_params) (void)hipFree(kv.second.d_params);
+        if (kv.second.d_tables) (void)hipFree(kv.second.d_tables);
+    }
+    if (have) (void)hipSetDevice(cur);
+    p->dev.clear();
+}
+
+extern "C" void sdfk_program_destroy(sdfk_program* p) {
+    if (!p) return;
+    free_dev_state(p);
+    delete p;
+}
+
+extern "C" int sdfk_program_set_params(sdfk_program* p, const float* params, size_t n_params) {
+    if (!p) return fail(-1, "null program");
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (n_params != p->params.size()) return fail(-2, "sdfk_program_set_params: parameter count differs from the program's");
+    std::vector<float> old = p->params;
+    p->params.assign(params, params + n_params);
+    std::string why;
+    if (!validate(p, &why)) {  // table counts / offsets live in the parameters
+        p->params = old;
+        return fail(-2, "sdfk_program_set_params: " + why);
+    }
+    p->params_version++;
+    return 0;
+}
+
+extern "C" const char* sdfk_program_source(sdfk_program* p) {
+    if (!p) return nullptr;
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (p->source.empty())
+        p->source = sdfk_generate_source(g_ops, SDFK_OP_COUNT, p->code.data(), p->code.size() / 2, p->result_reg);
+    return p->source.c_str();
+}
+
+static int rtc_compile(const std::string& src, std::vector<char>* out, std::string* log) {
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "sdfk_spec.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+        *log = "hiprtcCreateProgram failed";
+        return -1;
+    }
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"};
+    hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+    size_t ls = 0;
+    hiprtcGetProgramLogSize(prog, &ls);
+    if (ls > 1) {
+        log->resize(ls);
+        hiprtcGetProgramLog(prog, &(*log)[0]);
+    }
+    if (r != HIPRTC_SUCCESS) {
+        *log = std::string("hiprtc: ") + hiprtcGetErrorString(r) + "\n" + *log;
+        hiprtcDestroyProgram(&prog);
+        return -1;
+    }
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    out->resize(cs);
+    hiprtcGetCode(prog, out->data());
+    hiprtcDestroyProgram(&prog);
+    return 0;
+}
+
+extern "C" int sdfk_program_compile_check(sdfk_program* p, size_t* code_size) {
+    const char* src = sdfk_program_source(p);
+    if (!src) return fail(-1, "null program");
+    std::vector<char> co;
+    std::string log;
+    if (rtc_compile(src, &co, &log) != 0) return fail(-3, log);
+    if (code_size) *code_size = co.size();
+    return 0;
+}
+
+static std::shared_ptr<SpecKernel> get_spec(sdfk_program* p, int device) {
+    std::lock_guard<std::mutex> lk(g_spec_mu);
+    auto k = std::make_pair(device, p->key);
+    auto it = g_spec.find(k);
+    if (it != g_spec.end()) return it->second;
+    auto sk = std::make_shared<SpecKernel>();
+    g_spec[k] = sk;
+    const char* src = sdfk_program_source(p);
+    std::vector<char> co;
+    std::string log;
+    if (rtc_compile(src, &co, &log) != 0) {
+        sk->failed = true;
+        sk->error = log;
+        return sk;
+    }
+    hipError_t e = hipModuleLoadData(&sk->mod, co.data());
+    if (e == hipSuccess) e = hipModuleGetFunction(&sk->v4, sk->mod, "sdfk_spec_v4");
+    if (e == hipSuccess) e = hipModuleGetFunction(&sk->v1, sk->mod, "sdfk_spec_v1");
+    if (e == hipSuccess) e = hipModuleGetFunction(&sk->g4, sk->mod, "sdfk_spec_g4");
+    if (e == hipSuccess) e = hipModuleGetFunction(&sk->g1, sk->mod, "sdfk_spec_g1");
+    if (e != hipSuccess) {
+        sk->failed = true;
+        sk->error = std::string("hipModuleLoadData/GetFunction: ") + hipGetErrorString(e);
+    }
+    return sk;
+}
+
+// make sure code / params / tables of `p` are resident on the current device
+static int ensure_resident(sdfk_program* p, int device, hipStream_t stream, DevState** out) {
+    std::lock_guard<std::mutex> lk(p->mu);
+    DevState& d = p->dev[device];
+    if (!d.d_code) {
+        HIPCHK(hipMalloc(&d.d_code, p->code.size() * sizeof(uint32_t)));
+        HIPCHK(hipMemcpy(d.d_code, p->code.data(), p->code.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc(&d.d_params, std::max<size_t>(p->params.size(), 1) * sizeof(float)));
+        HIPCHK(hipMalloc(&d.d_tables, std::max<size_t>(p->tables.size(), 1) * sizeof(float)));
+        if (!p->tables.empty())
+            HIPCHK(hipMemcpy(d.d_tables, p->tables.data(), p->tables.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    if (d.params_version != p->params_version) {
+        if (!p->params.empty())
+            HIPCHK(hipMemcpyAsync(d.d_params, p->params.data(), p->params.size() * sizeof(float),
+                                  hipMemcpyHostToDevice, stream));
+        d.params_version = p->params_version;
+    }
+    *out = &d;
+    return 0;
+}
+
+static inline unsigned blocks_for(long long n, int vec) {
+    return (unsigned)((n + (long long)SDFK_BLOCK * vec - 1) / ((long long)SDFK_BLOCK * vec));
+}
+
+static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long long n, float* d_out, void* stream_,
+               int mode, bool vec_ok) {
+    if (!p) return fail(-1, "null program");
+    if (n < 0) return fail(-1, "negative point count");
+    if (n == 0) return 0;
+    if (mode == SDFK_MODE_AUTO) mode = g_default_mode;
+    hipStream_t stream = (hipStream_t)stream_;
+    int device = 0;
+    HIPCHK(hipGetDevice(&device));
+    DevState* d = nullptr;
+    int rc = ensure_resident(p, device, stream, &d);
+    if (rc) return rc;
+
+    // split into a 4-wide body and a scalar tail
+    long long n4 = vec_ok ? (n / 4) * 4 : 0;
+    long long tail = n - n4;
+
+    std::shared_ptr<SpecKernel> sk;
+    if (mode != SDFK_MODE_INTERPRET) {
+        sk = get_spec(p, device);
+        if (sk->failed) {
+            if (mode == SDFK_MODE_SPECIALIZED || !p->interp_ok)
+                return fail(-3, "specialised kernel unavailable: " + sk->error);
+            static bool warned = false;
+            if (!warned) {
+                fprintf(stderr, "[sdfk] hiprtc specialisation failed, using the interpreter kernel: %s\n",
+                        sk->error.c_str());
+                warned = true;
+            }
+            sk.reset();
+        }
+    }
+    if (!sk && !p->interp_ok)
+        return fail(-4, "program needs more registers than the interpreter kernel has (use the specialised mode)");
+
+    const float* prm = d->d_params;
+    const float* tab = d->d_tables;
+    if (sk) {
+        if (arr) {
+            const float* co = arr->co;
+            long long stride = arr->stride;
+            if (n4) {
+                long long off = 0;
+                void* args[] = {&prm, &tab, &co, &stride, &off, &n4, &d_out};
+                HIPCHK(hipModuleLaunchKernel(sk->v4, blocks_for(n4, 4), 1, 1, SDFK_BLOCK, 1, 1, 0, stream, args,
+                                             nullptr));
+            }
+            if (tail) {
+                long long off = n4;
+                void* args[] = {&prm, &tab, &co, &stride, &off, &tail, &d_out};
+                HIPCHK(hipModuleLaunchKernel(sk->v1, blocks_for(tail, 1), 1, 1, SDFK_BLOCK, 1, 1, 0, stream, args,
+                                             nullptr));
+            }
+        } else {
+            SrcGrid g = *grid;
+            if (n4) {
+                long long off = 0;
+                void* args[] = {&prm, &tab, &g, &off, &n4, &d_out};
+                HIPCHK(hipModuleLaunchKernel(sk->g4, blocks_for(n4, 4), 1, 1, SDFK_BLOCK, 1, 1, 0, stream, args,
+                                             nullptr));
+            }
+            if (tail) {
+                long long off = n4;
+                void* args[] = {&prm, &tab, &g, &off, &tail, &d_out};
+                HIPCHK(hipModuleLaunchKernel(sk->g1, blocks_for(tail, 1), 1, 1, SDFK_BLOCK, 1, 1, 0, stream, args,
+                                             nullptr));
+            }
+        }
+        return 0;
+    }
+    // interpreter
+    const int n_instr = (int)(p->code.size() / 2);
+    const long long zero = 0;
+    if (arr) {
+        if (n4)
+            hipLaunchKernelGGL((sdfk_interp_kernel<4, SrcArray>), dim3(blocks_for(n4, 4)), dim3(SDFK_BLOCK), 0, stream,
+                               d->d_code, n_instr, prm, tab, *arr, zero, n4, d_out, p->result_reg);
+        if (tail)
+            hipLaunchKernelGGL((sdfk_interp_kernel<1, SrcArray>), dim3(blocks_for(tail, 1)), dim3(SDFK_BLOCK), 0,
+                               stream, d->d_code, n_instr, prm, tab, *arr, n4, tail, d_out, p->result_reg);
+    } else {
+        if (n4)
+            hipLaunchKernelGGL((sdfk_interp_kernel<4, SrcGrid>), dim3(blocks_for(n4, 4)), dim3(SDFK_BLOCK), 0, stream,
+                               d->d_code, n_instr, prm, tab, *grid, zero, n4, d_out, p->result_reg);
+        if (tail)
+            hipLaunchKernelGGL((sdfk_interp_kernel<1, SrcGrid>), dim3(blocks_for(tail, 1)), dim3(SDFK_BLOCK), 0,
+                               stream, d->d_code, n_instr, prm, tab, *grid, n4, tail, d_out, p->result_reg);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+extern "C" int sdfk_eval_device(sdfk_program* p, const float* d_co, int64_t n, int64_t row_stride, float* d_out,
+                                void* stream, int mode) {
+    if (!d_co || !d_out) return fail(-1, "sdfk_eval_device: null device pointer");
+    if (row_stride < n) return fail(-1, "sdfk_eval_device: row stride smaller than the point count");
+    SrcArray a = {d_co, (long long)row_stride};
+    bool vec_ok = aligned16(d_co) && aligned16(d_out) && (row_stride % 4 == 0);
+    return run(p, &a, nullptr, n, d_out, stream, mode, vec_ok);
+}
+
+// ---- grids -------------------------------------------------------------------------------------
+extern "C" int sdfk_linspace_f32(double lo, double hi, int64_t n, float* out) {
+    if (n < 0 || (n > 0 && !out)) return fail(-1, "sdfk_linspace_f32: bad arguments");
+    if (n == 0) return 0;
+    if (n == 1) {
+        out[0] = (float)lo;
+        return 0;
+    }
+    const double div = (double)(n - 1);
+    const double delta = hi - lo;
+    const double step = delta / div;
+    for (int64_t i = 0; i < n; ++i) {
+        // numpy: y = arange(n) * step + start  (step != 0) ; y = arange(n)/div * delta + start (step == 0)
+        volatile double t = (step != 0.0) ? (double)i * step : ((double)i / div) * delta;
+        out[i] = (float)(t + lo);
+    }
+    out[n - 1] = (float)hi;
+    return 0;
+}
+
+struct AxisTables {
+    float* d = nullptr;
+    ~AxisTables() {
+        if (d) (void)hipFree(d);
+    }
+};
+
+static int upload_axes(const float* ax0, int64_t n0, const float* ax1, int64_t n1, const float* ax2, int64_t n2,
+                       hipStream_t stream, AxisTables* t, SrcGrid* g, int64_t start) {
+    if (!ax0 || !ax1 || !ax2 || n0 < 1 || n1 < 1 || n2 < 1) return fail(-1, "grid axes missing or empty");
+    if (n1 > 0x7fffffff || n2 > 0x7fffffff) return fail(-1, "grid axis too long");
+    HIPCHK(hipMalloc(&t->d, (size_t)(n0 + n1 + n2) * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(t->d, ax0, (size_t)n0 * sizeof(float), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(t->d + n0, ax1, (size_t)n1 * sizeof(float), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(t->d + n0 + n1, ax2, (size_t)n2 * sizeof(float), hipMemcpyHostToDevice, stream));
+    g->ax0 = t->d;
+    g->ax1 = t->d + n0;
+    g->ax2 = t->d + n0 + n1;
+    g->n1 = (unsigned)n1;
+    g->n2 = (unsigned)n2;
+    g->start = start;
+    return 0;
+}
+
+extern "C" int sdfk_eval_grid(sdfk_program* p, const float* ax0, int64_t n0, const float* ax1, int64_t n1,
+                              const float* ax2, int64_t n2, int64_t start, int64_t count, float* d_out, void* stream,
+                              int mode) {
+    if (!d_out) return fail(-1, "sdfk_eval_grid: null output");
+    if (start < 0 || count < 0 || start + count > n0 * n1 * n2) return fail(-1, "sdfk_eval_grid: range outside the grid");
+    AxisTables t;
+    SrcGrid g;
+    int rc = upload_axes(ax0, n0, ax1, n1, ax2, n2, (hipStream_t)stream, &t, &g, start);
+    if (rc) return rc;
+    rc = run(p, nullptr, &g, count, d_out, stream, mode, aligned16(d_out));
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));  // the axis tables are freed on return
+    return 0;
+}
+
+extern "C" int sdfk_grid_fill(float* d_co, int64_t row_stride, const float* ax0, int64_t n0, const float* ax1,
+                              int64_t n1, const float* ax2, int64_t n2, int64_t start, int64_t count, void* stream) {
+    if (!d_co) return fail(-1, "sdfk_grid_fill: null output");
+    if (row_stride < count) return fail(-1, "sdfk_grid_fill: row stride smaller than count");
+    if (start < 0 || count < 0 || start + count > n0 * n1 * n2) return fail(-1, "sdfk_grid_fill: range outside the grid");
+    if (count == 0) return 0;
+    AxisTables t;
+    SrcGrid g;
+    int rc = upload_axes(ax0, n0, ax1, n1, ax2, n2, (hipStream_t)stream, &t, &g, start);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sdfk_gridfill_kernel, dim3(blocks_for(count, 4)), dim3(SDFK_BLOCK), 0, (hipStream_t)stream, g,
+                       (long long)count, d_co, (long long)row_stride);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+// ---- host-buffer convenience --------------------------------------------------------------------
+extern "C" int sdfk_eval_host(sdfk_program* p, const void* co, int co_dtype, int64_t n, int64_t row_stride, float* out,
+                              int device, int mode) {
+    if (!p) return fail(-1, "null program");
+    if (n < 0 || (n > 0 && (!co || !out))) return fail(-1, "sdfk_eval_host: bad arguments");
+    if (co_dtype != 0 && co_dtype != 1) return fail(-1, "sdfk_eval_host: co_dtype must be 0 (fp32) or 1 (fp64)");
+    if (row_stride < n) return fail(-1, "sdfk_eval_host: row stride smaller than the point count");
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(device));
+    const int64_t chunk = std::min<int64_t>(n, (int64_t)1 << 25);  // 32 Mi points = 512 MiB of device staging
+    const int64_t stride = (chunk + 63) & ~(int64_t)63;
+    float *d_co = nullptr, *d_out = nullptr;
+    HIPCHK(hipMalloc(&d_co, (size_t)stride * 3 * sizeof(float)));
+    if (hipMalloc(&d_out, (size_t)stride * sizeof(float)) != hipSuccess) {
+        (void)hipFree(d_co);
+        return fail(-5, "sdfk_eval_host: out of device memory");
+    }
+    std::vector<float> tmp;
+    if (co_dtype == 1) tmp.resize((size_t)chunk);
+    int rc = 0;
+    for (int64_t s = 0; s < n && rc == 0; s += chunk) {
+        const int64_t m = std::min(chunk, n - s);
+        for (int r = 0; r < 3 && rc == 0; ++r) {
+            const float* srcf;
+            if (co_dtype == 0) {
+                srcf = static_cast<const float*>(co) + r * row_stride + s;
+            } else {
+                const double* sd = static_cast<const double*>(co) + r * row_stride + s;
+                for (int64_t i = 0; i < m; ++i) tmp[(size_t)i] = (float)sd[i];
+                srcf = tmp.data();
+            }
+            if (hipMemcpy(d_co + r * stride, srcf, (size_t)m * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+                rc = fail(-6, "sdfk_eval_host: host-to-device copy failed");
+        }
+        if (rc == 0) rc = sdfk_eval_device(p, d_co, m, stride, d_out, nullptr, mode);
+        if (rc == 0 && hipMemcpy(out + s, d_out, (size_t)m * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(-6, "sdfk_eval_host: device-to-host copy failed");
+    }
+    (void)hipFree(d_co);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+// ---- plumbing -----------------------------------------------------------------------------------
+extern "C" int sdfk_set_device(int device) {
+    HIPCHK(hipSetDevice(device));
+    return 0;
+}
+extern "C" void* sdfk_malloc(size_t bytes) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        fail(-5, std::string("hipMalloc: ") + hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+extern "C" int sdfk_free(void* d_ptr) {
+    HIPCHK(hipFree(d_ptr));
+    return 0;
+}
+extern "C" int sdfk_memcpy_h2d(void* d_dst, const void* src, size_t bytes) {
+    HIPCHK(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" int sdfk_memcpy_d2h(void* dst, const void* d_src, size_t bytes) {
+    HIPCHK(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int sdfk_sync(void* stream) {
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+extern "C" void* sdfk_event_create(void) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) {
+        fail(-7, "hipEventCreate failed");
+        return nullptr;
+    }
+    return e;
+}
+extern "C" int sdfk_event_destroy(void* ev) {
+    HIPCHK(hipEventDestroy((hipEvent_t)ev));
+    return 0;
+}
+extern "C" int sdfk_event_record(void* ev, void* stream) {
+    HIPCHK(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int sdfk_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms) {
+    HIPCHK(hipEventSynchronize((hipEvent_t)ev_stop));
+    HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)ev_start, (hipEvent_t)ev_stop));
+    return 0;
+}
+extern "C" int sdfk_stream_probe(const float* d_co, int64_t n, int64_t row_stride, float* d_out, void* stream) {
+    if (!d_co || !d_out) return fail(-1, "sdfk_stream_probe: null pointer");
+    if (!(aligned16(d_co) && aligned16(d_out) && row_stride % 4 == 0 && n % 4 == 0))
+        return fail(-1, "sdfk_stream_probe: needs 16-byte aligned rows and n % 4 == 0");
+    SrcArray a = {d_co, (long long)row_stride};
+    hipLaunchKernelGGL(sdfk_probe_kernel, dim3(blocks_for(n, 4)), dim3(SDFK_BLOCK), 0, (hipStream_t)stream, a,
+                       (long long)n, d_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}

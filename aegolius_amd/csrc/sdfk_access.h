@@ -1,0 +1,76 @@
+// sdfk_access.h — how a kernel reads its points and writes the field. Shared (like sdfk_device.h)
+// by the interpreter kernel and, as embedded text, by every hiprtc-specialised kernel.
+//
+// HBM layout: coordinates are a C-contiguous (3, N) fp32 array (row 0/1/2 = x/y/z, row pitch
+// `stride` elements), exactly the reference's `co` (C/helper_functions.py:90-91) in fp32; the
+// field is N fp32. One thread owns VEC consecutive points: with VEC = 4 a wave reads 1 KiB per
+// row per instruction (global_load_dwordx4, fully coalesced) and writes 1 KiB.
+#ifndef SDFK_ACCESS_H
+#define SDFK_ACCESS_H
+
+#define SDFK_BLOCK 256
+
+struct SrcArray {  // (3, n) array resident in HBM
+    const float* __restrict__ co;
+    long long stride;
+};
+struct SrcGrid {  // regular grid expanded on the fly from three per-axis tables (generate_grid on device)
+    const float* __restrict__ ax0;
+    const float* __restrict__ ax1;
+    const float* __restrict__ ax2;
+    unsigned n1, n2;
+    long long start;  // flat index of point 0 of this launch:  n = (ix*n1 + iy)*n2 + iz
+};
+
+// block_base : index of the workgroup's first point (wave-uniform), lane_off : threadIdx.x * VEC
+template <int VEC>
+static __device__ __forceinline__ void sdfk_load(const SrcArray& s, long long block_base, unsigned lane_off,
+                                                 V3 (&p)[VEC]) {
+    const long long i = block_base + lane_off;
+    if constexpr (VEC == 4) {
+        const float4 x = *reinterpret_cast<const float4*>(s.co + i);
+        const float4 y = *reinterpret_cast<const float4*>(s.co + s.stride + i);
+        const float4 z = *reinterpret_cast<const float4*>(s.co + 2 * s.stride + i);
+        p[0] = {x.x, y.x, z.x};
+        p[1] = {x.y, y.y, z.y};
+        p[2] = {x.z, y.z, z.z};
+        p[3] = {x.w, y.w, z.w};
+    } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) p[v] = {s.co[i + v], s.co[s.stride + i + v], s.co[2 * s.stride + i + v]};
+    }
+}
+
+// The 64-bit divisions act on wave-uniform values only (scalar unit, once per workgroup); the
+// per-lane part is 32-bit.
+template <int VEC>
+static __device__ __forceinline__ void sdfk_load(const SrcGrid& s, long long block_base, unsigned lane_off,
+                                                 V3 (&p)[VEC]) {
+    const unsigned long long base = (unsigned long long)(s.start + block_base);
+    const unsigned long long row = base / s.n2;
+    const unsigned iz0 = (unsigned)(base - row * s.n2);
+    const unsigned long long ix0 = row / s.n1;
+    const unsigned iy0 = (unsigned)(row - ix0 * s.n1);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const unsigned t = iz0 + lane_off + v;
+        const unsigned cz = t / s.n2;
+        const unsigned iz = t - cz * s.n2;
+        const unsigned ty = iy0 + cz;
+        const unsigned cy = ty / s.n1;
+        const unsigned iy = ty - cy * s.n1;
+        p[v] = {s.ax0[ix0 + cy], s.ax1[iy], s.ax2[iz]};
+    }
+}
+
+template <int VEC>
+static __device__ __forceinline__ void sdfk_store(float* __restrict__ out, long long i, const float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        *reinterpret_cast<float4*>(out + i) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) out[i + k] = v[k];
+    }
+}
+
+#endif  // SDFK_ACCESS_H

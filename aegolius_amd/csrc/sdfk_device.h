@@ -1,0 +1,642 @@
+// sdfk_device.h — per-point SDF math for gfx950, shared verbatim by
+//   * the interpreter kernel (sdfk_interp.hip, compiled by hipcc) and
+//   * every topology-specialised kernel (text of this file is embedded in libsdfk.so and
+//     handed to hiprtc in front of the generated straight-line body),
+// so both paths execute the same fp32 instruction sequences (both are built with
+// -ffp-contract=off; every fused multiply-add below is spelled out).
+//
+// Conventions
+//   V3        : one point (x, y, z) held in VGPRs.
+//   P         : this instruction's slice of the parameter table. It is addressed with
+//               wave-uniform offsets only, so the compiler fetches it with s_load_* through the
+//               scalar data cache into SGPRs — shape parameters never occupy VGPRs or LDS bandwidth.
+//   T         : base of the variable-length tables (poly-lines, point sets, convex pieces).
+//   Host side : every constant that does not depend on the point (reciprocals, sin/cos of fixed
+//               angles, R^T t, half sizes …) is computed in float64 by aegolius_amd/_lower.py
+//               and rounded once to fp32. Divisions by constants therefore appear here as
+//               multiplications by a pre-rounded reciprocal.
+//   Citations : "C/" = Code/spomso/spomso/cores/ of the reference (read-only study copy).
+//
+// No MFMA: this is scalar per-point math; the bound is HBM (16 B/point) for shallow trees and
+// VALU issue for deep ones.
+#ifndef SDFK_DEVICE_H
+#define SDFK_DEVICE_H
+
+#define SDFK_DEV static __device__ __forceinline__
+
+struct V3 { float x, y, z; };
+
+#define SDFK_TWO_PI 6.283185307179586f
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+SDFK_DEV float sd_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// v_sqrt_f32: 1 ulp, quarter rate — instead of the ~10-instruction correctly-rounded expansion.
+SDFK_DEV float sd_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+SDFK_DEV float sd_min(float a, float b) { return __builtin_fminf(a, b); }
+SDFK_DEV float sd_max(float a, float b) { return __builtin_fmaxf(a, b); }
+SDFK_DEV float sd_abs(float a) { return __builtin_fabsf(a); }
+// np.clip(v, lo, hi) == minimum(maximum(v, lo), hi)
+SDFK_DEV float sd_clip(float v, float lo, float hi) { return sd_min(sd_max(v, lo), hi); }
+SDFK_DEV float sd_clip01(float v) { return sd_min(sd_max(v, 0.0f), 1.0f); }
+// np.sign: -1, 0, +1
+SDFK_DEV float sd_sign(float v) { return (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f); }
+SDFK_DEV float sd_len2(float x, float y) { return sd_sqrt(sd_fma(x, x, y * y)); }
+SDFK_DEV float sd_len3(float x, float y, float z) { return sd_sqrt(sd_fma(x, x, sd_fma(y, y, z * z))); }
+SDFK_DEV float sd_dot2(float ax, float ay, float bx, float by) { return sd_fma(ax, bx, ay * by); }
+SDFK_DEV float sd_dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return sd_fma(ax, bx, sd_fma(ay, by, az * bz));
+}
+// np.mod(a, d): floored modulo, result carries the sign of the divisor. inv_d = 1/d (host, f64->f32).
+// One fma recovers a - q*d exactly once q is right; the two fix-ups repair an off-by-one q.
+SDFK_DEV float sd_mod(float a, float d, float inv_d) {
+    float q = __builtin_floorf(a * inv_d);
+    float r = sd_fma(-q, d, a);
+    if (d > 0.0f) {            // wave-uniform: d is a parameter
+        r = (r < 0.0f) ? r + d : r;
+        r = (r >= d) ? r - d : r;
+    } else {
+        r = (r > 0.0f) ? r + d : r;
+        r = (r <= d) ? r - d : r;
+    }
+    return r;
+}
+// distance from p to segment a + t*ba, t in [0,1]; inv = 1/dot(ba,ba)
+SDFK_DEV float sd_seg3_sq(float px, float py, float pz, const float* __restrict__ S) {
+    float pax = px - S[0], pay = py - S[1], paz = pz - S[2];
+    float h = sd_clip01(sd_dot3(pax, pay, paz, S[3], S[4], S[5]) * S[6]);
+    float dx = sd_fma(-S[3], h, pax), dy = sd_fma(-S[4], h, pay), dz = sd_fma(-S[5], h, paz);
+    return sd_fma(dx, dx, sd_fma(dy, dy, dz * dz));
+}
+SDFK_DEV float sd_seg2_sq(float px, float py, const float* __restrict__ S) {
+    float pax = px - S[0], pay = py - S[1];
+    float h = sd_clip01(sd_dot2(pax, pay, S[2], S[3]) * S[4]);
+    float dx = sd_fma(-S[2], h, pax), dy = sd_fma(-S[3], h, pay);
+    return sd_fma(dx, dx, dy * dy);
+}
+
+// =============================================================================================
+// coordinate -> coordinate
+// signature: V3 f(V3 p, const float* P, const float* T, int imm)
+// =============================================================================================
+SDFK_DEV V3 op_movc(V3 p, const float* __restrict__, const float* __restrict__, int) { return p; }
+
+// C/transformations.py:232-242  co' = (R^T co)/s - R^T t.  P = M(9, row major, R^T/s) , c(3) = R^T t
+SDFK_DEV V3 op_xform(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
+    V3 q;
+    q.x = sd_fma(P[0], p.x, sd_fma(P[1], p.y, sd_fma(P[2], p.z, -P[9])));
+    q.y = sd_fma(P[3], p.x, sd_fma(P[4], p.y, sd_fma(P[5], p.z, -P[10])));
+    q.z = sd_fma(P[6], p.x, sd_fma(P[7], p.y, sd_fma(P[8], p.z, -P[11])));
+    return q;
+}
+// R = I, s = 1 (I·co and co/1.0 are exact in the reference): q = p - t.  Also move_sdf C/modifications.py:1283
+SDFK_DEV V3 op_xlate(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
+    V3 q = {p.x - P[0], p.y - P[1], p.z - P[2]};
+    return q;
+}
+// q = O p : the six named shears + shear(), rotate_sdf.  C/modifications.py:579-774, :1323-1324
+SDFK_DEV V3 op_lin3(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
+    V3 q;
+    q.x = sd_fma(P[0], p.x, sd_fma(P[1], p.y, P[2] * p.z));
+    q.y = sd_fma(P[3], p.x, sd_fma(P[4], p.y, P[5] * p.z));
+    q.z = sd_fma(P[6], p.x, sd_fma(P[7], p.y, P[8] * p.z));
+    return q;
+}
+// q = p / k with P[0] = 1/k
+SDFK_DEV V3 op_cscale(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
+    V3 q = {p.x * P[0], p.y * P[0], p.z * P[0]};
+    return q;
+}
+// elongation C/modifications.py:88-93 ; P = ev/2
+SDFK_DEV V3 op_elongate(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
+    V3 q = {p.x - sd_clip(p.x, -P[0], P[0]), p.y - sd_clip(p.y, -P[1], P[1]), p.z - sd_clip(p.z, -P[2], P[2])};
+    return q;
+}
+// revolution C/modifications.py:426-431 ; P = radius
+SDFK_DEV V3 op_revolve(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
+    V3 q = {sd_len2(p.x, p.z) - P[0], p.y, 0.0f};
+    return q;
+}
+// xy <- [[c, s], [-s, c]] xy ; P = (c, s). z untouched.
+SDFK_DEV V3 op_rot2d(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
+    V3 q = {sd_fma(P[0], p.x, P[1] * p.y), sd_fma(-P[1], p.x, P[0] * p.y), p.z};
+    return q;
+}
+// axis_revolution tail C/modifications.py:460-466 (input already rotated in place); P = (c, s, radius)
+SDFK_DEV V3 op_axrev(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
+    float m = sd_len2(p.x, p.z);
+    // qo[:2] = rot.T · (m, y)   with rot.T = [[c, -s], [s, c]]
+    V3 q = {sd_fma(P[0], m, -P[1] * p.y) - P[2], sd_fma(P[1], m, P[0] * p.y), 0.0f};
+    return q;
+}
+SDFK_DEV V3 op_zeroz(V3 p, const float* __restrict__, const float* __restrict__, int) {
+    V3 q = {p.x, p.y, 0.0f};
+    return q;
+}
+// twist C/modifications.py:517-522 ; P = pitch
+SDFK_DEV V3 op_twist(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
+    float s, c;
+    sincosf(P[0] * p.z, &s, &c);
+    V3 q = {sd_fma(c, p.x, -s * p.y), sd_fma(s, p.x, c * p.y), p.z};
+    return q;
+}
+// bend C/modifications.py:546-571 ; P = (R, cos(a/2), sin(a/2), R*a/2, R*sin(a/2), R*(1-cos(a/2)))
+SDFK_DEV V3 op_bend(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
+    float R = P[0], c = P[1], s = P[2];
+    float yr = p.y - R;
+    float phi = atan2f(p.x, -yr);
+    float qx = R * phi;
+    float qy = -R + sd_len2(p.x, yr);
+    if (P[3] <= sd_abs(qx)) {                     // rigid continuation past the bent arc
+        float sg = sd_sign(p.x);
+        float wx = p.x - P[4] * sg;
+        float wy = p.y - P[5];
+        float rx, ry;
+        if (p.x >= 0.0f) { rx = sd_fma(c, wx, s * wy);  ry = sd_fma(-s, wx, c * wy); }
+        else             { rx = sd_fma(c, wx, -s * wy); ry = sd_fma(s, wx, c * wy); }
+        qx = rx + P[3] * sg;
+        qy = ry;
+    }
+    V3 q = {qx, qy, p.z};
+    return q;
+}
+// infinite_repetition C/modifications.py:819-821 ; P = half(3), d(3), 1/d(3)
+SDFK_DEV V3 op_infrep(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
+    V3 q = {sd_mod(p.x + P[0], P[3], P[6]) - P[0], sd_mod(p.y + P[1], P[4], P[7]) - P[1],
+            sd_mod(p.z + P[2], P[5], P[8]) - P[2]};
+    return q;
+}
+// finite_repetition C/modifications.py:846-868 ; P = c(3), d(3), s(3), s/2(3), 1/s(3)
+SDFK_DEV float sd_finrep1(float x, float c, float d, float s, float hs, float inv_s) {
+    float v = sd_abs(x) - c;
+    v = (x < 0.0f) ? -v : v;                      // v -= 2 v (x < 0)
+    float u = sd_mod(x - d, s, inv_s) - hs;
+    return (x >= -d && x <= d) ? u : v;
+}
+SDFK_DEV V3 op_finrep(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
+    V3 q = {sd_finrep1(p.x, P[0], P[3], P[6], P[9], P[12]), sd_finrep1(p.y, P[1], P[4], P[7], P[10], P[13]),
+            sd_finrep1(p.z, P[2], P[5], P[8], P[11], P[14])};
+    return q;
+}
+// symmetry C/modifications.py:948-952 ; imm = axis
+SDFK_DEV V3 op_symmetry(V3 p, const float* __restrict__, const float* __restrict__, int imm) {
+    V3 q = {imm == 0 ? sd_abs(p.x) : p.x, imm == 1 ? sd_abs(p.y) : p.y, imm == 2 ? sd_abs(p.z) : p.z};
+    return q;
+}
+// mirror tail C/modifications.py:990-993 ; P = l/2
+SDFK_DEV V3 op_foldx(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
+    V3 q = {sd_abs(p.x) - P[0], p.y, p.z};
+    return q;
+}
+// rotational_symmetry tail C/modifications.py:1023-1029 ; P = (angle, angle/2, 1/angle, radius)
+SDFK_DEV V3 op_rotsym(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
+    float phi = atan2f(p.y, p.x);
+    phi = (phi < 0.0f) ? SDFK_TWO_PI + phi : phi;
+    phi = sd_mod(phi, P[0], P[2]) - P[1];
+    float r = sd_len2(p.x, p.y);
+    float s, c;
+    sincosf(phi, &s, &c);
+    V3 q = {sd_fma(r, c, -P[3]), r * s, p.z};
+    return q;
+}
+// linear_instancing tail C/modifications.py:1070-1084 ; P = (l/2, lo, hi, l/2-d, s, d, 1/s, n>2)
+SDFK_DEV V3 op_lininst(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
+    float v = sd_abs(p.x) - P[0];
+    v = (p.x < 0.0f) ? -v : v;
+    if (P[7] != 0.0f) {                           // wave-uniform
+        float u = sd_mod(p.x - P[3], P[4], P[6]) - P[5];
+        v = (p.x >= P[1] && p.x <= P[2]) ? u : v;
+    }
+    V3 q = {v, p.y, p.z};
+    return q;
+}
+// curve_instancing family C/modifications.py:1108-1263 ; P = (count, table offset, has_frames)
+// table: per instance centre(3) [frame rows dx,dy,dz (9)]
+SDFK_DEV V3 op_curveinst(V3 p, const float* __restrict__ P, const float* __restrict__ T, int) {
+    int n = (int)P[0];
+    int stride = (P[2] != 0.0f) ? 12 : 3;
+    const float* __restrict__ tab = T + (int)P[1];
+    float best = 3.0e38f;
+    int bi = 0;
+    for (int i = 0; i < n; ++i) {
+        const float* __restrict__ c = tab + i * stride;
+        float dx = p.x - c[0], dy = p.y - c[1], dz = p.z - c[2];
+        float d2 = sd_fma(dx, dx, sd_fma(dy, dy, dz * dz));
+        if (d2 < best) { best = d2; bi = i; }
+    }
+    const float* __restrict__ c = tab + bi * stride;   // per-lane gather (L1/L2 resident table)
+    V3 v = {p.x - c[0], p.y - c[1], p.z - c[2]};
+    if (P[2] != 0.0f) {
+        V3 w = {sd_dot3(c[3], c[4], c[5], v.x, v.y, v.z), sd_dot3(c[6], c[7], c[8], v.x, v.y, v.z),
+                sd_dot3(c[9], c[10], c[11], v.x, v.y, v.z)};
+        return w;
+    }
+    return v;
+}
+
+// =============================================================================================
+// primitives: coordinate -> value
+// signature: float f(V3 p, const float* P, const float* T)
+// =============================================================================================
+// sdf_x/y/z C/sdf_3D.py:13-22 ; P = (offset, axis)
+SDFK_DEV float prim_axis(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    float v = (P[1] == 0.0f) ? p.x : ((P[1] == 1.0f) ? p.y : p.z);
+    return v - P[0];
+}
+// sdf_sphere C/sdf_3D.py:25-27
+SDFK_DEV float prim_sphere(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    return sd_len3(p.x, p.y, p.z) - P[0];
+}
+// sdf_cylinder C/sdf_3D.py:30-37 ; P = (radius, height/2)
+SDFK_DEV float prim_cylinder(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    float d0 = sd_len2(p.x, p.y) - P[0];
+    float d1 = sd_abs(p.z) - P[1];
+    float t1 = sd_min(sd_max(d0, d1), 0.0f);
+    float t2 = sd_len2(sd_max(d0, 0.0f), sd_max(d1, 0.0f));
+    return t1 + t2;
+}
+// sdf_box C/sdf_3D.py:40-47 ; P = size/2
+SDFK_DEV float prim_box(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    float qx = sd_abs(p.x) - P[0], qy = sd_abs(p.y) - P[1], qz = sd_abs(p.z) - P[2];
+    float t1 = sd_len3(sd_max(qx, 0.0f), sd_max(qy, 0.0f), sd_max(qz, 0.0f));
+    float t2 = sd_min(sd_max(qx, sd_max(qy, qz)), 0.0f);
+    return t1 + t2;
+}
+// sdf_torus C/sdf_3D.py:50-53 ; P = (R, r)
+SDFK_DEV float prim_torus(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    float a = sd_len2(p.x, p.y) - P[0];
+    return sd_len2(a, p.z) - P[1];
+}
+// sdf_chainlink C/sdf_3D.py:56-61 ; P = (R, r, length/2)  (length as passed to sdf_chainlink)
+SDFK_DEV float prim_chainlink(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    float x = p.x - sd_clip(p.x, -P[2], P[2]);
+    float a = sd_len2(x, p.y) - P[0];
+    return sd_len2(a, p.z) - P[1];
+}
+// sdf_braid C/sdf_3D.py:64-75 ; P = (length/2, R, r, pitch)
+SDFK_DEV float prim_braid(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    float s, c;
+    sincosf(P[3] * p.z, &s, &c);
+    // co[:2] = rot[0]*x + rot[1]*y with rot = [[c, s], [-s, c]]  ->  x' = c x - s y ; y' = s x + c y
+    float x = sd_fma(c, p.x, -s * p.y);
+    float y = sd_fma(s, p.x, c * p.y);
+    float z = p.z - sd_clip(p.z, -P[0], P[0]);
+    float a = sd_len2(x, z) - P[1];
+    return sd_len2(a, y) - P[2];
+}
+// shared by arcs / sectors: rotate xy by the mid angle with [[c, s], [-s, c]]
+SDFK_DEV void sd_rotmid(float x, float y, float c, float s, float* ox, float* oy) {
+    *ox = sd_fma(c, x, s * y);
+    *oy = sd_fma(-s, x, c * y);
+}
+// sdf_arc_3d C/sdf_3D.py:78-96 ; P = (R, r, cos mid, sin mid, |end - mid|)
+SDFK_DEV float prim_arc3d(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    float x, y;
+    sd_rotmid(p.x, p.y, P[2], P[3], &x, &y);
+    y = sd_abs(y);
+    float psi = sd_clip(atan2f(y, x), 0.0f, P[4]);
+    float s, c;
+    sincosf(psi, &s, &c);
+    return sd_len3(x - P[0] * c, y - P[0] * s, p.z) - P[1];
+}
+// sdf_plane C/sdf_3D.py:99-102 ; P = (n̂(3), offset)
+SDFK_DEV float prim_plane(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    return sd_dot3(p.x, p.y, p.z, P[0], P[1], P[2]) - P[3];
+}
+// sudf_plane C/sdf_3D.py:105-108 ; P = (n̂(3), thickness/2)
+SDFK_DEV float prim_uplane(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    return sd_abs(sd_dot3(p.x, p.y, p.z, P[0], P[1], P[2])) - P[3];
+}
+// sdf_segment_3d C/sdf_3D.py:111-118 ; P = a(3), ba(3), 1/dot(ba,ba)
+SDFK_DEV float prim_segment3(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    return sd_sqrt(sd_seg3_sq(p.x, p.y, p.z, P));
+}
+// sdf_cone C/sdf_3D.py:121-136 ; P = (q0 = H tan a, q1 = -H, z offset, 1/dot(q,q), 1/q0)
+SDFK_DEV float prim_cone(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    float q0 = P[0], q1 = P[1];
+    float w0 = sd_len2(p.x, p.y);
+    float w1 = p.z - P[2];
+    float t1 = sd_clip01(sd_dot2(w0, w1, q0, q1) * P[3]);
+    float ax = sd_fma(-q0, t1, w0), ay = sd_fma(-q1, t1, w1);
+    float t2 = sd_clip01(w0 * P[4]);
+    float bx = sd_fma(-q0, t2, w0), by = w1 - q1;
+    float d = sd_min(sd_fma(ax, ax, ay * ay), sd_fma(bx, bx, by * by));
+    float s = sd_max(-sd_fma(w0, q1, -w1 * q0), -(w1 - q1));
+    return sd_sqrt(d) * sd_sign(s);
+}
+// sdf_infinite_cone / sdf_oriented_infinite_cone C/sdf_3D.py:139-157 ; P = (sin a, cos a, oriented)
+SDFK_DEV float prim_infcone(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    float q0 = sd_len2(p.x, p.y), q1 = -p.z;
+    float t = sd_max(sd_dot2(q0, q1, P[0], P[1]), 0.0f);
+    float d = sd_len2(sd_fma(-P[0], t, q0), sd_fma(-P[1], t, q1));
+    if (P[2] != 0.0f) d = (sd_fma(q0, P[1], -q1 * P[0]) < 0.0f) ? -d : d;
+    return d;
+}
+// common tail of sdf_solid_angle C/sdf_3D.py:168-183 and sdf_sector C/sdf_2D.py:114-129
+// (x, y) already rotated / folded ; P = (radius, cos mid, sin mid, half width, cos hw, sin hw)
+SDFK_DEV float sd_sector_tail(float x, float y, const float* __restrict__ P) {
+    float phi = atan2f(y, x);
+    float psi = sd_clip(phi, 0.0f, P[3]);
+    float s, c;
+    sincosf(psi, &s, &c);
+    float length = sd_len2(x - P[0] * c, y - P[0] * s);
+    float t = sd_clip(sd_dot2(x, y, P[4], P[5]), 0.0f, P[0]);
+    float m = sd_len2(sd_fma(-P[4], t, x), sd_fma(-P[5], t, y));
+    float out = sd_min(m, length);
+    return (sd_len2(x, y) <= P[0] && phi <= P[3]) ? -out : out;
+}
+SDFK_DEV float prim_solidangle(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    float x, y;
+    sd_rotmid(p.x, p.y, P[1], P[2], &x, &y);
+    return sd_sector_tail(x, sd_len2(y, p.z), P);
+}
+// sdf_triangle_3d C/sdf_3D.py:186-214
+// P = a b c (9) | s1 s2 s3 (9) | cross(s_i, normal) (9) | normal (3) | 1/dot(s_i,s_i) (3) | 1/dot(n,n)
+SDFK_DEV float sd_edge_sq(float cx, float cy, float cz, const float* __restrict__ s, float inv) {
+    float h = sd_clip01(sd_dot3(s[0], s[1], s[2], cx, cy, cz) * inv);
+    float dx = sd_fma(s[0], h, -cx), dy = sd_fma(s[1], h, -cy), dz = sd_fma(s[2], h, -cz);
+    return sd_fma(dx, dx, sd_fma(dy, dy, dz * dz));
+}
+SDFK_DEV float prim_triangle3(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    float ax = p.x - P[0], ay = p.y - P[1], az = p.z - P[2];
+    float bx = p.x - P[3], by = p.y - P[4], bz = p.z - P[5];
+    float cx = p.x - P[6], cy = p.y - P[7], cz = p.z - P[8];
+    float m = sd_sign(sd_dot3(P[18], P[19], P[20], ax, ay, az)) + sd_sign(sd_dot3(P[21], P[22], P[23], bx, by, bz)) +
+              sd_sign(sd_dot3(P[24], P[25], P[26], cx, cy, cz));
+    float e;
+    if (m < 2.0f) {
+        e = sd_min(sd_min(sd_edge_sq(ax, ay, az, P + 9, P[30]), sd_edge_sq(bx, by, bz, P + 12, P[31])),
+                   sd_edge_sq(cx, cy, cz, P + 15, P[32]));
+    } else {
+        float d = sd_dot3(P[27], P[28], P[29], ax, ay, az);
+        e = d * d * P[33];
+    }
+    return sd_sqrt(e);
+}
+// sdf_quad_3d C/sdf_3D.py:217-250
+// P = a b c d (12) | s1..s4 (12) | cross(s_i, normal) (12) | normal (3) | 1/dot(s_i,s_i) (4) | 1/dot(n,n)
+SDFK_DEV float prim_quad3(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    float ax = p.x - P[0], ay = p.y - P[1], az = p.z - P[2];
+    float bx = p.x - P[3], by = p.y - P[4], bz = p.z - P[5];
+    float cx = p.x - P[6], cy = p.y - P[7], cz = p.z - P[8];
+    float dx = p.x - P[9], dy = p.y - P[10], dz = p.z - P[11];
+    float m = sd_sign(sd_dot3(P[24], P[25], P[26], ax, ay, az)) + sd_sign(sd_dot3(P[27], P[28], P[29], bx, by, bz)) +
+              sd_sign(sd_dot3(P[30], P[31], P[32], cx, cy, cz)) + sd_sign(sd_dot3(P[33], P[34], P[35], dx, dy, dz));
+    float e;
+    if (m < 3.0f) {
+        float e12 = sd_min(sd_edge_sq(ax, ay, az, P + 12, P[39]), sd_edge_sq(bx, by, bz, P + 15, P[40]));
+        float e43 = sd_min(sd_edge_sq(dx, dy, dz, P + 21, P[42]), sd_edge_sq(cx, cy, cz, P + 18, P[41]));
+        e = sd_min(e43, e12);
+    } else {
+        float d = sd_dot3(P[36], P[37], P[38], ax, ay, az);
+        e = d * d * P[43];
+    }
+    return sd_sqrt(e);
+}
+// sdf_segmented_line_3d C/sdf_3D.py:264-271 ; P = (segment count, table offset) ; table rows a(3) ba(3) inv
+SDFK_DEV float prim_segline3(V3 p, const float* __restrict__ P, const float* __restrict__ T) {
+    int n = (int)P[0];
+    const float* __restrict__ tab = T + (int)P[1];
+    float best = 1.0e32f;                                   // (1e16)^2
+    for (int i = 0; i < n; ++i) best = sd_min(best, sd_seg3_sq(p.x, p.y, p.z, tab + 7 * i));
+    return sd_sqrt(best);
+}
+// KDTree nearest-point distance C/sdf_3D.py:253-261,274-286 ; P = (point count, table offset) ; rows xyz
+SDFK_DEV float prim_nearest3(V3 p, const float* __restrict__ P, const float* __restrict__ T) {
+    int n = (int)P[0];
+    const float* __restrict__ tab = T + (int)P[1];
+    float best = 3.0e38f;
+    for (int i = 0; i < n; ++i) {
+        float dx = p.x - tab[3 * i], dy = p.y - tab[3 * i + 1], dz = p.z - tab[3 * i + 2];
+        best = sd_min(best, sd_fma(dx, dx, sd_fma(dy, dy, dz * dz)));
+    }
+    return sd_sqrt(best);
+}
+
+// ---- 2-D primitives (z ignored) -------------------------------------------------------------
+// sdf_circle C/sdf_2D.py:12-14
+SDFK_DEV float prim_circle(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    return sd_len2(p.x, p.y) - P[0];
+}
+// sdf_neu_circle C/sdf_2D.py:17-19 ; P = (radius, ord, kind) kind: 0 general p-norm, 1 = +inf, 2 = -inf, 3 = ord 0
+SDFK_DEV float prim_neucircle(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    float ax = sd_abs(p.x), ay = sd_abs(p.y);
+    float l;
+    if (P[2] == 1.0f) l = sd_max(ax, ay);
+    else if (P[2] == 2.0f) l = sd_min(ax, ay);
+    else if (P[2] == 3.0f) l = ((ax != 0.0f) ? 1.0f : 0.0f) + ((ay != 0.0f) ? 1.0f : 0.0f);
+    else if (P[1] == 1.0f) l = ax + ay;
+    else if (P[1] == 2.0f) l = sd_len2(ax, ay);
+    else l = powf(powf(ax, P[1]) + powf(ay, P[1]), 1.0f / P[1]);
+    return l - P[0];
+}
+// sdf_box_2d C/sdf_2D.py:22-28 ; P = size/2
+SDFK_DEV float prim_box2(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    float dx = sd_abs(p.x) - P[0], dy = sd_abs(p.y) - P[1];
+    return sd_len2(sd_max(dx, 0.0f), sd_max(dy, 0.0f)) + sd_min(sd_max(dx, dy), 0.0f);
+}
+// sdf_segment_2d C/sdf_2D.py:31-38 ; P = a(2), ba(2), 1/dot(ba,ba)
+SDFK_DEV float prim_segment2(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    return sd_sqrt(sd_seg2_sq(p.x, p.y, P));
+}
+// sdf_rounded_box_2d C/sdf_2D.py:41-57 ; P = size/2 (2), rounding (4)
+SDFK_DEV float prim_rbox2(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    float r = P[2];
+    r = (p.x > 0.0f) ? P[3] : r;
+    r = (p.y > 0.0f) ? P[4] : r;
+    r = (p.x < 0.0f && p.y > 0.0f) ? P[5] : r;
+    float dx = (sd_abs(p.x) - P[0]) + r, dy = (sd_abs(p.y) - P[1]) + r;
+    float o = sd_len2(sd_max(dx, 0.0f), sd_max(dy, 0.0f));
+    float u = sd_min(sd_max(dx, dy), 0.0f) - r;
+    return o + u;
+}
+// sdf_triangle_2d C/sdf_2D.py:60-82 ; P = p0 p1 p2 (6) | e0 e1 e2 (6) | 1/dot(e_i,e_i) (3) | s
+SDFK_DEV float prim_triangle2(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    float dmin = 3.0e38f, cmin = 3.0e38f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float vx = p.x - P[2 * i], vy = p.y - P[2 * i + 1];
+        float ex = P[6 + 2 * i], ey = P[7 + 2 * i];
+        float h = sd_clip01(sd_dot2(vx, vy, ex, ey) * P[12 + i]);
+        float qx = sd_fma(-ex, h, vx), qy = sd_fma(-ey, h, vy);
+        dmin = sd_min(dmin, sd_fma(qx, qx, qy * qy));
+        cmin = sd_min(cmin, P[15] * sd_fma(vx, ey, -vy * ex));
+    }
+    return -sd_sqrt(dmin) * sd_sign(cmin);
+}
+// sdf_arc C/sdf_2D.py:85-103 ; P = (radius, cos mid, sin mid, |end - mid|)
+SDFK_DEV float prim_arc2(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    float x, y;
+    sd_rotmid(p.x, p.y, P[1], P[2], &x, &y);
+    y = sd_abs(y);
+    float psi = sd_clip(atan2f(y, x), 0.0f, P[3]);
+    float s, c;
+    sincosf(psi, &s, &c);
+    return sd_len2(x - P[0] * c, y - P[0] * s);
+}
+// sdf_sector C/sdf_2D.py:105-129 ; P as sd_sector_tail
+SDFK_DEV float prim_sector(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    float x, y;
+    sd_rotmid(p.x, p.y, P[1], P[2], &x, &y);
+    return sd_sector_tail(x, sd_abs(y), P);
+}
+// sdf_inf_sector C/sdf_2D.py:132-150 ; P = (cos mid, sin mid, half width, cos hw, sin hw)
+SDFK_DEV float prim_infsector(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    float x, y;
+    sd_rotmid(p.x, p.y, P[0], P[1], &x, &y);
+    y = sd_abs(y);
+    float phi = atan2f(y, x);
+    float t = sd_max(sd_dot2(x, y, P[3], P[4]), 0.0f);
+    float m = sd_len2(sd_fma(-P[3], t, x), sd_fma(-P[4], t, y));
+    return sd_sign(phi - P[2]) * m;
+}
+// sdf_ngon C/sdf_2D.py:153-177 ; P = (radius, alpha, 1/alpha, t0 = -cos β, t1 = sin β, n0 = sin β, n1 = cos β, l)
+SDFK_DEV float prim_ngon(V3 p, const float* __restrict__ P, const float* __restrict__) {
+    float phi = atan2f(p.y, p.x);
+    phi = (phi < 0.0f) ? SDFK_TWO_PI + phi : phi;
+    phi = sd_mod(phi, P[1], P[2]);
+    float r = sd_len2(p.x, p.y);
+    float s, c;
+    sincosf(phi, &s, &c);
+    float qx = c * r - P[0], qy = s * r;
+    float h = sd_clip(sd_dot2(qx, qy, P[3], P[4]), 0.0f, P[7]);
+    float len = sd_len2(sd_fma(-P[3], h, qx), sd_fma(-P[4], h, qy));
+    return len * sd_sign(sd_dot2(qx, qy, P[5], P[6]));
+}
+// sdf_segmented_line_2d / edge loop of sdf_polygon_2d C/sdf_2D.py:191-208 ; table rows a(2) ba(2) inv
+SDFK_DEV float prim_segline2(V3 p, const float* __restrict__ P, const float* __restrict__ T) {
+    int n = (int)P[0];
+    const float* __restrict__ tab = T + (int)P[1];
+    float best = 1.0e32f;
+    for (int i = 0; i < n; ++i) best = sd_min(best, sd_seg2_sq(p.x, p.y, tab + 5 * i));
+    return sd_sqrt(best);
+}
+// KDTree nearest-point distance in the plane C/sdf_2D.py:180-188,214-224 ; table rows xy
+SDFK_DEV float prim_nearest2(V3 p, const float* __restrict__ P, const float* __restrict__ T) {
+    int n = (int)P[0];
+    const float* __restrict__ tab = T + (int)P[1];
+    float best = 3.0e38f;
+    for (int i = 0; i < n; ++i) {
+        float dx = p.x - tab[2 * i], dy = p.y - tab[2 * i + 1];
+        best = sd_min(best, sd_fma(dx, dx, dy * dy));
+    }
+    return sd_sqrt(best);
+}
+// interior_polygon C/triangulation_functions.py:355-430 : -1 inside any convex piece, +1 outside.
+// P = (piece count, table offset) ; table: per piece  K, then K rows (px, py, nx, ny)
+SDFK_DEV float prim_polysign(V3 p, const float* __restrict__ P, const float* __restrict__ T) {
+    int np_ = (int)P[0];
+    const float* __restrict__ tab = T + (int)P[1];
+    float interior = 1.0f;
+    for (int j = 0; j < np_; ++j) {
+        int k = (int)tab[0];
+        float sp = -1.0f;
+        for (int i = 0; i < k; ++i) {
+            const float* __restrict__ h = tab + 1 + 4 * i;
+            sp = sd_max(sp, sd_sign(sd_dot2(p.x - h[0], p.y - h[1], h[2], h[3])));
+        }
+        interior = (sp <= 0.0f) ? -1.0f : interior;
+        tab += 1 + 4 * k;
+    }
+    return interior;
+}
+// ParametricCurve.shape() C/geom_2d.py:432-452: product over the outline's edges whose x-range
+// [lx, ux) contains the point of sign(dot(p - p_i, n_i)). P = (edge count, table offset);
+// table rows (px, py, nx, ny, lx, ux)
+SDFK_DEV float prim_shapesign(V3 p, const float* __restrict__ P, const float* __restrict__ T) {
+    int n = (int)P[0];
+    const float* __restrict__ tab = T + (int)P[1];
+    float interior = 1.0f;
+    for (int i = 0; i < n; ++i) {
+        const float* __restrict__ h = tab + 6 * i;
+        float s = sd_sign(sd_dot2(p.x - h[0], p.y - h[1], h[2], h[3]));
+        interior = (p.x >= h[4] && p.x < h[5]) ? interior * s : interior;
+    }
+    return interior;
+}
+// |z| - h/2 of extrusion C/modifications.py:493 ; P = h/2
+SDFK_DEV float prim_zslab(V3 p, const float* __restrict__ P, const float* __restrict__) { return sd_abs(p.z) - P[0]; }
+
+// =============================================================================================
+// value -> value     signature: float f(float v, const float* P)
+// =============================================================================================
+SDFK_DEV float val_scale(float v, const float* __restrict__ P) { return P[0] * v; }
+SDFK_DEV float val_subc(float v, const float* __restrict__ P) { return v - P[0]; }
+// rounding_cs C/modifications.py:141 : scale*f - r   (two roundings, as the reference)
+SDFK_DEV float val_affine(float v, const float* __restrict__ P) { return P[0] * v - P[1]; }
+SDFK_DEV float val_abs(float v, const float* __restrict__) { return sd_abs(v); }
+SDFK_DEV float val_neg(float v, const float* __restrict__) { return -v; }
+SDFK_DEV float val_sign(float v, const float* __restrict__) { return sd_sign(v); }
+SDFK_DEV float val_onion(float v, const float* __restrict__ P) { return sd_abs(v) - P[0]; }
+SDFK_DEV float val_concentric(float v, const float* __restrict__ P) { return sd_abs(v - P[0]); }
+// sigmoid_falloff / positive_sigmoid_falloff C/post_processing.py:380-412 ; P = (A, 4/w, shift)
+SDFK_DEV float val_sigmoid(float v, const float* __restrict__ P) {
+    float e = expf((v - P[2]) * P[1]);
+    return P[0] * (1.0f / (1.0f + e));
+}
+// capped_exponential :415-429 ; P = (A, -4/w)
+SDFK_DEV float val_capexp(float v, const float* __restrict__ P) { return P[0] * sd_min(expf(v * P[1]), 1.0f); }
+// hard_binarization :432-446
+SDFK_DEV float val_hardbin(float v, const float* __restrict__ P) { return (v <= P[0]) ? 1.0f : 0.0f; }
+// linear_falloff :449-463 ; P = (A, 1/w)
+SDFK_DEV float val_linfall(float v, const float* __restrict__ P) { return sd_clip01(1.0f - v * P[1]) * P[0]; }
+// relu :466-477 ; P = 1/w
+SDFK_DEV float val_relu(float v, const float* __restrict__ P) { return sd_max(v * P[0], 0.0f); }
+// smooth_relu :480-500 ; P = (1/w, b)
+SDFK_DEV float val_smoothrelu(float v, const float* __restrict__ P) {
+    float u = v * P[0];
+    return (u + sd_sqrt(sd_fma(u, u, P[1]))) * 0.5f;
+}
+// slowstart :503-523 ; P = (1/w, b/w, sqrt(b/w)*ground)
+SDFK_DEV float val_slowstart(float v, const float* __restrict__ P) {
+    float u = sd_max(v * P[0], 0.0f);
+    return sd_sqrt(sd_fma(u, u, P[1])) - P[2];
+}
+// gaussian_boundary / gaussian_falloff :526-558 ; P = (A, 1/w, clamp_at_zero)
+SDFK_DEV float val_gauss(float v, const float* __restrict__ P) {
+    float u = (P[2] != 0.0f) ? sd_max(v, 0.0f) : v;
+    u = u * P[1];
+    return P[0] * expf(-4.0f * (u * u));
+}
+
+// =============================================================================================
+// (value, value) -> value     signature: float f(float a, float b, const float* P)
+// =============================================================================================
+SDFK_DEV float cmb_mul(float a, float b, const float* __restrict__) { return a * b; }
+SDFK_DEV float cmb_add(float a, float b, const float* __restrict__) { return a + b; }
+SDFK_DEV float cmb_diff(float a, float b, const float* __restrict__) { return a - b; }
+SDFK_DEV float cmb_min(float a, float b, const float* __restrict__) { return sd_min(a, b); }
+SDFK_DEV float cmb_max(float a, float b, const float* __restrict__) { return sd_max(a, b); }
+SDFK_DEV float cmb_subtract(float a, float b, const float* __restrict__) { return sd_max(a, -b); }
+// smoothmin_poly2 C/combine.py:12-18 ; P = (w, 1/w, w/4) ; w == 0 -> plain min
+SDFK_DEV float cmb_smin2(float a, float b, const float* __restrict__ P) {
+    float m = sd_min(a, b);
+    if (P[0] == 0.0f) return m;                               // wave-uniform
+    float h = sd_max(P[0] - sd_abs(a - b), 0.0f) * P[1];
+    return sd_fma(-(h * h), P[2], m);
+}
+// smoothmin_poly3 C/combine.py:20-26 ; P = (w, 1/w, w/6)
+SDFK_DEV float cmb_smin3(float a, float b, const float* __restrict__ P) {
+    float m = sd_min(a, b);
+    if (P[0] == 0.0f) return m;
+    float h = sd_max(P[0] - sd_abs(a - b), 0.0f) * P[1];
+    return sd_fma(-(h * h * h), P[2], m);
+}
+SDFK_DEV float cmb_smax3(float a, float b, const float* __restrict__ P) { return -cmb_smin3(-a, -b, P); }
+SDFK_DEV float cmb_ssub3(float a, float b, const float* __restrict__ P) { return -cmb_smin3(-a, b, P); }
+// smoothmax_boltz C/combine.py:29-34 ; P = 1/w. Both exponentials are shifted by max(a,b)/w, which
+// cancels between numerator and denominator (identical in exact arithmetic, no fp32 overflow).
+SDFK_DEV float cmb_boltz(float a, float b, const float* __restrict__ P) {
+    float xa = a * P[0], xb = b * P[0];
+    float m = sd_max(xa, xb);
+    float ea = expf(xa - m), eb = expf(xb - m);
+    return sd_fma(a, ea, b * eb) / (ea + eb);
+}
+SDFK_DEV float cmb_boltzsub(float a, float b, const float* __restrict__ P) { return cmb_boltz(a, -b, P); }
+// extrusion tail C/modifications.py:494-496 ; a = d(x, y, 0), b = |z| - h/2
+SDFK_DEV float cmb_extrude(float a, float b, const float* __restrict__) {
+    return sd_min(sd_max(a, b), 0.0f) + sd_len2(sd_max(a, 0.0f), sd_max(b, 0.0f));
+}
+
+#endif  // SDFK_DEVICE_H

@@ -1,0 +1,106 @@
+/* sdfk.h — C-ABI of libsdfk.so, the MI355X (gfx950) SDF grid-evaluation engine.
+ *
+ * The reference (peterropac/Aegolius = SPOMSO, pure Python) has no FFI seam; its seam is the
+ * Python object protocol `GenericGeometry.create(co) -> (N,)`
+ * (reference Code/spomso/spomso/cores/geom.py:29-43). The Python layer in aegolius_amd/ keeps that
+ * protocol and lowers the expression tree it records to the register-machine program consumed here.
+ * Each entry point below names the reference interface whose work it replaces.
+ *
+ * Conventions: plain C types only; 0 = success, negative = error (text via sdfk_last_error(),
+ * thread-local); the caller owns every host buffer for the duration of a call; the library owns
+ * programs and the device memory it allocates; programs are immutable after creation and may be
+ * shared between threads; "device pointers" are ordinary HIP device addresses (for example
+ * torch.Tensor.data_ptr() of a ROCm tensor) and `stream` is a hipStream_t passed as void*
+ * (NULL = the default stream).
+ */
+#ifndef SDFK_H
+#define SDFK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDFK_ABI_VERSION 1
+
+/* evaluation modes for sdfk_eval_device / sdfk_set_default_mode */
+#define SDFK_MODE_AUTO 0        /* topology-specialised kernel (hiprtc), built on first use and cached */
+#define SDFK_MODE_INTERPRET 1   /* generic register-machine interpreter kernel */
+#define SDFK_MODE_SPECIALIZED 2 /* as AUTO but fail instead of falling back if hiprtc fails */
+
+typedef struct sdfk_program sdfk_program;
+
+int sdfk_abi_version(void);
+/* number of visible HIP devices (0 when there is no GPU; never an error) */
+int sdfk_device_count(void);
+const char* sdfk_last_error(void);
+
+/* ---- programs --------------------------------------------------------------------------------
+ * A program is the lowered form of one expression tree: what the reference holds as nested Python
+ * closures (cores/modifications.py:55-63 `modified_object`, cores/combine.py:129-138) plus the
+ * Euclidean transform of every node (cores/transformations.py:232-242).
+ *   code   : 2 words per instruction: {op | a<<8 | b<<16 | c<<24, parameter offset}
+ *            (opcodes: aegolius_amd/csrc/sdfk_ops.def)
+ *   params : fp32 parameter table (host-precomputed constants)
+ *   tables : fp32 variable-length tables (poly-lines, point sets, convex pieces); may be NULL/0
+ *   result_reg : value register that holds the field after the last instruction
+ * The program is validated (opcodes, register indices, parameter ranges) — a malformed program is
+ * rejected here, never launched. */
+sdfk_program* sdfk_program_create(const uint32_t* code, size_t n_instr, const float* params, size_t n_params,
+                                  const float* tables, size_t n_tables, int result_reg);
+void sdfk_program_destroy(sdfk_program* prog);
+/* Replace the parameter values of a program in place (same topology, new shape parameters). */
+int sdfk_program_set_params(sdfk_program* prog, const float* params, size_t n_params);
+/* Generated HIP source of the specialised kernel (for inspection / tests); NULL on error. */
+const char* sdfk_program_source(sdfk_program* prog);
+/* Compile the specialised kernel for gfx950 with hiprtc without needing a GPU (build check).
+ * Returns 0 and the code-object size in *code_size. */
+int sdfk_program_compile_check(sdfk_program* prog, size_t* code_size);
+
+/* ---- evaluation ------------------------------------------------------------------------------
+ * Replaces GenericGeometry.create / propagate (cores/geom.py:29-60) for one whole tree:
+ * out[i] = tree(co[0][i], co[1][i], co[2][i]).
+ * d_co  : device pointer to a (3, n) fp32 array; row r starts at d_co + r*row_stride (elements).
+ * d_out : device pointer to n fp32.
+ * Uses 16-byte vector loads when d_co, d_out and row_stride allow (16-B aligned, stride % 4 == 0). */
+int sdfk_eval_device(sdfk_program* prog, const float* d_co, int64_t n, int64_t row_stride, float* d_out,
+                     void* stream, int mode);
+/* Host-buffer convenience: stages co (dtype 0 = fp32, 1 = fp64; (3, n) with row stride in elements)
+ * through device memory in chunks, evaluates and copies the fp32 field back. */
+int sdfk_eval_host(sdfk_program* prog, const void* co, int co_dtype, int64_t n, int64_t row_stride, float* out,
+                   int device, int mode);
+/* Evaluate directly on a regular grid without materialising coordinates (4 B/point of traffic):
+ * point `start + i` of the flat index n = (ix*n1 + iy)*n2 + iz takes (ax0[ix], ax1[iy], ax2[iz]).
+ * Replaces generate_grid + create (cores/helper_functions.py:23-93). Axis tables are HOST pointers. */
+int sdfk_eval_grid(sdfk_program* prog, const float* ax0, int64_t n0, const float* ax1, int64_t n1, const float* ax2,
+                   int64_t n2, int64_t start, int64_t count, float* d_out, void* stream, int mode);
+void sdfk_set_default_mode(int mode);
+
+/* ---- grid builder -----------------------------------------------------------------------------
+ * numpy.linspace(lo, hi, n) in float64 (step = (hi-lo)/(n-1); y[i] = i*step + lo; y[n-1] = hi),
+ * rounded to fp32 — the per-axis table of generate_grid (cores/helper_functions.py:56-88). */
+int sdfk_linspace_f32(double lo, double hi, int64_t n, float* out);
+/* Fill a device (3, count) coordinate slab for flat indices [start, start+count) of the grid. */
+int sdfk_grid_fill(float* d_co, int64_t row_stride, const float* ax0, int64_t n0, const float* ax1, int64_t n1,
+                   const float* ax2, int64_t n2, int64_t start, int64_t count, void* stream);
+
+/* ---- device memory / timing plumbing (so callers need no HIP binding of their own) ------------ */
+int sdfk_set_device(int device);
+void* sdfk_malloc(size_t bytes);
+int sdfk_free(void* d_ptr);
+int sdfk_memcpy_h2d(void* d_dst, const void* src, size_t bytes);
+int sdfk_memcpy_d2h(void* dst, const void* d_src, size_t bytes);
+int sdfk_sync(void* stream);
+void* sdfk_event_create(void);
+int sdfk_event_destroy(void* ev);
+int sdfk_event_record(void* ev, void* stream);
+int sdfk_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms); /* synchronises on ev_stop */
+/* plain (3,n)->(n) streaming kernel out = x+y+z with the same access pattern: measured HBM ceiling */
+int sdfk_stream_probe(const float* d_co, int64_t n, int64_t row_stride, float* d_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDFK_H */

@@ -1,0 +1,68 @@
+"""Golden-vector generator — runs ONLY in the build container, where the reference is mounted
+read-only at /root/reference. It imports the real SPOMSO NumPy implementation (the parity target),
+evaluates every scene of tests/scenes.py on the shared input cloud and stores inputs + float64
+outputs as small fixtures next to this script. Nothing of the reference travels: the fixtures are
+data (coordinates in, field values out).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/generate_golden.py
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import scipy
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, "/root/reference/Code/spomso")
+sys.dont_write_bytecode = True
+
+import spomso.cores as ref  # noqa: E402  (the real reference)
+import scenes  # noqa: E402
+
+
+def main():
+    co = scenes.input_points()
+    out = {"inputs": co.astype(np.float32)}
+    meta = {"numpy": np.__version__, "scipy": scipy.__version__, "reference": "peterropac/Aegolius SPOMSO 1.4.0",
+            "n_points": int(co.shape[1]), "scenes": {}}
+    failures = []
+    for name, build in scenes.SCENES.items():
+        try:
+            with contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):
+                obj = build(ref)
+                field = np.asarray(obj.create(co.copy()), dtype=np.float64)
+        except Exception as exc:  # noqa: BLE001
+            failures.append((name, repr(exc)))
+            continue
+        assert field.shape == (co.shape[1],), (name, field.shape)
+        out["scene/" + name] = field
+        meta["scenes"][name] = {"rotation_matrix": np.asarray(obj.rotation_matrix).tolist(),
+                                "center": np.asarray(obj.center, dtype=float).tolist(), "scale": float(obj.scale),
+                                "nan": int(np.isnan(field).sum())}
+    # grid builder
+    grids = {"g3_even": ((2, 2, 2), (8, 8, 8)), "g3_mixed": ((2.0, 3.0, 1.0), (5, 8, 7)), "g3_scalar_res": ((4, 4, 4), 6),
+             "g2": ((10, 6), (8, 5)), "g2_scalar_res": ((3, 3), 4), "g1": ((5,), (6,))}
+    for gname, (size, res) in grids.items():
+        g, r = ref.generate_grid(size, res)
+        out["grid/" + gname] = g
+        meta.setdefault("grids", {})[gname] = {"size": list(np.atleast_1d(size).astype(float)),
+                                              "resolution": [int(x) for x in np.atleast_1d(res)],
+                                              "returned_resolution": [int(x) for x in r]}
+    # reshape helper
+    meta["smarter_reshape"] = {"129_cubed": list(ref.smarter_reshape(np.zeros(9 ** 3), 8).shape),
+                               "2d": list(ref.smarter_reshape(np.zeros(9 * 5), (8, 5)).shape)}
+    np.savez_compressed(os.path.join(HERE, "golden_scenes.npz"), **out)
+    with open(os.path.join(HERE, "golden_meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("scenes: %d ok, %d failed" % (len(meta["scenes"]), len(failures)))
+    for name, err in failures:
+        print("  FAILED %-40s %s" % (name, err[:200]))
+    return 1 if failures else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

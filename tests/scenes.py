@@ -1,0 +1,500 @@
+"""Scene builders shared by the golden-vector generator (run against the real reference in the build
+container) and by the parity tests (run against aegolius_amd + the oracle).
+
+Every builder takes `ns`, a namespace with the `spomso.cores` layout — the reference package itself
+(`import spomso.cores as ns`) or the drop-in (`import aegolius_amd.cores as ns`) — and returns a
+geometry object. The same Python text therefore drives both implementations: that is the drop-in
+claim under test.
+"""
+import numpy as np
+
+SCENES = {}
+# scenes whose value jumps (sign / binarisation / cell boundaries): fp32 may legitimately take the other
+# branch for a point sitting within rounding of the jump — the GPU tests count such points instead of
+# bounding them
+DISCONTINUOUS = set()
+
+
+def scene(name, discontinuous=False):
+    def deco(fn):
+        assert name not in SCENES, name
+        SCENES[name] = fn
+        if discontinuous:
+            DISCONTINUOUS.add(name)
+        return fn
+    return deco
+
+
+def placed(obj, angle=0.7, axis=(0.3, -0.5, 0.8), move=(0.15, -0.1, 0.2), scale=None):
+    obj.rotate(angle, axis)
+    obj.move(move)
+    if scale is not None:
+        obj.set_scale(scale)
+    return obj
+
+
+# -------------------------------------------------------------------------------------------------
+# inputs
+# -------------------------------------------------------------------------------------------------
+def input_points():
+    """(3, 2042) float64 holding fp32-representable values: 1024 random points in [-2,2]^3, a 9^3 grid
+    over [-1.5,1.5]^3 (exact zeros and symmetry planes) and a 17^2 planar grid with z = 0."""
+    rng = np.random.default_rng(20240607)
+    rnd = rng.uniform(-2.0, 2.0, size=(3, 1024))
+    ax = np.linspace(-1.5, 1.5, 9)
+    g3 = np.asarray(np.meshgrid(ax, ax, ax, indexing="ij")).reshape(3, -1)
+    ax2 = np.linspace(-1.6, 1.6, 17)
+    g2 = np.zeros((3, 17 * 17))
+    g2[:2] = np.asarray(np.meshgrid(ax2, ax2, indexing="ij")).reshape(2, -1)
+    co = np.concatenate([rnd, g3, g2], axis=1)
+    return co.astype(np.float32).astype(np.float64)
+
+
+# -------------------------------------------------------------------------------------------------
+# curves used by parametric shapes / instancing
+# -------------------------------------------------------------------------------------------------
+def helix(t, radius, pitch):
+    return np.asarray((radius * np.cos(t), radius * np.sin(t), pitch * t))
+
+
+def ellipse(t, a, b):
+    return np.asarray((a * np.cos(t), b * np.sin(t)))
+
+
+def ellipse3(t, a, b):
+    return np.asarray((a * np.cos(t), b * np.sin(t), 0 * t))
+
+
+ZIGZAG3 = np.asarray([[-0.9, -0.3, 0.2, 0.8, 0.4], [-0.5, 0.6, -0.4, 0.5, -0.7], [-0.2, 0.3, 0.1, -0.3, 0.4]])
+ZIGZAG2 = np.asarray([[-0.9, -0.3, 0.2, 0.8, 0.4], [-0.5, 0.6, -0.4, 0.5, -0.7], [0.0, 0.0, 0.0, 0.0, 0.0]])
+CONVEX_POLY = np.asarray([[-0.8, 0.7, 0.9, 0.1, -0.7], [-0.6, -0.7, 0.3, 0.9, 0.4], [0, 0, 0, 0, 0]], dtype=float)
+CONCAVE_POLY = np.asarray([[-0.9, 0.0, 0.9, 0.6, 0.0, -0.6], [-0.7, -0.2, -0.7, 0.8, 0.1, 0.8], [0, 0, 0, 0, 0, 0]],
+                          dtype=float)
+CLOUD3 = np.random.default_rng(5).uniform(-1.0, 1.0, size=(3, 37))
+
+
+# -------------------------------------------------------------------------------------------------
+# primitives, each under a general rotation + translation (and some under a scale)
+# -------------------------------------------------------------------------------------------------
+_PRIMS = {
+    "x": lambda ns: ns.X(0.2), "y": lambda ns: ns.Y(-0.3), "z": lambda ns: ns.Z(0.1),
+    "sphere": lambda ns: ns.Sphere(0.5),
+    "cylinder": lambda ns: ns.Cylinder(0.4, 1.1),
+    "infinite_cylinder": lambda ns: ns.InfiniteCylinder(0.45),
+    "box": lambda ns: ns.Box(0.9, 0.6, 0.4),
+    "torus": lambda ns: ns.Torus(0.6, 0.17),
+    "chainlink": lambda ns: ns.ChainLink(0.4, 0.1, 0.9),
+    "braid": lambda ns: ns.Braid(1.6, 0.3, 0.08, 2.5),
+    "arc3d": lambda ns: ns.Arc3D(0.7, 0.12, 0.3, 2.4),
+    "plane": lambda ns: ns.Plane((0.2, -0.4, 0.9), 0.3),
+    "oriented_plane": lambda ns: ns.OrientedPlane((0.5, 0.1, -0.7), 0.25),
+    "line": lambda ns: ns.Line((-0.4, 0.3, -0.5), (0.6, -0.2, 0.7)),
+    "cone": lambda ns: ns.Cone(0.9, np.pi / 7),
+    "infinite_cone": lambda ns: ns.InfiniteCone(np.pi / 5),
+    "oriented_infinite_cone": lambda ns: ns.OrientedInfiniteCone(np.pi / 6),
+    "solid_angle": lambda ns: ns.geom_3d.SolidAngle(0.8, 0.2, 1.5),
+    "triangle3d": lambda ns: ns.Triangle3D((-0.5, -0.4, 0.1), (0.7, -0.2, -0.3), (0.1, 0.8, 0.4)),
+    "quad": lambda ns: ns.Quad((-0.6, -0.5, 0.0), (0.6, -0.6, 0.2), (0.7, 0.5, 0.0), (-0.5, 0.6, -0.2)),
+    "segmented_line3d_closed": lambda ns: ns.SegmentedLine3D(ZIGZAG3, closed=True),
+    "segmented_curve3d": lambda ns: ns.SegmentedParametricCurve3D(ZIGZAG3, (0, 5, 23)),
+    "segmented_curve3d_closed": lambda ns: ns.SegmentedParametricCurve3D(ZIGZAG3, (0, 5, 23), closed=True),
+    "parametric_curve3d": lambda ns: ns.ParametricCurve3D(helix, (0.6, 0.1), (0, 2 * np.pi, 41)),
+    "parametric_curve3d_closed": lambda ns: ns.ParametricCurve3D(helix, (0.6, 0.1), (0, 2 * np.pi, 41), closed=True),
+    "point_cloud3d": lambda ns: ns.geom_3d.PointCloud3D(CLOUD3),
+    # 2-D
+    "circle": lambda ns: ns.Circle(0.55),
+    "neu_circle_3": lambda ns: ns.NEUCircle(0.6, 3),
+    "neu_circle_1": lambda ns: ns.NEUCircle(0.6, 1),
+    "neu_circle_inf": lambda ns: ns.NEUCircle(0.6, np.inf),
+    "ngon": lambda ns: ns.NGon(0.6, 5),
+    "rectangle": lambda ns: ns.Rectangle(0.9, 0.5),
+    "rounded_rectangle": lambda ns: ns.RoundedRectangle(1.0, 0.7, (0.1, 0.05, 0.2, 0.0)),
+    "segment": lambda ns: ns.Segment((-0.5, -0.2, 0.0), (0.6, 0.4, 0.0)),
+    "triangle": lambda ns: ns.Triangle(np.asarray((-0.6, -0.4)), np.asarray((0.7, -0.3)), np.asarray((0.0, 0.8))),
+    "sector": lambda ns: ns.Sector(0.8, 0.3, 1.9),
+    "infinite_sector": lambda ns: ns.InfiniteSector(0.4, 1.6),
+    "arc": lambda ns: ns.Arc(0.7, 0.2, 2.6),
+    "polygon_convex": lambda ns: ns.Polygon(CONVEX_POLY.copy()),
+    "polygon_concave": lambda ns: ns.Polygon(CONCAVE_POLY.copy()),
+    "segmented_line2d": lambda ns: ns.SegmentedLine(ZIGZAG2),
+    "segmented_line2d_closed": lambda ns: ns.SegmentedLine(ZIGZAG2, closed=True),
+    "segmented_curve2d": lambda ns: ns.SegmentedParametricCurve(ZIGZAG2, (0, 5, 19)),
+    "segmented_curve2d_closed": lambda ns: ns.SegmentedParametricCurve(ZIGZAG2, (0, 5, 19), closed=True),
+    "parametric_curve2d": lambda ns: ns.ParametricCurve(ellipse, (0.8, 0.5), (0, 2 * np.pi, 33)),
+    "parametric_curve2d_closed": lambda ns: ns.ParametricCurve(ellipse, (0.8, 0.5), (0, 5.5, 33), closed=True),
+    "point_cloud2d": lambda ns: ns.PointCloud2D(CLOUD3),
+}
+_DISCONT_PRIMS = {"polygon_convex", "polygon_concave", "oriented_infinite_cone", "infinite_sector", "solid_angle",
+                  "sector", "cone", "triangle", "ngon"}
+
+for _name, _make in _PRIMS.items():
+    scene("prim_" + _name, _name in _DISCONT_PRIMS)(lambda ns, m=_make: placed(m(ns)))
+    scene("prim_" + _name + "_raw", _name in _DISCONT_PRIMS)(lambda ns, m=_make: m(ns))
+
+scene("prim_sphere_scaled")(lambda ns: placed(ns.Sphere(0.5), scale=1.7))
+scene("prim_box_scaled_int")(lambda ns: placed(ns.Box(0.9, 0.6, 0.4), scale=2))
+scene("prim_torus_translated")(lambda ns: placed(ns.Torus(0.6, 0.17), angle=0.0, axis=(0, 0, 1)))
+
+
+@scene("prim_sphere_set_ops")
+def _(ns):
+    s = ns.Sphere(0.4)
+    s.set_location((0.3, 0.1))
+    s.set_rotation(0.9, (0.0, 1.0, 0.0))
+    s.rescale(1.5)
+    s.rotate(0.4, (1, 0, 0))
+    return s
+
+
+@scene("prim_box_rotate_matrix")
+def _(ns):
+    b = ns.Box(0.8, 0.5, 0.3)
+    b.set_rotation(0.6, (0.0, 0.0, 1.0))
+    b.move((0.1, 0.2, -0.1))
+    return b
+
+
+# -------------------------------------------------------------------------------------------------
+# modifications
+# -------------------------------------------------------------------------------------------------
+def _mod_scene(name, base, apply, discontinuous=False, place=True):
+    def build(ns):
+        obj = base(ns)
+        apply(obj, ns)
+        return placed(obj) if place else obj
+    scene("mod_" + name, discontinuous)(build)
+
+
+_box = lambda ns: ns.Box(0.6, 0.3, 0.2)          # noqa: E731
+_sph = lambda ns: ns.Sphere(0.4)                 # noqa: E731
+_rect = lambda ns: ns.Rectangle(0.5, 0.3)        # noqa: E731
+_circ = lambda ns: ns.Circle(0.3)                # noqa: E731
+_tor = lambda ns: ns.Torus(0.4, 0.12)            # noqa: E731
+
+_mod_scene("elongation", _box, lambda o, ns: o.elongation((0.4, 0.0, 0.1)))
+_mod_scene("rounding", _box, lambda o, ns: o.rounding(0.07))
+_mod_scene("rounding_cs", _box, lambda o, ns: o.rounding_cs(0.05, 0.6))
+_mod_scene("boundary", _sph, lambda o, ns: o.boundary())
+_mod_scene("invert", _box, lambda o, ns: o.invert())
+_mod_scene("sign", _box, lambda o, ns: o.sign(), True)
+_mod_scene("onion", _sph, lambda o, ns: o.onion(0.05))
+_mod_scene("concentric", _sph, lambda o, ns: o.concentric(0.2))
+_mod_scene("revolution", _rect, lambda o, ns: o.revolution(0.6))
+_mod_scene("axis_revolution", _rect, lambda o, ns: o.axis_revolution(0.6, 0.4))
+_mod_scene("extrusion", _circ, lambda o, ns: o.extrusion(0.7))
+_mod_scene("twist", _box, lambda o, ns: o.twist(np.pi / 2))
+_mod_scene("bend", _box, lambda o, ns: o.bend(1.5, np.pi / 3))
+_mod_scene("bend_tight", lambda ns: ns.Box(1.6, 0.2, 0.2), lambda o, ns: o.bend(0.5, 2.0))
+for _sh in ("shear_xz", "shear_yz", "shear_xy", "shear_zy", "shear_yx", "shear_zx"):
+    _mod_scene(_sh, _box, lambda o, ns, s=_sh: getattr(o, s)(0.35))
+for _sa, _fa in ((0, 1), (0, 2), (1, 0), (1, 2), (2, 0), (2, 1)):
+    _mod_scene("shear_%d%d" % (_sa, _fa), _box, lambda o, ns, a=_sa, f=_fa: o.shear(0.3, a, f))
+_mod_scene("infinite_repetition", _sph, lambda o, ns: o.infinite_repetition((1.1, 1.3, 0.9)), True)
+_mod_scene("finite_repetition", lambda ns: ns.Sphere(0.12),
+           lambda o, ns: o.finite_repetition((2.0, 1.5, 1.2), (4, 3, 2)), True)
+_mod_scene("finite_repetition_rescaled", lambda ns: ns.Sphere(0.4),
+           lambda o, ns: o.finite_repetition_rescaled((2.0, 1.5, 1.2), (4, 3, 2), (0.8, 0.8, 0.8), (0.1, 0.1, 0.1)),
+           True)
+_mod_scene("symmetry_x", lambda ns: placed(ns.Box(0.5, 0.3, 0.2), move=(0.4, 0.2, 0.1)),
+           lambda o, ns: o.symmetry(0), place=False)
+_mod_scene("symmetry_z", lambda ns: placed(ns.Box(0.5, 0.3, 0.2), move=(0.4, 0.2, 0.3)),
+           lambda o, ns: o.symmetry(2), place=False)
+_mod_scene("symmetry_noop", _box, lambda o, ns: o.symmetry(4))
+_mod_scene("mirror", _sph, lambda o, ns: o.mirror((-0.6, 0.1, 0.0), (0.5, 0.4, 0.3)))
+_mod_scene("rotational_symmetry", lambda ns: ns.Sphere(0.15), lambda o, ns: o.rotational_symmetry(5, 0.7, 0.3), True)
+_mod_scene("linear_instancing", lambda ns: ns.Sphere(0.12),
+           lambda o, ns: o.linear_instancing(5, (-0.8, -0.2, 0.1), (0.9, 0.3, -0.2)), True)
+_mod_scene("linear_instancing_2", lambda ns: ns.Sphere(0.12),
+           lambda o, ns: o.linear_instancing(2, (-0.8, -0.2, 0.1), (0.9, 0.3, -0.2)))
+_mod_scene("curve_instancing", lambda ns: ns.Sphere(0.1),
+           lambda o, ns: o.curve_instancing(helix, (0.6, 0.15), (0, 2 * np.pi, 7)), True)
+_mod_scene("aligned_curve_instancing", lambda ns: ns.Box(0.3, 0.1, 0.05),
+           lambda o, ns: o.aligned_curve_instancing(ellipse3, (0.8, 0.5), (0.1, 6.0, 7)), True)
+_mod_scene("fully_aligned_curve_instancing", lambda ns: ns.Box(0.3, 0.1, 0.05),
+           lambda o, ns: o.fully_aligned_curve_instancing(helix, (0.6, 0.15), (0.1, 6.0, 7)), True)
+_mod_scene("move_sdf", _box, lambda o, ns: o.move_sdf((0.2, -0.3, 0.1)))
+_mod_scene("scale_sdf", _box, lambda o, ns: o.scale_sdf(1.6))
+_mod_scene("rotate_sdf", _box, lambda o, ns: o.rotate_sdf(
+    np.asarray([[np.cos(0.5), -np.sin(0.5), 0.0], [np.sin(0.5), np.cos(0.5), 0.0], [0.0, 0.0, 1.0]])))
+_mod_scene("sigmoid_falloff", _sph, lambda o, ns: o.sigmoid_falloff(2.0, 0.3))
+_mod_scene("positive_sigmoid_falloff", _sph, lambda o, ns: o.positive_sigmoid_falloff(2.0, 0.3))
+_mod_scene("capped_exponential", _sph, lambda o, ns: o.capped_exponential(1.5, 0.4))
+_mod_scene("hard_binarization", _sph, lambda o, ns: o.hard_binarization(0.0), True)
+_mod_scene("linear_falloff", _sph, lambda o, ns: o.linear_falloff(1.5, 0.5))
+_mod_scene("relu", _sph, lambda o, ns: o.relu(0.5))
+_mod_scene("smooth_relu", _sph, lambda o, ns: o.smooth_relu(0.1, 0.5, 0.02))
+_mod_scene("slowstart", _sph, lambda o, ns: o.slowstart(0.1, 0.5, 0.02))
+_mod_scene("slowstart_noground", _sph, lambda o, ns: o.slowstart(0.1, 0.5, 0.02, ground=False))
+_mod_scene("gaussian_boundary", _sph, lambda o, ns: o.gaussian_boundary(1.2, 0.4))
+_mod_scene("gaussian_falloff", _sph, lambda o, ns: o.gaussian_falloff(1.2, 0.4))
+_mod_scene("polygon_from_line", lambda ns: ns.SegmentedLine(CONCAVE_POLY.copy(), closed=True),
+           lambda o, ns: o.polygon(), True)
+_mod_scene("shape_from_curve", lambda ns: ns.ParametricCurve(ellipse, (0.8, 0.5), (0, 2 * np.pi, 33), closed=True),
+           lambda o, ns: o.shape(), True)
+
+
+@scene("mod_recover_volume", True)
+def _(ns):
+    b = ns.Box(0.6, 0.4, 0.3)
+    inside = b.sign(direct=True)
+    b.boundary()
+    b.recover_volume(inside)
+    return placed(b)
+
+
+@scene("mod_define_volume", True)
+def _(ns):
+    s = ns.Sphere(0.5)
+    other = ns.Box(0.5, 0.5, 0.5)
+    s.boundary()
+    s.define_volume(other.sign(direct=True), ((0.5, 0.5, 0.5),))
+    return placed(s)
+
+
+@scene("mod_displacement_node")
+def _(ns):
+    s = ns.Sphere(0.5)
+    bump = ns.Sphere(0.2)
+    bump.move((0.4, 0.0, 0.0))
+    bump.gaussian_boundary(0.1, 0.3)
+    s.displacement(bump.propagate, ())
+    return placed(s)
+
+
+@scene("mod_displacement_sdf_function")
+def _(ns):
+    s = ns.Box(0.6, 0.4, 0.3)
+    s.displacement(ns.sdf_sphere, (0.3,))
+    return placed(s)
+
+
+# ---- in-place aliasing: the second field sees the coordinates the inner chain mutated ----
+@scene("alias_symmetry_displacement")
+def _(ns):
+    s = ns.Sphere(0.5)
+    s.move_sdf((0.2, 0.0, 0.0))
+    s.symmetry(0)
+    s.displacement(ns.sdf_x, (0.0,))       # evaluates to |x| (mutated array), not x
+    return placed(s)
+
+
+@scene("alias_rotsym_recover", True)
+def _(ns):
+    s = ns.Sphere(0.2)
+    s.rotational_symmetry(4, 0.5, 0.1)
+    s.rounding(0.02)
+    s.recover_volume(ns.sdf_y)             # sees the rotated / folded coordinates
+    return placed(s)
+
+
+@scene("alias_axis_revolution_displacement")
+def _(ns):
+    r = ns.Rectangle(0.4, 0.2)
+    r.axis_revolution(0.5, 0.3)
+    r.displacement(ns.sdf_x, (0.1,))       # sees xy rotated in place, but not the revolved array
+    return placed(r)
+
+
+@scene("alias_symmetry_in_child_not_visible")
+def _(ns):
+    a = ns.Sphere(0.3)
+    a.symmetry(0)
+    b = ns.Box(0.4, 0.3, 0.2)
+    b.move((0.3, 0.1, 0.0))
+    u = ns.CombineGeometry("UNION2").combine(a, b)   # b must see the untouched coordinates
+    u.displacement(ns.sdf_x, (0.0,))
+    return placed(u)
+
+
+@scene("alias_nested_two_field", True)
+def _(ns):
+    s = ns.Sphere(0.45)
+    s.symmetry(1)
+    s.displacement(ns.sdf_y, (0.0,))
+    s.recover_volume(ns.sdf_y)
+    return placed(s)
+
+
+@scene("frozen_node_chain")
+def _(ns):
+    base = placed(ns.Box(0.5, 0.3, 0.2))
+    frozen = ns.GenericGeometry(base.propagate)
+    frozen.twist(1.1)
+    frozen.symmetry(0)
+    return placed(frozen, angle=0.4, axis=(1, 0, 0), move=(0.0, 0.1, 0.0))
+
+
+@scene("modified_object_as_sdf")
+def _(ns):
+    b = ns.Box(0.5, 0.4, 0.3)
+    b.rounding(0.05)
+    g = ns.GenericGeometry(b.modified_object, (0.7, 0.2, 0.3))   # same chain, other parameters
+    return placed(g)
+
+
+# -------------------------------------------------------------------------------------------------
+# combiners
+# -------------------------------------------------------------------------------------------------
+def _pair(ns):
+    a = placed(ns.Sphere(0.45), move=(-0.15, 0.05, 0.0))
+    b = placed(ns.Box(0.7, 0.4, 0.5), angle=0.5, axis=(1, 1, 0), move=(0.25, -0.05, 0.1))
+    return a, b
+
+
+for _op in ("UNION2", "UNION", "SUBTRACT2", "INTERSECT2", "INTERSECT", "SUM", "DIFFERENCE"):
+    scene("combine_" + _op)(lambda ns, op=_op: ns.CombineGeometry(op).combine(*_pair(ns)))
+for _op in ("SMOOTH_UNION2_2", "SMOOTH_UNION2", "SMOOTH_INTERSECT2", "SMOOTH_INTERSECT2_BOLTZMANN",
+            "SMOOTH_SUBTRACT2", "SMOOTH_SUBTRACT2_BOLTZMANN"):
+    scene("combine_" + _op)(lambda ns, op=_op: ns.CombineGeometry(op).combine_parametric(*_pair(ns), parameters=0.2))
+scene("combine_SMOOTH_UNION2_zero_width")(
+    lambda ns: ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(*_pair(ns), parameters=0.0))
+
+
+@scene("combine_UNION_nary")
+def _(ns):
+    objs = [placed(ns.Sphere(0.2), move=(0.5 * np.cos(k), 0.5 * np.sin(k), 0.1 * k)) for k in range(6)]
+    return placed(ns.CombineGeometry("UNION").combine(*objs), scale=1.3)
+
+
+@scene("combine_INTERSECT_nary")
+def _(ns):
+    objs = [placed(ns.Sphere(0.7), move=(0.2 * np.cos(k), 0.2 * np.sin(k), 0.0)) for k in range(4)]
+    return ns.CombineGeometry("INTERSECT").combine(*objs)
+
+
+@scene("combine_modified_result")
+def _(ns):
+    u = ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(*_pair(ns), parameters=0.15)
+    u.onion(0.03)
+    u.elongation((0.2, 0.1, 0.0))
+    return placed(u, angle=1.1, axis=(0, 1, 0), move=(0.1, 0.0, -0.1), scale=0.8)
+
+
+# -------------------------------------------------------------------------------------------------
+# tree-level scenes: the five BASELINE configs at reduced resolution, plus example-like ones
+# -------------------------------------------------------------------------------------------------
+def _cfg2_prims(ns, rng, count):
+    makers = [lambda: ns.Sphere(0.3), lambda: ns.Box(0.5, 0.4, 0.3), lambda: ns.Cylinder(0.2, 0.6),
+              lambda: ns.Torus(0.3, 0.1), lambda: ns.Cone(0.6, np.pi / 8)]
+    out = []
+    for k in range(count):
+        o = makers[k % 5]()
+        angle = float(rng.uniform(0, np.pi))
+        axis = rng.normal(0, 1, 3)
+        o.rotate(angle, axis)
+        o.move(rng.uniform(-0.7, 0.7, 3))
+        out.append(o)
+    return out
+
+
+def cfg2_tree(ns, seed=1234, count=10, width=0.1):
+    """BASELINE configs[1] / north-star: left-deep chain of SMOOTH_UNION2 over `count` primitives."""
+    prims = _cfg2_prims(ns, np.random.default_rng(seed), count)
+    acc = prims[0]
+    for p in prims[1:]:
+        acc = ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(acc, p, parameters=width)
+    return acc
+
+
+def cfg3_chain(ns):
+    """BASELINE configs[2]: deep modification chain."""
+    b = ns.Box(0.6, 0.3, 0.2)
+    b.elongation((0.4, 0, 0.1))
+    b.twist(np.pi / 2)
+    b.bend(1.5, np.pi / 3)
+    b.infinite_repetition((2, 2, 2))
+    b.rotate(0.3, (0, 1, 1))
+    b.move((0.1, -0.2, 0.05))
+    return b
+
+
+def cfg4_scene2d(ns, seed=7, count=50):
+    """BASELINE configs[3]: n-ary UNION of 2-D primitives with onion / rounding."""
+    rng = np.random.default_rng(seed)
+    makers = [lambda: ns.Circle(0.4), lambda: ns.Rectangle(0.8, 0.5), lambda: ns.NGon(0.4, 6),
+              lambda: ns.RoundedRectangle(0.8, 0.6, (0.1, 0.05, 0.15, 0.0))]
+    objs = []
+    for k in range(count):
+        o = makers[k % 4]()
+        if k % 2 == 0:
+            o.onion(0.03)
+        else:
+            o.rounding(0.05)
+        o.rotate(float(rng.uniform(0, np.pi)), (0, 0, 1))
+        o.move((float(rng.uniform(-4, 4)), float(rng.uniform(-4, 4)), 0))
+        objs.append(o)
+    return ns.CombineGeometry("UNION").combine(*objs)
+
+
+def cfg5_tree(ns, seed=2049):
+    """BASELINE configs[4]: 20 primitives, 3 levels."""
+    prims = _cfg2_prims(ns, np.random.default_rng(seed), 20)
+    groups = []
+    for g in range(5):
+        acc = prims[4 * g]
+        for p in prims[4 * g + 1:4 * g + 4]:
+            acc = ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(acc, p, parameters=0.1)
+        groups.append(acc)
+    union = ns.CombineGeometry("UNION").combine(*groups[:4])
+    return ns.CombineGeometry("SUBTRACT2").combine(union, groups[4])
+
+
+scene("tree_cfg1_sphere")(lambda ns: ns.Sphere(0.5))
+scene("tree_cfg2_smooth_union10")(cfg2_tree)
+scene("tree_cfg3_mod_chain", True)(cfg3_chain)
+scene("tree_cfg4_union50_2d", True)(cfg4_scene2d)
+scene("tree_cfg5_three_level")(cfg5_tree)
+
+
+@scene("tree_pawn_like")
+def _(ns):
+    body = ns.Cone(1.2, np.pi / 9)
+    body.move((0, 0, 0.2))
+    head = ns.Sphere(0.25)
+    head.move((0, 0, 0.55))
+    base = ns.Cylinder(0.45, 0.15)
+    base.rounding(0.03)
+    base.move((0, 0, -0.7))
+    collar = ns.Torus(0.2, 0.05)
+    collar.move((0, 0, 0.3))
+    t = ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(body, head, parameters=0.1)
+    t = ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(t, base, parameters=0.2)
+    t = ns.CombineGeometry("UNION2").combine(t, collar)
+    cut = ns.Box(2.0, 2.0, 0.3)
+    cut.move((0, 0, -0.95))
+    return ns.CombineGeometry("SUBTRACT2").combine(t, cut)
+
+
+@scene("tree_chip_like")
+def _(ns):
+    body = ns.Box(1.2, 0.8, 0.2)
+    body.rounding_cs(0.04, 1.2)
+    pin = ns.Box(0.08, 0.3, 0.05)
+    pin.move((0.0, 0.5, 0.0))
+    pins = ns.GenericGeometry(pin.propagate, ())
+    pins.symmetry(1)
+    pins.finite_repetition((1.0, 3.0, 1.0), (5, 1, 1))
+    pins.move((0.0, 0.0, -0.05))
+    return placed(ns.CombineGeometry("UNION2").combine(body, pins), angle=0.3, axis=(1, 0, 0), move=(0, 0, 0.1))
+
+
+@scene("tree_rings_2d")
+def _(ns):
+    rings = []
+    for k in range(5):
+        c = ns.Circle(0.3)
+        c.onion(0.03)
+        c.move((-0.7 + 0.35 * k, 0.15 * (-1) ** k, 0))
+        rings.append(c)
+    return ns.CombineGeometry("UNION").combine(*rings)
+
+
+@scene("tree_deep_right")
+def _(ns):
+    """Right-deep nesting: exercises the value-register stack."""
+    rng = np.random.default_rng(99)
+    prims = _cfg2_prims(ns, rng, 6)
+    acc = prims[-1]
+    for p in reversed(prims[:-1]):
+        acc = ns.CombineGeometry("SMOOTH_UNION2_2").combine_parametric(p, acc, parameters=0.12)
+    return acc

@@ -1,0 +1,48 @@
+"""Developer tool: evaluate every scene on the GPU (both kernel flavours) and print the deviation
+from the golden vectors. Not part of the product or the test-suite."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import scenes  # noqa: E402
+import aegolius_amd  # noqa: E402
+import aegolius_amd.cores as ns  # noqa: E402
+from aegolius_amd import _engine  # noqa: E402
+
+
+def main():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_scenes.npz"))
+    co = g["inputs"].astype(np.float64)
+    worst = []
+    t0 = time.time()
+    for name, build in scenes.SCENES.items():
+        ref = g["scene/" + name]
+        row = [name]
+        outs = []
+        for mode in (_engine.MODE_INTERPRET, _engine.MODE_SPECIALIZED):
+            aegolius_amd.config.mode = mode
+            try:
+                out = build(ns).create(co).astype(np.float64)
+            except Exception as exc:  # noqa: BLE001
+                row.append("EXC " + repr(exc)[:120])
+                continue
+            outs.append(out)
+            both_nan = np.isnan(ref) & np.isnan(out)
+            err = np.abs(out - ref) / np.maximum(1.0, np.abs(ref))
+            err[both_nan] = 0
+            nbad = int((~(err <= 1e-6)).sum())
+            row.append("max %.2e bad %4d" % (np.nanmax(err), nbad))
+        if len(outs) == 2:
+            same = np.array_equal(outs[0], outs[1], equal_nan=True)
+            row.append("interp==spec" if same else "INTERP!=SPEC (%d)" % int((outs[0] != outs[1]).sum()))
+        print("%-42s %s" % (row[0], " | ".join(row[1:])), flush=True)
+    print("total %.1fs" % (time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()
