@@ -18,6 +18,12 @@ PARAMETRIC_OPS = {"SMOOTH_UNION2_2": "SMIN2", "SMOOTH_UNION2": "SMIN3", "SMOOTH_
 _NONPARAMETRIC_ORDER = ["UNION2", "UNION", "SUBTRACT2", "INTERSECT2", "INTERSECT", "SUM", "DIFFERENCE"]
 
 
+class UnknownOperation(SyntaxError, TypeError):
+    """The reference means to raise SyntaxError(msg, hint) for an unknown operation name (reference
+    cores/combine.py:125-127, 150-152); because the hint is a plain string, CPython rejects that
+    constructor call and what callers actually see is a TypeError. This class is both."""
+
+
 class CombineGeometry:
     """Combination operations on scalar fields.
 
@@ -50,14 +56,14 @@ class CombineGeometry:
 
     def combine(self, *combined_objects):
         if self.operation_type not in self.operations:
-            raise SyntaxError(f"{self.operation_type} is not an implemented non-parametric operation.",
-                              f"Possible operations are {list(self.operations)}")
+            raise UnknownOperation(f"{self.operation_type} is not an implemented non-parametric operation. "
+                                   f"Possible operations are {list(self.operations)}")
         self._combined_geometry = CombineSDF(self, combined_objects, parametric=False)
         return GenericGeometry(self._combined_geometry, ())
 
     def combine_parametric(self, *combined_objects, parameters):
         if self.operation_type not in self.parametric_operations:
-            raise SyntaxError(f"{self.operation_type} is not an implemented parametric operation.",
-                              f"Possible parametric operations are {list(self.parametric_operations)}")
+            raise UnknownOperation(f"{self.operation_type} is not an implemented parametric operation. "
+                                   f"Possible parametric operations are {list(self.parametric_operations)}")
         self._combined_geometry = CombineSDF(self, combined_objects, parametric=True, parameters=parameters)
         return GenericGeometry(self._combined_geometry, ())

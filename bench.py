@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpoints/s of SDF evaluation on the 1024^3-request grid (1025^3 points after the
+reference's odd-resolution rule) for the 10-primitive smooth-union tree (BASELINE.json `metric`,
+SURVEY.md §8(d) "cfg 2 / north-star" recipe), coordinates resident in HBM, field left in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one evaluation of the whole grid. With N > 1 the flat point index is cut into N
+contiguous slabs (= slabs along x), one per rank/GPU, no data-path collective (the path is
+pointwise) -> strong scaling of the same grid. The RCCL all-gather that reassembles the field is
+timed separately after the timed region and reported under "allgather".
+
+The JSON line carries `roofline` (algorithmic 16 B/point over the live HIP-event kernel time, against
+the 8 TB/s HBM peak) and `cpu_baseline` (the NumPy oracle timed on this host on a bounded x-slab
+sample of the same grid).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+BYTES_PER_POINT = 16            # 3 x fp32 coordinate loads + 1 x fp32 store
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", type=int, default=1024, help="requested resolution per axis (odd-converted)")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg5"])
+    ap.add_argument("--mode", default="auto", choices=["auto", "interpret"])
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-allgather", action="store_true")
+    return ap.parse_args()
+
+
+def build_workload(name, ns, scenes):
+    if name == "cfg1":
+        return ns.Sphere(0.5), (2, 2, 2), "cfg1: Sphere(0.5)"
+    if name == "cfg2":
+        return scenes.cfg2_tree(ns), (2, 2, 2), "cfg2: 10-primitive left-deep SMOOTH_UNION2(0.1) chain, rng 1234"
+    if name == "cfg3":
+        return scenes.cfg3_chain(ns), (4, 4, 4), "cfg3: Box + elongation/twist/bend/infinite_repetition"
+    return scenes.cfg5_tree(ns), (3, 3, 3), "cfg5: 20-primitive 3-level tree, rng 2049"
+
+
+def cpu_baseline(scenes, workload, axes, budget_s):
+    """Oracle (float64 NumPy restatement of the reference, same operation order and temporaries)
+    on whole x-planes of the same grid, default NumPy/BLAS threading."""
+    import aegolius_amd.cores as ns
+    from oracle import sdf_oracle
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:  # noqa: BLE001
+        threads = os.cpu_count() or 1
+    tree, _size, _desc = build_workload(workload, ns, scenes)
+    ny, nz = axes[1].size, axes[2].size
+    plane = np.empty((3, ny * nz))
+    plane[1] = np.repeat(axes[1].astype(np.float64), nz)
+    plane[2] = np.tile(axes[2].astype(np.float64), ny)
+    done_pts, spent, k = 0, 0.0, 0
+    order = np.linspace(0, axes[0].size - 1, min(axes[0].size, 64)).astype(int)   # planes spread over the grid
+    while k < len(order):
+        plane[0] = float(axes[0][order[k]])
+        t0 = time.perf_counter()
+        with np.errstate(all="ignore"):
+            sdf_oracle.evaluate(tree, plane)
+        dt = time.perf_counter() - t0
+        spent += dt
+        done_pts += plane.shape[1]
+        k += 1
+        if spent + dt > budget_s:
+            break
+    return {"value": done_pts / spent / 1e6, "unit": "Mpoints/s", "cores": int(threads), "kind": "port",
+            "sample": "%d x-planes of %dx%d points of the same grid (%.1f s)" % (k, ny, nz, spent),
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched through torch.distributed.run" % args.gpus)
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()                               # no-op when libsdfk.so is current
+    if world > 1:
+        dist.barrier()
+    import scenes
+    import aegolius_amd.cores as ns
+    from aegolius_amd import _engine
+    from aegolius_amd._lower import lower_geometry
+    from aegolius_amd.cores.helper_functions import grid_axes
+    _engine.lib()  # fail loudly if the HIP extension is missing
+
+    tree, size, desc = build_workload(args.workload, ns, scenes)
+    axes64, res = grid_axes(size, (args.grid,) * 3)
+    axes = [a.astype(np.float32) for a in axes64]           # fp32-rounded float64 linspace ("identical grids")
+    n_total = int(res[0]) * int(res[1]) * int(res[2])
+    # contiguous slabs of the flat index (x-slabs); remainder to the last rank
+    per = n_total // world
+    start = rank * per
+    count = per if rank < world - 1 else n_total - start
+
+    stride = (count + 255) // 256 * 256                      # 16-byte aligned rows -> dwordx4 loads
+    co = torch.empty((3, stride), dtype=torch.float32, device=dev)
+    out = torch.empty((stride,), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    _engine.grid_fill(co.data_ptr(), stride, axes, start, count, stream=stream)
+
+    low = lower_geometry(tree)
+    prog = _engine.Program(low.code, low.params, low.tables, low.result_reg)
+    mode = _engine.MODE_INTERPRET if args.mode == "interpret" else _engine.MODE_SPECIALIZED
+
+    def step():
+        prog.eval_device(co.data_ptr(), count, stride, out.data_ptr(), stream=stream, mode=mode)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ev0, ev1 = _engine.Event(), _engine.Event()
+    fence()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_ms(ev1) / args.steps            # HIP events on the launch stream
+
+    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, kernel_ms_max = float(t[0]), float(t[1])
+
+    # ---- extras outside the timed region ----
+    probe_gbps = None
+    if rank == 0:
+        n4 = count // 4 * 4
+        lib = _engine.lib()
+        for _ in range(2):
+            _engine.check(lib.sdfk_stream_probe(co.data_ptr(), n4, stride, out.data_ptr(), stream), "probe")
+        p0, p1 = _engine.Event(), _engine.Event()
+        p0.record(stream)
+        for _ in range(5):
+            _engine.check(lib.sdfk_stream_probe(co.data_ptr(), n4, stride, out.data_ptr(), stream), "probe")
+        p1.record(stream)
+        probe_gbps = BYTES_PER_POINT * n4 / (p0.elapsed_ms(p1) / 5 * 1e-3) / 1e9
+        step()                                                # restore `out`
+        torch.cuda.synchronize()
+
+    allgather = None
+    if world > 1 and not args.no_allgather:
+        pad = (n_total - (world - 1) * per)                   # largest slab
+        send = out[:pad].contiguous()
+        full = torch.empty((world * pad,), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(full, send)               # warm-up (RCCL over xGMI)
+        fence()
+        g0 = time.perf_counter()
+        dist.all_gather_into_tensor(full, send)
+        fence()
+        gt = torch.tensor([time.perf_counter() - g0], dtype=torch.float64, device=dev)
+        dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+        allgather = {"ms": float(gt[0]) * 1e3, "bytes_per_rank": int(pad * 4),
+                     "mpoints_per_s_with_gather": n_total / (elapsed / args.steps + float(gt[0])) / 1e6}
+        del full
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n_total * args.steps / elapsed / 1e6
+        achieved = BYTES_PER_POINT * count / (kernel_ms_max * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("points_per_launch") == count and rec.get("workload") == args.workload:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        line = {
+            "metric": "Mpoints/sec SDF eval, 1024^3 grid, 10-prim smooth-union tree",
+            "value": value, "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "grid": "%dx%dx%d (request %d^3), size %s" % (res[0], res[1], res[2],
+                                                                                      args.grid, tuple(size)),
+                       "points": n_total, "points_per_gpu": count, "sharding": "contiguous x-slabs, no collective",
+                       "kernel": "sdfk_spec_v4 (hiprtc, topology-specialised)" if mode != _engine.MODE_INTERPRET
+                       else "sdfk_interp_kernel", "instructions": int(low.code.shape[0])},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel_ms": kernel_ms_max, "bytes_per_point": BYTES_PER_POINT,
+                         "stream_probe_gbps": probe_gbps},
+        }
+        if allgather:
+            line["allgather"] = allgather
+        if world == 1 and args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(scenes, args.workload, axes, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

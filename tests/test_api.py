@@ -1,0 +1,182 @@
+"""CPU: drop-in surface of the reference's operator API (names, signatures, histories, errors)."""
+import inspect
+
+import numpy as np
+import pytest
+
+import aegolius_amd.cores as ns
+from aegolius_amd._ir import CombineSDF, ModSDF, NodeSDF, PrimSDF, SDFExpr
+from aegolius_amd._lower import as_expr, lower_geometry
+
+
+def test_namespace_has_reference_names():
+    names = """CombineGeometry EuclideanTransform ModifyObject GenericGeometry resolution_conversion generate_grid
+    smarter_reshape sdf_circle sdf_segment_2d sdf_box_2d sdf_rounded_box_2d sdf_triangle_2d sdf_arc sdf_sector
+    sdf_inf_sector sdf_ngon sdf_polygon_2d sdf_segmented_curve_2d sdf_segmented_line_2d sdf_parametric_curve_2d
+    sdf_point_cloud_2d sdf_neu_circle Circle NEUCircle NGon Rectangle RoundedRectangle Segment Triangle Sector
+    InfiniteSector Arc Polygon ParametricCurve SegmentedParametricCurve SegmentedLine PointCloud2D sdf_sphere
+    sdf_cylinder sdf_box sdf_torus sdf_chainlink sdf_braid sdf_arc_3d sdf_plane sudf_plane sdf_segment_3d sdf_cone
+    sdf_oriented_infinite_cone sdf_infinite_cone sdf_solid_angle sdf_triangle_3d sdf_quad_3d sdf_segmented_line_3d
+    sdf_segmented_curve_3d sdf_parametric_curve_3d sdf_x sdf_y sdf_z sdf_point_cloud_3d InfiniteCylinder Cylinder
+    Sphere Box Plane OrientedPlane Line Triangle3D Quad Torus ChainLink Braid Arc3D Cone InfiniteCone
+    OrientedInfiniteCone ParametricCurve3D SegmentedParametricCurve3D SegmentedLine3D X Y Z""".split()
+    missing = [n for n in names if not hasattr(ns, n)]
+    assert not missing, missing
+    assert hasattr(ns.geom_3d, "SolidAngle") and hasattr(ns.geom_3d, "PointCloud3D")
+
+
+MOD_SIGNATURES = {
+    "elongation": ["elongate_vector"], "rounding": ["rounding_radius"], "rounding_cs": ["rounding_radius", "bb_size"],
+    "boundary": [], "signed_old": ["co_resolution"], "signed": ["co_resolution"], "invert": ["direct"],
+    "sign": ["direct"], "recover_volume": ["interior"], "define_volume": ["interior", "interior_parameters"],
+    "onion": ["thickness"], "concentric": ["width"], "revolution": ["radius"], "axis_revolution": ["radius", "angle"],
+    "extrusion": ["distance"], "twist": ["pitch"], "bend": ["radius", "angle"], "shear_xz": ["angle"],
+    "shear_yz": ["angle"], "shear_xy": ["angle"], "shear_zy": ["angle"], "shear_yx": ["angle"], "shear_zx": ["angle"],
+    "shear": ["angle", "sheared_axis", "fixed_axis"],
+    "displacement": ["displacement_function", "displacement_function_parameters"],
+    "infinite_repetition": ["distances"], "finite_repetition": ["size", "repetitions"],
+    "finite_repetition_rescaled": ["size", "repetitions", "instance_size", "padding"], "symmetry": ["axis"],
+    "mirror": ["a", "b"], "rotational_symmetry": ["n", "radius", "phase"], "linear_instancing": ["n", "a", "b"],
+    "curve_instancing": ["f", "f_parameters", "t_range"], "aligned_curve_instancing": ["f", "f_parameters", "t_range"],
+    "fully_aligned_curve_instancing": ["f", "f_parameters", "t_range"], "move_sdf": ["move_vector"],
+    "scale_sdf": ["scale_factor"], "rotate_sdf": ["rotation_matrix"],
+    "custom_modification": ["modification", "modification_parameters", "modification_name"],
+    "sigmoid_falloff": ["amplitude", "width"], "positive_sigmoid_falloff": ["amplitude", "width"],
+    "capped_exponential": ["amplitude", "width"], "hard_binarization": ["threshold"],
+    "linear_falloff": ["amplitude", "width"], "relu": ["width"], "smooth_relu": ["smooth_width", "width", "threshold"],
+    "slowstart": ["smooth_width", "width", "threshold", "ground"], "gaussian_boundary": ["amplitude", "width"],
+    "gaussian_falloff": ["amplitude", "width"], "conv_averaging": ["kernel_size", "iterations", "co_resolution"],
+    "conv_edge_detection": ["co_resolution"], "custom_post_process": ["function", "parameters", "post_process_name"],
+}
+
+
+def test_all_52_modification_methods_with_reference_signatures():
+    assert len(MOD_SIGNATURES) == 52
+    for name, params in MOD_SIGNATURES.items():
+        fn = getattr(ns.ModifyObject, name)
+        got = [p for p in inspect.signature(fn).parameters if p != "self"]
+        assert got == params, (name, got)
+    sig = inspect.signature(ns.ModifyObject.smooth_relu).parameters
+    assert sig["width"].default == 1 and sig["threshold"].default == 0.01
+    assert inspect.signature(ns.ModifyObject.slowstart).parameters["ground"].default is True
+
+
+def test_modification_history_and_closure_semantics():
+    b = ns.Box(1, 2, 3)
+    f1 = b.rounding(0.1)
+    f2 = b.sign(direct=True)        # returned but not installed
+    f3 = b.onion(0.05)
+    assert b.modifications == ["rounding", "sign", "onion"]
+    assert isinstance(f1, SDFExpr) and callable(f1)
+    assert f3.inner is f1 and f2.inner is f1 and b.modified_object is f3
+    assert isinstance(b.original_object, PrimSDF) and b.original_object is ns.sdf_box
+    b.custom_post_process(lambda u: u, (), post_process_name="mine")
+    assert b.modifications[-1] == "mine"
+
+
+def test_shape_properties():
+    assert ns.Sphere(0.5).radius == 0.5 and ns.Sphere(radius=0.25).radius == 0.25
+    bx = ns.Box(1, 2, 3)
+    assert (bx.a, bx.b, bx.c) == (1, 2, 3) and bx._geo_parameters == ((1, 2, 3),)
+    c = ns.Cone(0.9, 0.3)
+    assert c.height_offset == 0.9 * 0.5 ** (1 / 3) and c.base_radius == 0.9 * np.tan(0.3)
+    cl = ns.ChainLink(0.4, 0.1, 0.9)
+    assert cl.length == 0.45 and cl._geo_parameters == (0.4, 0.1, 0.45)
+    br = ns.Braid(1.6, 0.3, 0.08, 2.5)
+    assert br.length == 0.8 and br._geo_parameters == (0.8, 0.3, 0.08, 2.5)
+    rr = ns.RoundedRectangle(1.0, 0.7, (0.1, 0.05, 0.2, 0.0, 9.9))
+    assert list(rr.round_corners) == [0.1, 0.05, 0.2, 0.0] and list(rr.size) == [1.0, 0.7]
+    ln = ns.Line((0, 0, 0), (1, 0, 0))
+    assert list(ln.point_b) == [1, 0, 0]
+    with pytest.raises(TypeError):
+        ns.Sphere()
+    with pytest.raises(ValueError):
+        ns.Polygon(np.zeros((3, 2)))
+
+
+def test_transform_api_and_errors():
+    s = ns.Sphere(1.0)
+    s.move((1, 2, 3))
+    s.move((1,))
+    assert list(s.center) == [2, 3, 4]
+    s.set_location((5, 6))
+    assert list(s.center) == [5, 6, 4]
+    with pytest.raises(SyntaxError):
+        s.move((1, 2, 3, 4))
+    with pytest.raises(SyntaxError):
+        s.set_location((1, 2, 3, 4))
+    with pytest.raises(TypeError):
+        s.set_scale(np.float32(2))
+    with pytest.raises(TypeError):
+        s.set_scale("2")
+    s.set_scale(2)
+    s.rescale(1.5)
+    assert s.scale == 3.0
+    with pytest.raises(ValueError):
+        s.rotate(0.3, (0, 0, 0))
+    with pytest.raises(SyntaxError):
+        s.rotate(1, 2, 3)
+    with pytest.raises(TypeError):
+        s.set_rotation("a", (0, 0, 1))
+    s.rotate(np.pi / 2, (0, 0, 2))
+    np.testing.assert_allclose(s.rotation_matrix, [[0, -1, 0], [1, 0, 0], [0, 0, 1]], atol=1e-15)
+    np.testing.assert_allclose(s.rotation_angle, np.pi / 2)
+    np.testing.assert_allclose(s.rotation_axis, [0, 0, 1], atol=1e-15)
+    s.rotate(np.eye(3))                      # matrix form accepts a plain (3, 3)
+    # like the reference, a call is recorded before its arguments are validated
+    assert s.transformations == ["move", "move", "set_location", "move", "set_location", "set_scale", "set_scale",
+                                 "set_scale", "rescale", "rotate", "rotate", "set_rotation", "rotate", "rotate"]
+
+
+def test_combine_api_and_errors(capsys):
+    # intended SyntaxError, observed TypeError in the reference: the drop-in raises something that is both
+    for exc in (SyntaxError, TypeError):
+        with pytest.raises(exc):
+            ns.CombineGeometry("NOPE").combine(ns.Sphere(1), ns.Sphere(2))
+        with pytest.raises(exc):
+            ns.CombineGeometry("UNION2").combine_parametric(ns.Sphere(1), ns.Sphere(2), parameters=0.1)
+        with pytest.raises(exc):
+            ns.CombineGeometry("SMOOTH_UNION2").combine(ns.Sphere(1), ns.Sphere(2))
+    cg = ns.CombineGeometry("UNION2")
+    assert cg.available_operations == ["UNION2", "UNION", "SUBTRACT2", "INTERSECT2", "INTERSECT", "SUM", "DIFFERENCE"]
+    assert cg.available_parametric_operations == ["SMOOTH_UNION2_2", "SMOOTH_UNION2", "SMOOTH_INTERSECT2",
+                                                  "SMOOTH_INTERSECT2_BOLTZMANN", "SMOOTH_SUBTRACT2",
+                                                  "SMOOTH_SUBTRACT2_BOLTZMANN"]
+    assert "Available" in capsys.readouterr().out
+    assert cg.combined_geometry is None
+    u = cg.combine(ns.Sphere(1), ns.Sphere(2))
+    assert isinstance(u, ns.GenericGeometry) and isinstance(cg.combined_geometry, CombineSDF)
+    assert u._geo_parameters == ((),)
+    # wrong arity surfaces when the tree is evaluated, as in the reference (TypeError from the lambda)
+    with pytest.raises(TypeError):
+        lower_geometry(cg.combine(ns.Sphere(1), ns.Sphere(2), ns.Sphere(3)))
+    # operation looked up at evaluation time
+    cg.operation_type = "INTERSECT2"
+    from aegolius_amd import _ops
+    assert lower_geometry(u).code[-1, 0] & 255 == _ops.BY_NAME["VMAX"].code
+
+
+def test_callable_recognition():
+    s = ns.Sphere(1.0)
+    assert isinstance(as_expr(s.propagate), NodeSDF) and as_expr(s.propagate).obj is s
+    assert isinstance(as_expr(s.create), NodeSDF)
+    assert as_expr(ns.sdf_sphere) is ns.sdf_sphere
+    g = ns.GenericGeometry(lambda co, r: co[0] - r, 1.0)
+    with pytest.raises(NotImplementedError):
+        lower_geometry(g)
+    for mod in ("signed", "conv_edge_detection"):
+        b = ns.Box(1, 1, 1)
+        getattr(b, mod)((8, 8, 8))
+        with pytest.raises(NotImplementedError):
+            lower_geometry(b)
+    seg = ns.SegmentedLine3D(np.zeros((3, 4)))      # reference wires the open variant with the wrong arity
+    with pytest.raises(TypeError):
+        lower_geometry(seg)
+    b = ns.Box(1, 1, 1)
+    b.symmetry(3)
+    with pytest.raises(IndexError):
+        lower_geometry(b)
+    b = ns.Box(1, 1, 1)
+    b.shear(0.1, 0, 0)
+    with pytest.raises(ValueError):
+        lower_geometry(b)

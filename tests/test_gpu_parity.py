@@ -1,0 +1,283 @@
+"""GPU parity tests (run with -m gpu on an MI355X). Everything goes through the C-ABI of
+libsdfk.so; the checker is the golden vectors of the real reference (tests/golden) and the CPU
+oracle (oracle/sdf_oracle.py).
+
+Tolerance (BASELINE.json north_star): |gpu - ref| <= 1e-6 * max(1, |ref|), the
+reference being fed the same fp32-rounded coordinates. Scenes with jumps (sign, binarisation, cell
+boundaries — scenes.DISCONTINUOUS) may flip branch for points within rounding of the jump; those are
+counted and bounded (<= 0.5 % of the points), never hidden.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+import scenes
+import aegolius_amd
+import aegolius_amd.cores as ns
+from aegolius_amd._lower import lower_geometry
+from oracle import sdf_oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6
+ALL = sorted(scenes.SCENES)
+
+
+def violations(out, ref):
+    out = out.astype(np.float64)
+    both_nan = np.isnan(ref) & np.isnan(out)
+    err = np.abs(out - ref) / np.maximum(1.0, np.abs(ref))
+    err[both_nan] = 0.0
+    bad = ~(err <= TOL)
+    return err, bad
+
+
+def check(name, out, ref):
+    assert out.dtype == np.float32 and out.shape == ref.shape
+    err, bad = violations(out, ref)
+    if name in scenes.DISCONTINUOUS:
+        assert bad.sum() <= max(1, int(0.005 * ref.size)), "%s: %d points off (max %.2e)" % (name, bad.sum(),
+                                                                                             np.nanmax(err))
+    else:
+        assert not bad.any(), "%s: %d points off, max rel err %.3e" % (name, bad.sum(), np.nanmax(err))
+
+
+@pytest.fixture(scope="module")
+def engine(built):
+    built.require_gpu()
+    return built
+
+
+@pytest.fixture(autouse=True)
+def _restore_mode():
+    yield
+    aegolius_amd.config.mode = 0
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_scene_matches_reference_golden(name, engine, golden, golden_inputs):
+    """Every primitive / modification / combiner / tree scene, both kernel flavours."""
+    data, _ = golden
+    ref = data["scene/" + name]
+    outs = []
+    for mode in (engine.MODE_SPECIALIZED, engine.MODE_INTERPRET):
+        aegolius_amd.config.mode = mode
+        co = golden_inputs.copy()
+        out = scenes.SCENES[name](ns).create(co)
+        np.testing.assert_array_equal(co, golden_inputs)
+        check(name, out, ref)
+        outs.append(out)
+    # same device functions, same contraction rules: the two flavours agree bit for bit
+    np.testing.assert_array_equal(outs[0], outs[1])
+
+
+def test_float32_and_float64_coordinates_agree(engine, golden_inputs):
+    tree = scenes.cfg2_tree(ns)
+    a = tree.create(golden_inputs)
+    b = tree.create(golden_inputs.astype(np.float32))
+    np.testing.assert_array_equal(a, b)
+
+
+def test_empty_and_ragged_inputs(engine):
+    tree = scenes.cfg2_tree(ns)
+    assert tree.create(np.zeros((3, 0))).shape == (0,)
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 3, 4, 5, 63, 64, 65, 255, 257, 1023, 1025, 4099):
+        co = rng.uniform(-1, 1, (3, n)).astype(np.float32).astype(np.float64)
+        out = tree.create(co)
+        with np.errstate(all="ignore"):
+            ref = sdf_oracle.evaluate(scenes.cfg2_tree(ns), co)
+        check("tree_cfg2_smooth_union10", out, ref)
+    with pytest.raises(ValueError):
+        tree.create(np.zeros((2, 10)))
+
+
+def _device_eval(engine, prog, co32, n, stride, misalign=0, mode=None):
+    """eval_device on raw HIP buffers (optionally shifted by `misalign` floats to defeat 16-B alignment)."""
+    lib = engine.lib()
+    d_co = lib.sdfk_malloc((3 * stride + misalign + 4) * 4)
+    d_out = lib.sdfk_malloc((n + misalign + 4) * 4)
+    try:
+        host = np.zeros((3, stride), dtype=np.float32)
+        host[:, :n] = co32
+        engine.check(lib.sdfk_memcpy_h2d(ctypes.c_void_p(d_co + 4 * misalign), host.ctypes.data_as(ctypes.c_void_p),
+                                         host.nbytes), "h2d")
+        prog.eval_device(d_co + 4 * misalign, n, stride, d_out + 4 * misalign,
+                         mode=engine.MODE_SPECIALIZED if mode is None else mode)
+        engine.check(lib.sdfk_sync(None), "sync")
+        out = np.empty(n, dtype=np.float32)
+        engine.check(lib.sdfk_memcpy_d2h(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_out + 4 * misalign),
+                                         out.nbytes), "d2h")
+        return out
+    finally:
+        lib.sdfk_free(ctypes.c_void_p(d_co))
+        lib.sdfk_free(ctypes.c_void_p(d_out))
+
+
+def test_device_pointers_aligned_and_unaligned(engine, golden_inputs):
+    """16-byte vector path, scalar path (odd stride / shifted pointers) and the tail all agree."""
+    low = lower_geometry(scenes.cfg5_tree(ns))
+    prog = engine.Program(low.code, low.params, low.tables, low.result_reg)
+    co32 = golden_inputs.astype(np.float32)
+    n = co32.shape[1] - 1                                    # 2041: not a multiple of 4 -> tail launch
+    want = prog.eval_host(co32[:, :n])
+    for mode in (engine.MODE_SPECIALIZED, engine.MODE_INTERPRET):
+        for stride, mis in ((2048, 0), (2041, 0), (2044, 1), (2045, 3)):
+            got = _device_eval(engine, prog, co32[:, :n], n, stride, mis, mode)
+            np.testing.assert_array_equal(got, want)
+
+
+def test_program_rejects_malformed_code(engine):
+    from aegolius_amd import _ops
+    sphere = _ops.BY_NAME["P_SPHERE"].code
+    with pytest.raises(engine.SdfkError):                     # unknown opcode
+        engine.Program([[250, 0]], [0.5], [], 0)
+    with pytest.raises(engine.SdfkError):                     # parameters out of range
+        engine.Program([[sphere, 4]], [0.5], [], 0)
+    with pytest.raises(engine.SdfkError):                     # reads coordinate register 5, never written
+        engine.Program([[sphere | (5 << 16), 0]], [0.5], [], 0)
+    with pytest.raises(engine.SdfkError):                     # result register never written
+        engine.Program([[sphere, 0]], [0.5], [], 3)
+    near = _ops.BY_NAME["P_NEAREST3"].code
+    with pytest.raises(engine.SdfkError):                     # table rows beyond the table
+        engine.Program([[near, 0]], [10.0, 0.0], np.zeros(9), 0)
+
+
+def test_same_topology_new_parameters_reuses_kernel(engine, golden_inputs):
+    """The specialised kernel is keyed by tree topology; shape parameters stay runtime data."""
+    outs = []
+    for r in (0.3, 0.45):
+        s = scenes.placed(ns.Sphere(r))
+        out = s.create(golden_inputs)
+        with np.errstate(all="ignore"):
+            ref = sdf_oracle.evaluate(s, golden_inputs)
+        check("prim_sphere", out, ref)
+        outs.append(out)
+    assert np.abs(outs[0] - outs[1]).max() > 0.1
+    low = lower_geometry(scenes.placed(ns.Sphere(0.3)))
+    prog = engine.Program(low.code, low.params, low.tables, low.result_reg)
+    a = prog.eval_host(golden_inputs)
+    p2 = low.params.copy()
+    p2[-1] = 0.45
+    prog.set_params(p2)
+    b = prog.eval_host(golden_inputs)
+    np.testing.assert_array_equal(a, outs[0])
+    np.testing.assert_array_equal(b, outs[1])
+
+
+def test_grid_fill_and_grid_eval_match_generate_grid(engine):
+    from aegolius_amd.cores.helper_functions import grid_axes
+    size, res = (2.0, 3.0, 1.0), (20, 12, 34)
+    co, r = ns.generate_grid(size, res)
+    axes64, r2 = grid_axes(size, res)
+    assert r == r2
+    axes = [a.astype(np.float32) for a in axes64]
+    n = co.shape[1]
+    lib = engine.lib()
+    low = lower_geometry(scenes.cfg3_chain(ns))
+    prog = engine.Program(low.code, low.params, low.tables, low.result_reg)
+    want = prog.eval_host(co)
+    for start, count in ((0, n), (7, n - 7), (1234, 3001), (n - 5, 5)):
+        stride = (count + 3) // 4 * 4
+        d_co = lib.sdfk_malloc(3 * stride * 4)
+        d_out = lib.sdfk_malloc(stride * 4)
+        try:
+            engine.grid_fill(d_co, stride, axes, start, count)
+            host = np.empty((3, stride), dtype=np.float32)
+            engine.check(lib.sdfk_memcpy_d2h(host.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_co),
+                                             host.nbytes), "d2h")
+            np.testing.assert_array_equal(host[:, :count], co[:, start:start + count].astype(np.float32))
+            for mode in (engine.MODE_SPECIALIZED, engine.MODE_INTERPRET):
+                prog.eval_grid(axes, start, count, d_out, mode=mode)
+                got = np.empty(count, dtype=np.float32)
+                engine.check(lib.sdfk_memcpy_d2h(got.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_out),
+                                                 got.nbytes), "d2h")
+                np.testing.assert_array_equal(got, want[start:start + count])
+        finally:
+            lib.sdfk_free(ctypes.c_void_p(d_co))
+            lib.sdfk_free(ctypes.c_void_p(d_out))
+
+
+@pytest.mark.parametrize("cfg,request_res", [("cfg2", 512), ("cfg3", 1024)])
+def test_baseline_size_grids(cfg, request_res, engine):
+    """BASELINE.json configs[1] (513^3) and configs[2] (1025^3) at FULL size, evaluated straight from the
+    grid tables in x-slabs. Checked through (a) a random sample of points against the oracle and
+    (b) slab-partition independence: re-evaluating a window with a different partition is identical."""
+    from aegolius_amd.cores.helper_functions import grid_axes
+    build, size = (scenes.cfg2_tree, (2, 2, 2)) if cfg == "cfg2" else (scenes.cfg3_chain, (4, 4, 4))
+    axes64, res = grid_axes(size, (request_res,) * 3)
+    axes = [a.astype(np.float32) for a in axes64]
+    n = res[0] * res[1] * res[2]
+    assert n == (request_res + 1) ** 3
+    low = lower_geometry(build(ns))
+    prog = engine.Program(low.code, low.params, low.tables, low.result_reg)
+    lib = engine.lib()
+    d_out = lib.sdfk_malloc(n * 4)
+    assert d_out
+    try:
+        plane = res[1] * res[2]
+        slab = 97 * plane
+        for s in range(0, n, slab):
+            c = min(slab, n - s)
+            prog.eval_grid(axes, s, c, d_out + 4 * s)
+        rng = np.random.default_rng(11)
+        idx = np.sort(rng.choice(n, size=20000, replace=False))
+        # pull the sampled values (contiguous windows of 1 float each would be slow: fetch planes lazily)
+        got = np.empty(idx.size, dtype=np.float32)
+        win = np.empty(plane, dtype=np.float32)
+        cur = -1
+        for k, i in enumerate(idx):
+            p = i // plane
+            if p != cur:
+                engine.check(lib.sdfk_memcpy_d2h(win.ctypes.data_as(ctypes.c_void_p),
+                                                 ctypes.c_void_p(d_out + 4 * p * plane), win.nbytes), "d2h")
+                cur = p
+            got[k] = win[i - p * plane]
+        ix, rem = idx // plane, idx % plane
+        iy, iz = rem // res[2], rem % res[2]
+        co = np.stack([axes[0][ix], axes[1][iy], axes[2][iz]]).astype(np.float64)
+        with np.errstate(all="ignore"):
+            ref = sdf_oracle.evaluate(build(ns), co)
+        check("tree_cfg3_mod_chain" if cfg == "cfg3" else "tree_cfg2_smooth_union10", got, ref)
+        # partition independence on a window straddling slab boundaries
+        w0, wn = 96 * plane + 12345, 2 * plane + 777
+        d_w = lib.sdfk_malloc(wn * 4)
+        try:
+            prog.eval_grid(axes, w0, wn, d_w)
+            a, b = np.empty(wn, dtype=np.float32), np.empty(wn, dtype=np.float32)
+            engine.check(lib.sdfk_memcpy_d2h(a.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_w), a.nbytes), "d2h")
+            engine.check(lib.sdfk_memcpy_d2h(b.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_out + 4 * w0),
+                                             b.nbytes), "d2h")
+            np.testing.assert_array_equal(a, b)
+        finally:
+            lib.sdfk_free(ctypes.c_void_p(d_w))
+    finally:
+        lib.sdfk_free(ctypes.c_void_p(d_out))
+
+
+def test_sdf_function_called_directly(engine, golden_inputs):
+    """`sdf_*(co, *params)` and modification closures are callable like the reference's functions."""
+    out = ns.sdf_torus(golden_inputs, 0.6, 0.17)
+    with np.errstate(all="ignore"):
+        ref = sdf_oracle.PRIMS["sdf_torus"](golden_inputs, 0.6, 0.17)
+    check("prim_torus", out, ref)
+    b = ns.Box(0.6, 0.4, 0.3)
+    f = b.rounding(0.05)
+    out = f(golden_inputs, (0.6, 0.4, 0.3))
+    with np.errstate(all="ignore"):
+        ref = sdf_oracle.PRIMS["sdf_box"](golden_inputs, (0.6, 0.4, 0.3)) - 0.05
+    check("mod_rounding", out, ref)
+
+
+def test_output_dtype_option_and_point_cloud(engine, golden_inputs):
+    s = ns.Sphere(0.8)
+    try:
+        aegolius_amd.config.output_dtype = np.float64
+        assert s.create(golden_inputs).dtype == np.float64
+    finally:
+        aegolius_amd.config.output_dtype = np.float32
+    pts = s.point_cloud(golden_inputs)
+    inside = np.linalg.norm(golden_inputs, axis=0) <= 0.8
+    assert pts.shape == (3, int(inside.sum())) and np.all(pts[2] == 0)
+    np.testing.assert_array_equal(pts[:2], golden_inputs[:2, inside])

@@ -1,0 +1,84 @@
+"""CPU: the oracle (oracle/sdf_oracle.py) and the host-side API mirror, pinned against golden vectors
+produced by the REAL reference (tests/golden/generate_golden.py, run in the build container)."""
+import numpy as np
+import pytest
+
+import scenes
+import aegolius_amd.cores as ns
+from oracle import sdf_oracle
+
+ALL = sorted(scenes.SCENES)
+
+
+def rel_err(out, ref):
+    both_nan = np.isnan(ref) & np.isnan(out)
+    err = np.abs(out - ref) / np.maximum(1.0, np.abs(ref))
+    err[both_nan] = 0.0
+    return err
+
+
+def test_golden_covers_every_scene(golden):
+    data, meta = golden
+    assert set(meta["scenes"]) == set(scenes.SCENES)
+    assert data["inputs"].dtype == np.float32 and data["inputs"].shape == (3, meta["n_points"])
+    # inputs are reproducible from the seed (no hidden state in the fixture)
+    np.testing.assert_array_equal(data["inputs"], scenes.input_points().astype(np.float32))
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_oracle_matches_reference(name, golden, golden_inputs):
+    data, _ = golden
+    ref = data["scene/" + name]
+    co = golden_inputs.copy()
+    with np.errstate(all="ignore"):
+        out = sdf_oracle.evaluate(scenes.SCENES[name](ns), co)
+    np.testing.assert_array_equal(co, golden_inputs)          # create() never mutates the caller's array
+    assert out.shape == ref.shape and out.dtype == np.float64
+    assert np.array_equal(np.isnan(out), np.isnan(ref))
+    assert rel_err(out, ref).max() <= 1e-12
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_transform_state_matches_reference(name, golden):
+    """EuclideanTransform bookkeeping (scipy Rotation composition, centre, scale) equals the reference's."""
+    _, meta = golden
+    m = meta["scenes"][name]
+    obj = scenes.SCENES[name](ns)
+    np.testing.assert_allclose(obj.rotation_matrix, np.asarray(m["rotation_matrix"]), rtol=0, atol=1e-15)
+    np.testing.assert_allclose(np.asarray(obj.center, dtype=float), np.asarray(m["center"]), rtol=0, atol=0)
+    assert float(obj.scale) == m["scale"]
+
+
+def test_aliasing_scenes_are_not_vacuous(golden, golden_inputs):
+    """The in-place-mutation fixtures really differ from a copy-semantics evaluation."""
+    data, _ = golden
+    s = ns.Sphere(0.5)
+    s.move_sdf((0.2, 0.0, 0.0))
+    s.symmetry(0)
+    plain = scenes.placed(s)                      # same chain without the displacement
+    with np.errstate(all="ignore"):
+        base = sdf_oracle.evaluate(plain, golden_inputs)
+    ref = data["scene/alias_symmetry_displacement"]
+    # displacement added |x'| (mutated coordinates), so ref - base >= 0 everywhere and > 0 somewhere
+    assert np.all(ref - base >= -1e-12) and np.any(ref - base > 0.1)
+
+
+@pytest.mark.parametrize("gname", ["g3_even", "g3_mixed", "g3_scalar_res", "g2", "g2_scalar_res", "g1"])
+def test_generate_grid_matches_reference(gname, golden):
+    data, meta = golden
+    g = meta["grids"][gname]
+    res = g["resolution"] if len(g["resolution"]) > 1 else g["resolution"][0]
+    co, r = ns.generate_grid(tuple(g["size"]), res)
+    assert list(r) == g["returned_resolution"]
+    assert co.dtype == np.float64
+    np.testing.assert_array_equal(co, data["grid/" + gname])
+
+
+def test_resolution_conversion_and_reshape(golden):
+    _, meta = golden
+    assert [ns.resolution_conversion(k) for k in (128, 129, 512, 1024, 2048, 16384)] == [129, 129, 513, 1025, 2049,
+                                                                                         16385]
+    assert list(ns.smarter_reshape(np.zeros(9 ** 3), 8).shape) == meta["smarter_reshape"]["129_cubed"]
+    assert list(ns.smarter_reshape(np.zeros(9 * 5), (8, 5)).shape) == meta["smarter_reshape"]["2d"]
+    with pytest.raises(ValueError):
+        ns.smarter_reshape(np.zeros(10), (8, 8, 8))
