@@ -184,9 +184,11 @@ class Lowerer:
             w = float(w)
             if opcode in ("BOLTZ", "BOLTZSUB"):
                 prm = [1.0 / w] if w != 0 else [np.inf]
+            elif w == 0:
+                # reference combine.py:14-18, 22-26: zero width degenerates to the hard operator
+                opcode, prm = {"SMIN2": "VMIN", "SMIN3": "VMIN", "SMAX3": "VMAX", "SSUB3": "VSUBTRACT"}[opcode], []
             else:
-                inv = (1.0 / w) if w != 0 else 0.0
-                prm = [w, inv, w / (4.0 if opcode == "SMIN2" else 6.0)]
+                prm = [w, 1.0 / (4.0 * w)] if opcode == "SMIN2" else [w, 1.0 / (6.0 * w * w)]
             if len(kids) != 2:
                 raise TypeError("%s takes exactly 2 objects (%d given)" % (op, len(kids)))
         else:

@@ -609,19 +609,17 @@ SDFK_DEV float cmb_diff(float a, float b, const float* __restrict__) { return a 
 SDFK_DEV float cmb_min(float a, float b, const float* __restrict__) { return sd_min(a, b); }
 SDFK_DEV float cmb_max(float a, float b, const float* __restrict__) { return sd_max(a, b); }
 SDFK_DEV float cmb_subtract(float a, float b, const float* __restrict__) { return sd_max(a, -b); }
-// smoothmin_poly2 C/combine.py:12-18 ; P = (w, 1/w, w/4) ; w == 0 -> plain min
+// smoothmin_poly2 C/combine.py:12-18 : min(a,b) - h^2 w/4, h = max(w - |a-b|, 0)/w  ==  min - t^2/(4w)
+// with t = max(w - |a-b|, 0). P = (w, 1/(4w)). The reference's `w == 0 -> plain min` case is resolved at
+// lowering time (VMIN is emitted instead), so the kernel stays branch-free.
 SDFK_DEV float cmb_smin2(float a, float b, const float* __restrict__ P) {
-    float m = sd_min(a, b);
-    if (P[0] == 0.0f) return m;                               // wave-uniform
-    float h = sd_max(P[0] - sd_abs(a - b), 0.0f) * P[1];
-    return sd_fma(-(h * h), P[2], m);
+    float t = sd_max(P[0] - sd_abs(a - b), 0.0f);
+    return sd_fma(-(t * t), P[1], sd_min(a, b));
 }
-// smoothmin_poly3 C/combine.py:20-26 ; P = (w, 1/w, w/6)
+// smoothmin_poly3 C/combine.py:20-26 : min(a,b) - h^3 w/6  ==  min - t^3/(6 w^2). P = (w, 1/(6 w^2))
 SDFK_DEV float cmb_smin3(float a, float b, const float* __restrict__ P) {
-    float m = sd_min(a, b);
-    if (P[0] == 0.0f) return m;
-    float h = sd_max(P[0] - sd_abs(a - b), 0.0f) * P[1];
-    return sd_fma(-(h * h * h), P[2], m);
+    float t = sd_max(P[0] - sd_abs(a - b), 0.0f);
+    return sd_fma(-(t * t * t), P[1], sd_min(a, b));
 }
 SDFK_DEV float cmb_smax3(float a, float b, const float* __restrict__ P) { return -cmb_smin3(-a, -b, P); }
 SDFK_DEV float cmb_ssub3(float a, float b, const float* __restrict__ P) { return -cmb_smin3(-a, b, P); }

@@ -227,7 +227,7 @@ def test_baseline_size_grids(cfg, request_res, engine):
         got = np.empty(idx.size, dtype=np.float32)
         win = np.empty(plane, dtype=np.float32)
         cur = -1
-        for k, i in enumerate(idx):
+        for k, i in enumerate(idx.tolist()):
             p = i // plane
             if p != cur:
                 engine.check(lib.sdfk_memcpy_d2h(win.ctypes.data_as(ctypes.c_void_p),
