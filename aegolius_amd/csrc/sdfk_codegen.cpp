@@ -18,8 +18,15 @@ static __device__ __forceinline__ void sdfk_body(const float* __restrict__ PRM, 
     V3 p[VEC];
     sdfk_load<VEC>(src, off + block_base, lane_off, p);
     float v[VEC];
+    if constexpr (VEC == 4) {
+        // two points per lane value: packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32)
+        const f2 ra = sdfk_point<f2>(sd_join(p[0], p[1]), PRM, TAB);
+        const f2 rb = sdfk_point<f2>(sd_join(p[2], p[3]), PRM, TAB);
+        v[0] = ra.x; v[1] = ra.y; v[2] = rb.x; v[3] = rb.y;
+    } else {
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) v[k] = sdfk_point(p[k], PRM, TAB);
+        for (int k = 0; k < VEC; ++k) v[k] = sdfk_point<float>(p[k], PRM, TAB);
+    }
     sdfk_store<VEC>(out, off + block_base + lane_off, v);
 }
 extern "C" __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_spec_v4(
@@ -53,8 +60,8 @@ std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32
     s += kEmbeddedDevice;
     s += "\n";
     s += kEmbeddedAccess;
-    s += "\nstatic __device__ __forceinline__ float sdfk_point(V3 C0, const float* __restrict__ PRM, "
-         "const float* __restrict__ TAB) {\n";
+    s += "\ntemplate <typename T> static __device__ __forceinline__ T sdfk_point(V3T<T> C0, "
+         "const float* __restrict__ PRM, const float* __restrict__ TAB) {\n";
     std::set<unsigned> cregs, vregs;
     for (size_t i = 0; i < n_instr; ++i) {
         const uint32_t w = code[2 * i];
@@ -66,11 +73,11 @@ std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32
     char buf[256];
     for (unsigned c : cregs)
         if (c != 0) {
-            snprintf(buf, sizeof buf, "    V3 C%u;\n", c);
+            snprintf(buf, sizeof buf, "    V3T<T> C%u;\n", c);
             s += buf;
         }
     for (unsigned v : vregs) {
-        snprintf(buf, sizeof buf, "    float V%u;\n", v);
+        snprintf(buf, sizeof buf, "    T V%u;\n", v);
         s += buf;
     }
     for (size_t i = 0; i < n_instr; ++i) {

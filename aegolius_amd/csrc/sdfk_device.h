@@ -24,30 +24,60 @@
 
 #define SDFK_DEV static __device__ __forceinline__
 
-struct V3 { float x, y, z; };
+// Lane value types. `float` = one point per lane; `f2` = TWO points per lane, which lets the
+// compiler use the packed-fp32 VALU forms (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): measured on
+// MI355X a packed instruction costs ~1.2x a plain one and does 2x the work (tools/valu_peak.hip),
+// and this path is VALU-issue-bound for deep trees. min/max/sqrt/abs/compare have no packed form
+// and are issued per element. The hot operators below are templates over the lane type so that the
+// interpreter (float) and the specialised kernels (f2) run the SAME operation sequence per element
+// (packed and plain fma/mul/add round identically) — results are bit-identical.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <typename T> struct V3T { T x, y, z; };
+typedef V3T<float> V3;
+typedef V3T<f2> V3P;
 
 #define SDFK_TWO_PI 6.283185307179586f
 
 // ---------------------------------------------------------------------------------------------
-// small helpers
+// small helpers (float and f2 overloads)
 // ---------------------------------------------------------------------------------------------
+template <typename T> SDFK_DEV T sp(float v);                      // broadcast a parameter to the lane type
+template <> SDFK_DEV float sp<float>(float v) { return v; }
+template <> SDFK_DEV f2 sp<f2>(float v) { f2 r = {v, v}; return r; }
+
 SDFK_DEV float sd_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-// v_sqrt_f32: 1 ulp, quarter rate — instead of the ~10-instruction correctly-rounded expansion.
+SDFK_DEV f2 sd_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+// v_sqrt_f32: 1 ulp, half rate — instead of the ~10-instruction correctly-rounded expansion.
 SDFK_DEV float sd_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+SDFK_DEV f2 sd_sqrt(f2 x) { f2 r = {__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)}; return r; }
 SDFK_DEV float sd_min(float a, float b) { return __builtin_fminf(a, b); }
+SDFK_DEV f2 sd_min(f2 a, f2 b) { f2 r = {__builtin_fminf(a.x, b.x), __builtin_fminf(a.y, b.y)}; return r; }
 SDFK_DEV float sd_max(float a, float b) { return __builtin_fmaxf(a, b); }
+SDFK_DEV f2 sd_max(f2 a, f2 b) { f2 r = {__builtin_fmaxf(a.x, b.x), __builtin_fmaxf(a.y, b.y)}; return r; }
 SDFK_DEV float sd_abs(float a) { return __builtin_fabsf(a); }
-// np.clip(v, lo, hi) == minimum(maximum(v, lo), hi)
-SDFK_DEV float sd_clip(float v, float lo, float hi) { return sd_min(sd_max(v, lo), hi); }
-SDFK_DEV float sd_clip01(float v) { return sd_min(sd_max(v, 0.0f), 1.0f); }
+SDFK_DEV f2 sd_abs(f2 a) { f2 r = {__builtin_fabsf(a.x), __builtin_fabsf(a.y)}; return r; }
 // np.sign: -1, 0, +1
 SDFK_DEV float sd_sign(float v) { return (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f); }
-SDFK_DEV float sd_len2(float x, float y) { return sd_sqrt(sd_fma(x, x, y * y)); }
-SDFK_DEV float sd_len3(float x, float y, float z) { return sd_sqrt(sd_fma(x, x, sd_fma(y, y, z * z))); }
-SDFK_DEV float sd_dot2(float ax, float ay, float bx, float by) { return sd_fma(ax, bx, ay * by); }
-SDFK_DEV float sd_dot3(float ax, float ay, float az, float bx, float by, float bz) {
-    return sd_fma(ax, bx, sd_fma(ay, by, az * bz));
+SDFK_DEV f2 sd_sign(f2 v) { f2 r = {sd_sign(v.x), sd_sign(v.y)}; return r; }
+// np.clip(v, lo, hi) == minimum(maximum(v, lo), hi)
+template <typename T> SDFK_DEV T sd_clip(T v, float lo, float hi) { return sd_min(sd_max(v, sp<T>(lo)), sp<T>(hi)); }
+template <typename T> SDFK_DEV T sd_clip01(T v) { return sd_min(sd_max(v, sp<T>(0.0f)), sp<T>(1.0f)); }
+template <typename T> SDFK_DEV T sd_max0(T v) { return sd_max(v, sp<T>(0.0f)); }
+template <typename T> SDFK_DEV T sd_min0(T v) { return sd_min(v, sp<T>(0.0f)); }
+template <typename T> SDFK_DEV T sd_len2(T x, T y) { return sd_sqrt(sd_fma(x, x, y * y)); }
+template <typename T> SDFK_DEV T sd_len3(T x, T y, T z) { return sd_sqrt(sd_fma(x, x, sd_fma(y, y, z * z))); }
+// dot products of lane values with PARAMETERS (b*)
+template <typename T> SDFK_DEV T sd_dot2(T ax, T ay, float bx, float by) {
+    return sd_fma(ax, sp<T>(bx), ay * by);
 }
+template <typename T> SDFK_DEV T sd_dot3(T ax, T ay, T az, float bx, float by, float bz) {
+    return sd_fma(ax, sp<T>(bx), sd_fma(ay, sp<T>(by), az * bz));
+}
+// pair plumbing for the operators that exist in scalar form only
+SDFK_DEV V3 sd_lo(V3P p) { V3 r = {p.x.x, p.y.x, p.z.x}; return r; }
+SDFK_DEV V3 sd_hi(V3P p) { V3 r = {p.x.y, p.y.y, p.z.y}; return r; }
+SDFK_DEV V3P sd_join(V3 a, V3 b) { V3P r = {{a.x, b.x}, {a.y, b.y}, {a.z, b.z}}; return r; }
 // np.mod(a, d): floored modulo, result carries the sign of the divisor. inv_d = 1/d (host, f64->f32).
 // One fma recovers a - q*d exactly once q is right; the two fix-ups repair an off-by-one q.
 SDFK_DEV float sd_mod(float a, float d, float inv_d) {
@@ -80,58 +110,58 @@ SDFK_DEV float sd_seg2_sq(float px, float py, const float* __restrict__ S) {
 // coordinate -> coordinate
 // signature: V3 f(V3 p, const float* P, const float* T, int imm)
 // =============================================================================================
-SDFK_DEV V3 op_movc(V3 p, const float* __restrict__, const float* __restrict__, int) { return p; }
+template <typename T> SDFK_DEV V3T<T> op_movc(V3T<T> p, const float* __restrict__, const float* __restrict__, int) { return p; }
 
 // C/transformations.py:232-242  co' = (R^T co)/s - R^T t.  P = M(9, row major, R^T/s) , c(3) = R^T t
-SDFK_DEV V3 op_xform(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
-    V3 q;
-    q.x = sd_fma(P[0], p.x, sd_fma(P[1], p.y, sd_fma(P[2], p.z, -P[9])));
-    q.y = sd_fma(P[3], p.x, sd_fma(P[4], p.y, sd_fma(P[5], p.z, -P[10])));
-    q.z = sd_fma(P[6], p.x, sd_fma(P[7], p.y, sd_fma(P[8], p.z, -P[11])));
+template <typename T> SDFK_DEV V3T<T> op_xform(V3T<T> p, const float* __restrict__ P, const float* __restrict__, int) {
+    V3T<T> q;
+    q.x = sd_fma(sp<T>(P[0]), p.x, sd_fma(sp<T>(P[1]), p.y, sd_fma(sp<T>(P[2]), p.z, sp<T>(-P[9]))));
+    q.y = sd_fma(sp<T>(P[3]), p.x, sd_fma(sp<T>(P[4]), p.y, sd_fma(sp<T>(P[5]), p.z, sp<T>(-P[10]))));
+    q.z = sd_fma(sp<T>(P[6]), p.x, sd_fma(sp<T>(P[7]), p.y, sd_fma(sp<T>(P[8]), p.z, sp<T>(-P[11]))));
     return q;
 }
 // R = I, s = 1 (I·co and co/1.0 are exact in the reference): q = p - t.  Also move_sdf C/modifications.py:1283
-SDFK_DEV V3 op_xlate(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
-    V3 q = {p.x - P[0], p.y - P[1], p.z - P[2]};
+template <typename T> SDFK_DEV V3T<T> op_xlate(V3T<T> p, const float* __restrict__ P, const float* __restrict__, int) {
+    V3T<T> q = {p.x - P[0], p.y - P[1], p.z - P[2]};
     return q;
 }
 // q = O p : the six named shears + shear(), rotate_sdf.  C/modifications.py:579-774, :1323-1324
-SDFK_DEV V3 op_lin3(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
-    V3 q;
-    q.x = sd_fma(P[0], p.x, sd_fma(P[1], p.y, P[2] * p.z));
-    q.y = sd_fma(P[3], p.x, sd_fma(P[4], p.y, P[5] * p.z));
-    q.z = sd_fma(P[6], p.x, sd_fma(P[7], p.y, P[8] * p.z));
+template <typename T> SDFK_DEV V3T<T> op_lin3(V3T<T> p, const float* __restrict__ P, const float* __restrict__, int) {
+    V3T<T> q;
+    q.x = sd_fma(sp<T>(P[0]), p.x, sd_fma(sp<T>(P[1]), p.y, P[2] * p.z));
+    q.y = sd_fma(sp<T>(P[3]), p.x, sd_fma(sp<T>(P[4]), p.y, P[5] * p.z));
+    q.z = sd_fma(sp<T>(P[6]), p.x, sd_fma(sp<T>(P[7]), p.y, P[8] * p.z));
     return q;
 }
 // q = p / k with P[0] = 1/k
-SDFK_DEV V3 op_cscale(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
-    V3 q = {p.x * P[0], p.y * P[0], p.z * P[0]};
+template <typename T> SDFK_DEV V3T<T> op_cscale(V3T<T> p, const float* __restrict__ P, const float* __restrict__, int) {
+    V3T<T> q = {p.x * P[0], p.y * P[0], p.z * P[0]};
     return q;
 }
 // elongation C/modifications.py:88-93 ; P = ev/2
-SDFK_DEV V3 op_elongate(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
-    V3 q = {p.x - sd_clip(p.x, -P[0], P[0]), p.y - sd_clip(p.y, -P[1], P[1]), p.z - sd_clip(p.z, -P[2], P[2])};
+template <typename T> SDFK_DEV V3T<T> op_elongate(V3T<T> p, const float* __restrict__ P, const float* __restrict__, int) {
+    V3T<T> q = {p.x - sd_clip(p.x, -P[0], P[0]), p.y - sd_clip(p.y, -P[1], P[1]), p.z - sd_clip(p.z, -P[2], P[2])};
     return q;
 }
 // revolution C/modifications.py:426-431 ; P = radius
-SDFK_DEV V3 op_revolve(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
-    V3 q = {sd_len2(p.x, p.z) - P[0], p.y, 0.0f};
+template <typename T> SDFK_DEV V3T<T> op_revolve(V3T<T> p, const float* __restrict__ P, const float* __restrict__, int) {
+    V3T<T> q = {sd_len2(p.x, p.z) - P[0], p.y, sp<T>(0.0f)};
     return q;
 }
 // xy <- [[c, s], [-s, c]] xy ; P = (c, s). z untouched.
-SDFK_DEV V3 op_rot2d(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
-    V3 q = {sd_fma(P[0], p.x, P[1] * p.y), sd_fma(-P[1], p.x, P[0] * p.y), p.z};
+template <typename T> SDFK_DEV V3T<T> op_rot2d(V3T<T> p, const float* __restrict__ P, const float* __restrict__, int) {
+    V3T<T> q = {sd_fma(sp<T>(P[0]), p.x, P[1] * p.y), sd_fma(sp<T>(-P[1]), p.x, P[0] * p.y), p.z};
     return q;
 }
 // axis_revolution tail C/modifications.py:460-466 (input already rotated in place); P = (c, s, radius)
-SDFK_DEV V3 op_axrev(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
-    float m = sd_len2(p.x, p.z);
+template <typename T> SDFK_DEV V3T<T> op_axrev(V3T<T> p, const float* __restrict__ P, const float* __restrict__, int) {
+    T m = sd_len2(p.x, p.z);
     // qo[:2] = rot.T · (m, y)   with rot.T = [[c, -s], [s, c]]
-    V3 q = {sd_fma(P[0], m, -P[1] * p.y) - P[2], sd_fma(P[1], m, P[0] * p.y), 0.0f};
+    V3T<T> q = {sd_fma(sp<T>(P[0]), m, -P[1] * p.y) - P[2], sd_fma(sp<T>(P[1]), m, P[0] * p.y), sp<T>(0.0f)};
     return q;
 }
-SDFK_DEV V3 op_zeroz(V3 p, const float* __restrict__, const float* __restrict__, int) {
-    V3 q = {p.x, p.y, 0.0f};
+template <typename T> SDFK_DEV V3T<T> op_zeroz(V3T<T> p, const float* __restrict__, const float* __restrict__, int) {
+    V3T<T> q = {p.x, p.y, sp<T>(0.0f)};
     return q;
 }
 // twist C/modifications.py:517-522 ; P = pitch
@@ -180,13 +210,13 @@ SDFK_DEV V3 op_finrep(V3 p, const float* __restrict__ P, const float* __restrict
     return q;
 }
 // symmetry C/modifications.py:948-952 ; imm = axis
-SDFK_DEV V3 op_symmetry(V3 p, const float* __restrict__, const float* __restrict__, int imm) {
-    V3 q = {imm == 0 ? sd_abs(p.x) : p.x, imm == 1 ? sd_abs(p.y) : p.y, imm == 2 ? sd_abs(p.z) : p.z};
+template <typename T> SDFK_DEV V3T<T> op_symmetry(V3T<T> p, const float* __restrict__, const float* __restrict__, int imm) {
+    V3T<T> q = {imm == 0 ? sd_abs(p.x) : p.x, imm == 1 ? sd_abs(p.y) : p.y, imm == 2 ? sd_abs(p.z) : p.z};
     return q;
 }
 // mirror tail C/modifications.py:990-993 ; P = l/2
-SDFK_DEV V3 op_foldx(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
-    V3 q = {sd_abs(p.x) - P[0], p.y, p.z};
+template <typename T> SDFK_DEV V3T<T> op_foldx(V3T<T> p, const float* __restrict__ P, const float* __restrict__, int) {
+    V3T<T> q = {sd_abs(p.x) - P[0], p.y, p.z};
     return q;
 }
 // rotational_symmetry tail C/modifications.py:1023-1029 ; P = (angle, angle/2, 1/angle, radius)
@@ -240,38 +270,38 @@ SDFK_DEV V3 op_curveinst(V3 p, const float* __restrict__ P, const float* __restr
 // signature: float f(V3 p, const float* P, const float* T)
 // =============================================================================================
 // sdf_x/y/z C/sdf_3D.py:13-22 ; P = (offset, axis)
-SDFK_DEV float prim_axis(V3 p, const float* __restrict__ P, const float* __restrict__) {
-    float v = (P[1] == 0.0f) ? p.x : ((P[1] == 1.0f) ? p.y : p.z);
+template <typename T> SDFK_DEV T prim_axis(V3T<T> p, const float* __restrict__ P, const float* __restrict__) {
+    T v = (P[1] == 0.0f) ? p.x : ((P[1] == 1.0f) ? p.y : p.z);     // wave-uniform selection
     return v - P[0];
 }
 // sdf_sphere C/sdf_3D.py:25-27
-SDFK_DEV float prim_sphere(V3 p, const float* __restrict__ P, const float* __restrict__) {
+template <typename T> SDFK_DEV T prim_sphere(V3T<T> p, const float* __restrict__ P, const float* __restrict__) {
     return sd_len3(p.x, p.y, p.z) - P[0];
 }
 // sdf_cylinder C/sdf_3D.py:30-37 ; P = (radius, height/2)
-SDFK_DEV float prim_cylinder(V3 p, const float* __restrict__ P, const float* __restrict__) {
-    float d0 = sd_len2(p.x, p.y) - P[0];
-    float d1 = sd_abs(p.z) - P[1];
-    float t1 = sd_min(sd_max(d0, d1), 0.0f);
-    float t2 = sd_len2(sd_max(d0, 0.0f), sd_max(d1, 0.0f));
+template <typename T> SDFK_DEV T prim_cylinder(V3T<T> p, const float* __restrict__ P, const float* __restrict__) {
+    T d0 = sd_len2(p.x, p.y) - P[0];
+    T d1 = sd_abs(p.z) - P[1];
+    T t1 = sd_min0(sd_max(d0, d1));
+    T t2 = sd_len2(sd_max0(d0), sd_max0(d1));
     return t1 + t2;
 }
 // sdf_box C/sdf_3D.py:40-47 ; P = size/2
-SDFK_DEV float prim_box(V3 p, const float* __restrict__ P, const float* __restrict__) {
-    float qx = sd_abs(p.x) - P[0], qy = sd_abs(p.y) - P[1], qz = sd_abs(p.z) - P[2];
-    float t1 = sd_len3(sd_max(qx, 0.0f), sd_max(qy, 0.0f), sd_max(qz, 0.0f));
-    float t2 = sd_min(sd_max(qx, sd_max(qy, qz)), 0.0f);
+template <typename T> SDFK_DEV T prim_box(V3T<T> p, const float* __restrict__ P, const float* __restrict__) {
+    T qx = sd_abs(p.x) - P[0], qy = sd_abs(p.y) - P[1], qz = sd_abs(p.z) - P[2];
+    T t1 = sd_len3(sd_max0(qx), sd_max0(qy), sd_max0(qz));
+    T t2 = sd_min0(sd_max(qx, sd_max(qy, qz)));
     return t1 + t2;
 }
 // sdf_torus C/sdf_3D.py:50-53 ; P = (R, r)
-SDFK_DEV float prim_torus(V3 p, const float* __restrict__ P, const float* __restrict__) {
-    float a = sd_len2(p.x, p.y) - P[0];
+template <typename T> SDFK_DEV T prim_torus(V3T<T> p, const float* __restrict__ P, const float* __restrict__) {
+    T a = sd_len2(p.x, p.y) - P[0];
     return sd_len2(a, p.z) - P[1];
 }
 // sdf_chainlink C/sdf_3D.py:56-61 ; P = (R, r, length/2)  (length as passed to sdf_chainlink)
-SDFK_DEV float prim_chainlink(V3 p, const float* __restrict__ P, const float* __restrict__) {
-    float x = p.x - sd_clip(p.x, -P[2], P[2]);
-    float a = sd_len2(x, p.y) - P[0];
+template <typename T> SDFK_DEV T prim_chainlink(V3T<T> p, const float* __restrict__ P, const float* __restrict__) {
+    T x = p.x - sd_clip(p.x, -P[2], P[2]);
+    T a = sd_len2(x, p.y) - P[0];
     return sd_len2(a, p.z) - P[1];
 }
 // sdf_braid C/sdf_3D.py:64-75 ; P = (length/2, R, r, pitch)
@@ -301,11 +331,11 @@ SDFK_DEV float prim_arc3d(V3 p, const float* __restrict__ P, const float* __rest
     return sd_len3(x - P[0] * c, y - P[0] * s, p.z) - P[1];
 }
 // sdf_plane C/sdf_3D.py:99-102 ; P = (n̂(3), offset)
-SDFK_DEV float prim_plane(V3 p, const float* __restrict__ P, const float* __restrict__) {
+template <typename T> SDFK_DEV T prim_plane(V3T<T> p, const float* __restrict__ P, const float* __restrict__) {
     return sd_dot3(p.x, p.y, p.z, P[0], P[1], P[2]) - P[3];
 }
 // sudf_plane C/sdf_3D.py:105-108 ; P = (n̂(3), thickness/2)
-SDFK_DEV float prim_uplane(V3 p, const float* __restrict__ P, const float* __restrict__) {
+template <typename T> SDFK_DEV T prim_uplane(V3T<T> p, const float* __restrict__ P, const float* __restrict__) {
     return sd_abs(sd_dot3(p.x, p.y, p.z, P[0], P[1], P[2])) - P[3];
 }
 // sdf_segment_3d C/sdf_3D.py:111-118 ; P = a(3), ba(3), 1/dot(ba,ba)
@@ -313,16 +343,16 @@ SDFK_DEV float prim_segment3(V3 p, const float* __restrict__ P, const float* __r
     return sd_sqrt(sd_seg3_sq(p.x, p.y, p.z, P));
 }
 // sdf_cone C/sdf_3D.py:121-136 ; P = (q0 = H tan a, q1 = -H, z offset, 1/dot(q,q), 1/q0)
-SDFK_DEV float prim_cone(V3 p, const float* __restrict__ P, const float* __restrict__) {
+template <typename T> SDFK_DEV T prim_cone(V3T<T> p, const float* __restrict__ P, const float* __restrict__) {
     float q0 = P[0], q1 = P[1];
-    float w0 = sd_len2(p.x, p.y);
-    float w1 = p.z - P[2];
-    float t1 = sd_clip01(sd_dot2(w0, w1, q0, q1) * P[3]);
-    float ax = sd_fma(-q0, t1, w0), ay = sd_fma(-q1, t1, w1);
-    float t2 = sd_clip01(w0 * P[4]);
-    float bx = sd_fma(-q0, t2, w0), by = w1 - q1;
-    float d = sd_min(sd_fma(ax, ax, ay * ay), sd_fma(bx, bx, by * by));
-    float s = sd_max(-sd_fma(w0, q1, -w1 * q0), -(w1 - q1));
+    T w0 = sd_len2(p.x, p.y);
+    T w1 = p.z - P[2];
+    T t1 = sd_clip01(sd_dot2(w0, w1, q0, q1) * P[3]);
+    T ax = sd_fma(sp<T>(-q0), t1, w0), ay = sd_fma(sp<T>(-q1), t1, w1);
+    T t2 = sd_clip01(w0 * P[4]);
+    T bx = sd_fma(sp<T>(-q0), t2, w0), by = w1 - q1;
+    T d = sd_min(sd_fma(ax, ax, ay * ay), sd_fma(bx, bx, by * by));
+    T s = sd_max(-sd_fma(w0, sp<T>(q1), -w1 * q0), -(w1 - q1));
     return sd_sqrt(d) * sd_sign(s);
 }
 // sdf_infinite_cone / sdf_oriented_infinite_cone C/sdf_3D.py:139-157 ; P = (sin a, cos a, oriented)
@@ -416,7 +446,7 @@ SDFK_DEV float prim_nearest3(V3 p, const float* __restrict__ P, const float* __r
 
 // ---- 2-D primitives (z ignored) -------------------------------------------------------------
 // sdf_circle C/sdf_2D.py:12-14
-SDFK_DEV float prim_circle(V3 p, const float* __restrict__ P, const float* __restrict__) {
+template <typename T> SDFK_DEV T prim_circle(V3T<T> p, const float* __restrict__ P, const float* __restrict__) {
     return sd_len2(p.x, p.y) - P[0];
 }
 // sdf_neu_circle C/sdf_2D.py:17-19 ; P = (radius, ord, kind) kind: 0 general p-norm, 1 = +inf, 2 = -inf, 3 = ord 0
@@ -432,9 +462,9 @@ SDFK_DEV float prim_neucircle(V3 p, const float* __restrict__ P, const float* __
     return l - P[0];
 }
 // sdf_box_2d C/sdf_2D.py:22-28 ; P = size/2
-SDFK_DEV float prim_box2(V3 p, const float* __restrict__ P, const float* __restrict__) {
-    float dx = sd_abs(p.x) - P[0], dy = sd_abs(p.y) - P[1];
-    return sd_len2(sd_max(dx, 0.0f), sd_max(dy, 0.0f)) + sd_min(sd_max(dx, dy), 0.0f);
+template <typename T> SDFK_DEV T prim_box2(V3T<T> p, const float* __restrict__ P, const float* __restrict__) {
+    T dx = sd_abs(p.x) - P[0], dy = sd_abs(p.y) - P[1];
+    return sd_len2(sd_max0(dx), sd_max0(dy)) + sd_min0(sd_max(dx, dy));
 }
 // sdf_segment_2d C/sdf_2D.py:31-38 ; P = a(2), ba(2), 1/dot(ba,ba)
 SDFK_DEV float prim_segment2(V3 p, const float* __restrict__ P, const float* __restrict__) {
@@ -531,12 +561,12 @@ SDFK_DEV float prim_polysign(V3 p, const float* __restrict__ P, const float* __r
     float interior = 1.0f;
     for (int j = 0; j < np_; ++j) {
         int k = (int)tab[0];
-        float sp = -1.0f;
+        float side = -1.0f;
         for (int i = 0; i < k; ++i) {
             const float* __restrict__ h = tab + 1 + 4 * i;
-            sp = sd_max(sp, sd_sign(sd_dot2(p.x - h[0], p.y - h[1], h[2], h[3])));
+            side = sd_max(side, sd_sign(sd_dot2(p.x - h[0], p.y - h[1], h[2], h[3])));
         }
-        interior = (sp <= 0.0f) ? -1.0f : interior;
+        interior = (side <= 0.0f) ? -1.0f : interior;
         tab += 1 + 4 * k;
     }
     return interior;
@@ -556,20 +586,20 @@ SDFK_DEV float prim_shapesign(V3 p, const float* __restrict__ P, const float* __
     return interior;
 }
 // |z| - h/2 of extrusion C/modifications.py:493 ; P = h/2
-SDFK_DEV float prim_zslab(V3 p, const float* __restrict__ P, const float* __restrict__) { return sd_abs(p.z) - P[0]; }
+template <typename T> SDFK_DEV T prim_zslab(V3T<T> p, const float* __restrict__ P, const float* __restrict__) { return sd_abs(p.z) - P[0]; }
 
 // =============================================================================================
 // value -> value     signature: float f(float v, const float* P)
 // =============================================================================================
-SDFK_DEV float val_scale(float v, const float* __restrict__ P) { return P[0] * v; }
-SDFK_DEV float val_subc(float v, const float* __restrict__ P) { return v - P[0]; }
+template <typename T> SDFK_DEV T val_scale(T v, const float* __restrict__ P) { return P[0] * v; }
+template <typename T> SDFK_DEV T val_subc(T v, const float* __restrict__ P) { return v - P[0]; }
 // rounding_cs C/modifications.py:141 : scale*f - r   (two roundings, as the reference)
-SDFK_DEV float val_affine(float v, const float* __restrict__ P) { return P[0] * v - P[1]; }
-SDFK_DEV float val_abs(float v, const float* __restrict__) { return sd_abs(v); }
-SDFK_DEV float val_neg(float v, const float* __restrict__) { return -v; }
-SDFK_DEV float val_sign(float v, const float* __restrict__) { return sd_sign(v); }
-SDFK_DEV float val_onion(float v, const float* __restrict__ P) { return sd_abs(v) - P[0]; }
-SDFK_DEV float val_concentric(float v, const float* __restrict__ P) { return sd_abs(v - P[0]); }
+template <typename T> SDFK_DEV T val_affine(T v, const float* __restrict__ P) { return P[0] * v - P[1]; }
+template <typename T> SDFK_DEV T val_abs(T v, const float* __restrict__) { return sd_abs(v); }
+template <typename T> SDFK_DEV T val_neg(T v, const float* __restrict__) { return -v; }
+template <typename T> SDFK_DEV T val_sign(T v, const float* __restrict__) { return sd_sign(v); }
+template <typename T> SDFK_DEV T val_onion(T v, const float* __restrict__ P) { return sd_abs(v) - P[0]; }
+template <typename T> SDFK_DEV T val_concentric(T v, const float* __restrict__ P) { return sd_abs(v - P[0]); }
 // sigmoid_falloff / positive_sigmoid_falloff C/post_processing.py:380-412 ; P = (A, 4/w, shift)
 SDFK_DEV float val_sigmoid(float v, const float* __restrict__ P) {
     float e = expf((v - P[2]) * P[1]);
@@ -580,18 +610,18 @@ SDFK_DEV float val_capexp(float v, const float* __restrict__ P) { return P[0] * 
 // hard_binarization :432-446
 SDFK_DEV float val_hardbin(float v, const float* __restrict__ P) { return (v <= P[0]) ? 1.0f : 0.0f; }
 // linear_falloff :449-463 ; P = (A, 1/w)
-SDFK_DEV float val_linfall(float v, const float* __restrict__ P) { return sd_clip01(1.0f - v * P[1]) * P[0]; }
+template <typename T> SDFK_DEV T val_linfall(T v, const float* __restrict__ P) { return sd_clip01(1.0f - v * P[1]) * P[0]; }
 // relu :466-477 ; P = 1/w
-SDFK_DEV float val_relu(float v, const float* __restrict__ P) { return sd_max(v * P[0], 0.0f); }
+template <typename T> SDFK_DEV T val_relu(T v, const float* __restrict__ P) { return sd_max0(v * P[0]); }
 // smooth_relu :480-500 ; P = (1/w, b)
-SDFK_DEV float val_smoothrelu(float v, const float* __restrict__ P) {
-    float u = v * P[0];
-    return (u + sd_sqrt(sd_fma(u, u, P[1]))) * 0.5f;
+template <typename T> SDFK_DEV T val_smoothrelu(T v, const float* __restrict__ P) {
+    T u = v * P[0];
+    return (u + sd_sqrt(sd_fma(u, u, sp<T>(P[1])))) * 0.5f;
 }
 // slowstart :503-523 ; P = (1/w, b/w, sqrt(b/w)*ground)
-SDFK_DEV float val_slowstart(float v, const float* __restrict__ P) {
-    float u = sd_max(v * P[0], 0.0f);
-    return sd_sqrt(sd_fma(u, u, P[1])) - P[2];
+template <typename T> SDFK_DEV T val_slowstart(T v, const float* __restrict__ P) {
+    T u = sd_max0(v * P[0]);
+    return sd_sqrt(sd_fma(u, u, sp<T>(P[1]))) - P[2];
 }
 // gaussian_boundary / gaussian_falloff :526-558 ; P = (A, 1/w, clamp_at_zero)
 SDFK_DEV float val_gauss(float v, const float* __restrict__ P) {
@@ -603,26 +633,26 @@ SDFK_DEV float val_gauss(float v, const float* __restrict__ P) {
 // =============================================================================================
 // (value, value) -> value     signature: float f(float a, float b, const float* P)
 // =============================================================================================
-SDFK_DEV float cmb_mul(float a, float b, const float* __restrict__) { return a * b; }
-SDFK_DEV float cmb_add(float a, float b, const float* __restrict__) { return a + b; }
-SDFK_DEV float cmb_diff(float a, float b, const float* __restrict__) { return a - b; }
-SDFK_DEV float cmb_min(float a, float b, const float* __restrict__) { return sd_min(a, b); }
-SDFK_DEV float cmb_max(float a, float b, const float* __restrict__) { return sd_max(a, b); }
-SDFK_DEV float cmb_subtract(float a, float b, const float* __restrict__) { return sd_max(a, -b); }
+template <typename T> SDFK_DEV T cmb_mul(T a, T b, const float* __restrict__) { return a * b; }
+template <typename T> SDFK_DEV T cmb_add(T a, T b, const float* __restrict__) { return a + b; }
+template <typename T> SDFK_DEV T cmb_diff(T a, T b, const float* __restrict__) { return a - b; }
+template <typename T> SDFK_DEV T cmb_min(T a, T b, const float* __restrict__) { return sd_min(a, b); }
+template <typename T> SDFK_DEV T cmb_max(T a, T b, const float* __restrict__) { return sd_max(a, b); }
+template <typename T> SDFK_DEV T cmb_subtract(T a, T b, const float* __restrict__) { return sd_max(a, -b); }
 // smoothmin_poly2 C/combine.py:12-18 : min(a,b) - h^2 w/4, h = max(w - |a-b|, 0)/w  ==  min - t^2/(4w)
 // with t = max(w - |a-b|, 0). P = (w, 1/(4w)). The reference's `w == 0 -> plain min` case is resolved at
 // lowering time (VMIN is emitted instead), so the kernel stays branch-free.
-SDFK_DEV float cmb_smin2(float a, float b, const float* __restrict__ P) {
-    float t = sd_max(P[0] - sd_abs(a - b), 0.0f);
-    return sd_fma(-(t * t), P[1], sd_min(a, b));
+template <typename T> SDFK_DEV T cmb_smin2(T a, T b, const float* __restrict__ P) {
+    T t = sd_max0(P[0] - sd_abs(a - b));
+    return sd_fma(-(t * t), sp<T>(P[1]), sd_min(a, b));
 }
 // smoothmin_poly3 C/combine.py:20-26 : min(a,b) - h^3 w/6  ==  min - t^3/(6 w^2). P = (w, 1/(6 w^2))
-SDFK_DEV float cmb_smin3(float a, float b, const float* __restrict__ P) {
-    float t = sd_max(P[0] - sd_abs(a - b), 0.0f);
-    return sd_fma(-(t * t * t), P[1], sd_min(a, b));
+template <typename T> SDFK_DEV T cmb_smin3(T a, T b, const float* __restrict__ P) {
+    T t = sd_max0(P[0] - sd_abs(a - b));
+    return sd_fma(-(t * t * t), sp<T>(P[1]), sd_min(a, b));
 }
-SDFK_DEV float cmb_smax3(float a, float b, const float* __restrict__ P) { return -cmb_smin3(-a, -b, P); }
-SDFK_DEV float cmb_ssub3(float a, float b, const float* __restrict__ P) { return -cmb_smin3(-a, b, P); }
+template <typename T> SDFK_DEV T cmb_smax3(T a, T b, const float* __restrict__ P) { return -cmb_smin3(-a, -b, P); }
+template <typename T> SDFK_DEV T cmb_ssub3(T a, T b, const float* __restrict__ P) { return -cmb_smin3(-a, b, P); }
 // smoothmax_boltz C/combine.py:29-34 ; P = 1/w. Both exponentials are shifted by max(a,b)/w, which
 // cancels between numerator and denominator (identical in exact arithmetic, no fp32 overflow).
 SDFK_DEV float cmb_boltz(float a, float b, const float* __restrict__ P) {
@@ -633,8 +663,41 @@ SDFK_DEV float cmb_boltz(float a, float b, const float* __restrict__ P) {
 }
 SDFK_DEV float cmb_boltzsub(float a, float b, const float* __restrict__ P) { return cmb_boltz(a, -b, P); }
 // extrusion tail C/modifications.py:494-496 ; a = d(x, y, 0), b = |z| - h/2
-SDFK_DEV float cmb_extrude(float a, float b, const float* __restrict__) {
-    return sd_min(sd_max(a, b), 0.0f) + sd_len2(sd_max(a, 0.0f), sd_max(b, 0.0f));
+template <typename T> SDFK_DEV T cmb_extrude(T a, T b, const float* __restrict__) {
+    return sd_min0(sd_max(a, b)) + sd_len2(sd_max0(a), sd_max0(b));
 }
+
+// =============================================================================================
+// pair adapters: operators written for one point per lane, applied to each half of an f2 lane
+// =============================================================================================
+#define SDFK_PAIR_C_C(F)                                                                                   \
+    SDFK_DEV V3P F(V3P p, const float* __restrict__ P, const float* __restrict__ T, int imm) {             \
+        return sd_join(F(sd_lo(p), P, T, imm), F(sd_hi(p), P, T, imm));                                    \
+    }
+#define SDFK_PAIR_V_C(F)                                                                                   \
+    SDFK_DEV f2 F(V3P p, const float* __restrict__ P, const float* __restrict__ T) {                       \
+        f2 r = {F(sd_lo(p), P, T), F(sd_hi(p), P, T)};                                                     \
+        return r;                                                                                          \
+    }
+#define SDFK_PAIR_V_V(F)                                                                                   \
+    SDFK_DEV f2 F(f2 v, const float* __restrict__ P) {                                                     \
+        f2 r = {F(v.x, P), F(v.y, P)};                                                                     \
+        return r;                                                                                          \
+    }
+#define SDFK_PAIR_V_VV(F)                                                                                  \
+    SDFK_DEV f2 F(f2 a, f2 b, const float* __restrict__ P) {                                               \
+        f2 r = {F(a.x, b.x, P), F(a.y, b.y, P)};                                                           \
+        return r;                                                                                          \
+    }
+SDFK_PAIR_C_C(op_twist) SDFK_PAIR_C_C(op_bend) SDFK_PAIR_C_C(op_infrep) SDFK_PAIR_C_C(op_finrep)
+SDFK_PAIR_C_C(op_rotsym) SDFK_PAIR_C_C(op_lininst) SDFK_PAIR_C_C(op_curveinst)
+SDFK_PAIR_V_C(prim_braid) SDFK_PAIR_V_C(prim_arc3d) SDFK_PAIR_V_C(prim_segment3) SDFK_PAIR_V_C(prim_infcone)
+SDFK_PAIR_V_C(prim_solidangle) SDFK_PAIR_V_C(prim_triangle3) SDFK_PAIR_V_C(prim_quad3) SDFK_PAIR_V_C(prim_segline3)
+SDFK_PAIR_V_C(prim_nearest3) SDFK_PAIR_V_C(prim_neucircle) SDFK_PAIR_V_C(prim_segment2) SDFK_PAIR_V_C(prim_rbox2)
+SDFK_PAIR_V_C(prim_triangle2) SDFK_PAIR_V_C(prim_arc2) SDFK_PAIR_V_C(prim_sector) SDFK_PAIR_V_C(prim_infsector)
+SDFK_PAIR_V_C(prim_ngon) SDFK_PAIR_V_C(prim_segline2) SDFK_PAIR_V_C(prim_nearest2) SDFK_PAIR_V_C(prim_polysign)
+SDFK_PAIR_V_C(prim_shapesign)
+SDFK_PAIR_V_V(val_sigmoid) SDFK_PAIR_V_V(val_capexp) SDFK_PAIR_V_V(val_hardbin) SDFK_PAIR_V_V(val_gauss)
+SDFK_PAIR_V_VV(cmb_boltz) SDFK_PAIR_V_VV(cmb_boltzsub)
 
 #endif  // SDFK_DEVICE_H
