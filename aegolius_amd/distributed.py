@@ -1,0 +1,89 @@
+"""Slab sharding of a grid evaluation across the GPUs of one node.
+
+The path is pointwise, so any partition of the flat point index is exact. Rank r of W evaluates the
+contiguous range `slab_bounds(N, W, r)` (an x-slab of the grid: the flat index is
+n = (ix*ny + iy)*nz + iz, reference cores/helper_functions.py:90-91) with no data-path collective.
+Only reassembling the field needs communication: one all-gather (RCCL over xGMI when the process
+group backend is "nccl"; gloo on CPU in the tests).
+
+One process per GPU, launched with torch.distributed.run; torch is plumbing here (device memory,
+streams, the process group), the evaluation itself is libsdfk.so.
+"""
+import numpy as np
+
+
+def slab_bounds(n_total, world_size, rank):
+    """(start, count) of rank's contiguous slab; the remainder goes to the last rank."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank %d outside world of %d" % (rank, world_size))
+    per = n_total // world_size
+    start = rank * per
+    count = per if rank < world_size - 1 else n_total - start
+    return start, count
+
+
+def gather_slabs(local, n_total, group=None):
+    """All-gather the per-rank slabs (1-D tensors laid out by slab_bounds) into the full field on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    start, count = slab_bounds(n_total, world, rank)
+    if local.numel() != count:
+        raise ValueError("rank %d holds %d values, its slab has %d" % (rank, local.numel(), count))
+    pad = n_total - (world - 1) * (n_total // world)          # largest slab (the last one)
+    send = local
+    if count != pad:
+        send = torch.zeros(pad, dtype=local.dtype, device=local.device)
+        send[:count] = local
+    full = torch.empty(world * pad, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(full, send.contiguous(), group=group)
+    if pad * world == n_total:
+        return full
+    per = n_total // world
+    out = torch.empty(n_total, dtype=local.dtype, device=local.device)
+    for r in range(world):
+        s, c = slab_bounds(n_total, world, r)
+        out[s:s + c] = full[r * pad:r * pad + c]
+    return out
+
+
+def evaluate_grid_sharded(geometry, size, resolution, gather=True, group=None, evaluate_slab=None):
+    """Evaluate `geometry` on generate_grid(size, resolution), this rank computing only its slab.
+
+    Returns (field, resolution): the full field on every rank when gather=True, else this rank's slab
+    (left distributed — the configuration that scales). `evaluate_slab(axes, start,
+    count) -> 1-D torch tensor` may replace the built-in GPU evaluator (the CPU tests pass the oracle).
+    """
+    import torch.distributed as dist
+    from .cores.helper_functions import grid_axes
+    axes64, res = grid_axes(size, resolution)
+    n_total = int(np.prod([a.size for a in axes64]))
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    start, count = slab_bounds(n_total, world, rank)
+    if evaluate_slab is None:
+        evaluate_slab = _GpuSlabEvaluator(geometry)
+    local = evaluate_slab([a.astype(np.float32) for a in axes64], start, count)
+    if gather and world > 1:
+        return gather_slabs(local, n_total, group), res
+    return local, res
+
+
+class _GpuSlabEvaluator:
+    """Evaluates a slab straight from the per-axis tables into a torch tensor on the current device."""
+
+    def __init__(self, geometry):
+        from . import _engine
+        from ._eval import program_for
+        from ._lower import lower_geometry
+        self._engine = _engine
+        self._prog = program_for(lower_geometry(geometry))
+
+    def __call__(self, axes, start, count):
+        import torch
+        self._engine.require_gpu()
+        out = torch.empty(count, dtype=torch.float32, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        self._prog.eval_grid(axes, start, count, out.data_ptr(), stream=stream)
+        return out

@@ -1,0 +1,89 @@
+"""CPU, world_size 2, gloo: the N > 1 path (slab partition + all-gather reassembly). The per-slab
+evaluator is the CPU oracle here (test infrastructure); on the GPU box the same code runs with the
+libsdfk evaluator (tests/test_gpu_parity.py::test_sharded_evaluation_matches_whole_grid)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_slab_bounds_partition_the_index_space():
+    from aegolius_amd.distributed import slab_bounds
+    for n in (0, 1, 7, 1025 ** 2, 129 ** 3, 1025 ** 3):
+        for w in (1, 2, 3, 4, 8):
+            spans = [slab_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+            for (s0, c0), (s1, _) in zip(spans, spans[1:]):
+                assert s0 + c0 == s1
+    with pytest.raises(ValueError):
+        slab_bounds(10, 2, 2)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, resolution, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import scenes
+        import aegolius_amd.cores as ns
+        from aegolius_amd.distributed import evaluate_grid_sharded, slab_bounds
+        from oracle import sdf_oracle
+
+        tree = scenes.cfg5_tree(ns)
+
+        def oracle_slab(axes, start, count):
+            n1, n2 = axes[1].size, axes[2].size
+            idx = np.arange(start, start + count)
+            co = np.stack([axes[0][idx // (n1 * n2)], axes[1][(idx // n2) % n1], axes[2][idx % n2]]).astype(np.float64)
+            with np.errstate(all="ignore"):
+                return torch.from_numpy(sdf_oracle.evaluate(tree, co).astype(np.float32))
+
+        full, res = evaluate_grid_sharded(tree, (3, 3, 3), resolution, gather=True, evaluate_slab=oracle_slab)
+        local, _ = evaluate_grid_sharded(tree, (3, 3, 3), resolution, gather=False, evaluate_slab=oracle_slab)
+        n = res[0] * res[1] * res[2]
+        s, c = slab_bounds(n, world, rank)
+        ok = full.numel() == n and local.numel() == c and torch.equal(full[s:s + c], local)
+        q.put((rank, bool(ok), full.numpy().copy(), tuple(res)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,resolution", [(2, (6, 8, 10)), (2, (8, 8, 8)), (3, (4, 6, 4))])
+def test_sharded_evaluation_equals_single_rank(world, resolution):
+    """Uneven slabs (odd-converted grids never divide evenly), gather on every rank, slab left distributed."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, resolution, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scenes
+    import aegolius_amd.cores as ns
+    from oracle import sdf_oracle
+    co, res = ns.generate_grid((3, 3, 3), resolution)
+    co = co.astype(np.float32).astype(np.float64)
+    with np.errstate(all="ignore"):
+        want = sdf_oracle.evaluate(scenes.cfg5_tree(ns), co).astype(np.float32)
+    for rank, ok, full, r in got:
+        assert ok and r == res
+        np.testing.assert_array_equal(full, want)

@@ -281,3 +281,20 @@ def test_output_dtype_option_and_point_cloud(engine, golden_inputs):
     inside = np.linalg.norm(golden_inputs, axis=0) <= 0.83
     assert pts.shape == (3, int(inside.sum())) and np.all(pts[2] == 0)
     np.testing.assert_array_equal(pts[:2], golden_inputs[:2, inside])
+
+
+def test_sharded_evaluation_matches_whole_grid(engine):
+    """Slab-sharding on ONE device (each 'rank' = one slab): concatenated slabs == the whole-grid field."""
+    import torch
+    from aegolius_amd.distributed import _GpuSlabEvaluator, slab_bounds
+    from aegolius_amd.cores.helper_functions import grid_axes
+    tree = scenes.cfg5_tree(ns)
+    size, resolution = (3, 3, 3), (40, 30, 52)
+    co, res = ns.generate_grid(size, resolution)
+    whole = tree.create(co)
+    axes = [a.astype(np.float32) for a in grid_axes(size, resolution)[0]]
+    ev = _GpuSlabEvaluator(tree)
+    for world in (2, 3, 8):
+        parts = [ev(axes, *slab_bounds(whole.size, world, r)) for r in range(world)]
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(torch.cat(parts).cpu().numpy(), whole)
