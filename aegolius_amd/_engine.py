@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsdfk.so")
 
-MODE_AUTO, MODE_INTERPRET, MODE_SPECIALIZED = 0, 1, 2
+MODE_AUTO, MODE_INTERPRET, MODE_SPECIALIZED, MODE_NOCULL = 0, 1, 2, 3
 
 _c = ctypes
 _vp, _i64, _int, _sz = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t
@@ -26,6 +26,7 @@ SIGNATURES = {
     "sdfk_program_create": (_vp, [_vp, _sz, _vp, _sz, _vp, _sz, _int]),
     "sdfk_program_destroy": (None, [_vp]),
     "sdfk_program_set_params": (_int, [_vp, _vp, _sz]),
+    "sdfk_program_set_cull": (_int, [_vp, _vp, _sz, _vp]),
     "sdfk_program_source": (_c.c_char_p, [_vp]),
     "sdfk_program_compile_check": (_int, [_vp, _c.POINTER(_sz)]),
     "sdfk_eval_device": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _int]),
@@ -104,7 +105,7 @@ def _ptr(a):
 class Program:
     """Owning wrapper of an `sdfk_program*` (a lowered expression tree)."""
 
-    def __init__(self, code, params, tables, result_reg):
+    def __init__(self, code, params, tables, result_reg, cull_sites=None, cull_k=None):
         self.code = np.ascontiguousarray(code, dtype=np.uint32).reshape(-1, 2)
         self.params = np.ascontiguousarray(params, dtype=np.float32).ravel()
         self.tables = np.ascontiguousarray(tables, dtype=np.float32).ravel()
@@ -113,6 +114,17 @@ class Program:
                                             _ptr(self.tables), self.tables.size, self.result_reg)
         if not self._h:
             raise SdfkError("sdfk_program_create rejected the program: " + last_error())
+        if cull_sites is not None and len(cull_sites):
+            sites = np.ascontiguousarray(cull_sites, dtype=np.uint32).reshape(-1, 5)
+            k = np.ascontiguousarray(cull_k, dtype=np.float32).ravel()
+            check(lib().sdfk_program_set_cull(self._h, _ptr(sites), sites.shape[0], _ptr(k)), "sdfk_program_set_cull")
+
+    @classmethod
+    def from_lowered(cls, low, cull=True):
+        """Program of a LoweredProgram (aegolius_amd._lower), with its brick-culling sites."""
+        if cull:
+            return cls(low.code, low.params, low.tables, low.result_reg, low.cull_sites, low.cull_k)
+        return cls(low.code, low.params, low.tables, low.result_reg)
 
     @property
     def handle(self):

@@ -33,7 +33,7 @@ def program_for(lowered):
         if prog is not None:
             _cache.move_to_end(key)
             return prog
-    prog = _engine.Program(lowered.code, lowered.params, lowered.tables, lowered.result_reg)
+    prog = _engine.Program.from_lowered(lowered)
     with _lock:
         _cache[key] = prog
         while len(_cache) > config.cache_size:

@@ -21,6 +21,7 @@ therefore lowered under one of three modes:
 """
 import numpy as np
 
+from . import _lipschitz as _lip
 from . import _ops
 from ._ir import CombineSDF, ModSDF, NodeSDF, PrimSDF, SDFExpr, UnsupportedSDF
 
@@ -32,14 +33,18 @@ class LoweringError(Exception):
 
 
 class LoweredProgram:
-    __slots__ = ("code", "params", "tables", "result_reg", "n_creg", "n_vreg")
+    __slots__ = ("code", "params", "tables", "result_reg", "n_creg", "n_vreg", "cull_sites", "cull_k")
 
-    def __init__(self, code, params, tables, result_reg, n_creg, n_vreg):
+    def __init__(self, code, params, tables, result_reg, n_creg, n_vreg, cull_sites=None, cull_k=None):
         self.code, self.params, self.tables = code, params, tables
         self.result_reg, self.n_creg, self.n_vreg = result_reg, n_creg, n_vreg
+        # brick-culling sites: rows (combiner index, a_start, a_end, b_start, b_end) + K = L_a + L_b
+        self.cull_sites = np.zeros((0, 5), dtype=np.uint32) if cull_sites is None else cull_sites
+        self.cull_k = np.zeros(0, dtype=np.float32) if cull_k is None else cull_k
 
     def key(self):
-        return (self.code.tobytes(), self.params.tobytes(), self.tables.tobytes(), self.result_reg)
+        return (self.code.tobytes(), self.params.tobytes(), self.tables.tobytes(), self.result_reg,
+                self.cull_sites.tobytes(), self.cull_k.tobytes())
 
     @property
     def fits_interpreter(self):
@@ -55,6 +60,9 @@ class Lowerer:
         self._v_used = set()
         self.n_creg = 1
         self.n_vreg = 0
+        self.lip_c = {0: 1.0}      # Lipschitz bound of each register w.r.t. the root point (_lipschitz.py)
+        self.lip_v = {}
+        self.cull = []             # (combiner index, a_start, a_end, b_start, b_end, K)
 
     # ---- registers ----
     def new_c(self):
@@ -92,6 +100,16 @@ class Lowerer:
         poff = len(self.params)
         self.params.extend(params)
         self.code.append((info.code | (a << 8) | (b << 16) | (c << 24), poff))
+        if info.kind == "C_C":
+            self.lip_c[a] = self.lip_c.get(b, _lip.INF) * _lip.factor(_lip.C_C, opname, params)
+        elif info.kind == "V_C":
+            self.lip_v[a] = self.lip_c.get(b, _lip.INF) * _lip.factor(_lip.V_C, opname, params)
+        elif info.kind == "V_V":
+            self.lip_v[a] = self.lip_v.get(b, _lip.INF) * _lip.factor(_lip.V_V, opname, params)
+        else:
+            fn = _lip.V_VV.get(opname)
+            la, lb = self.lip_v.get(b, _lip.INF), self.lip_v.get(c, _lip.INF)
+            self.lip_v[a] = fn(la, lb) if fn and np.isfinite(la) and np.isfinite(lb) else _lip.INF
 
     def add_table(self, values):
         off = len(self.tables)
@@ -104,8 +122,13 @@ class Lowerer:
         with np.errstate(over="ignore"):
             params = np.asarray(self.params, dtype=np.float64).astype(np.float32)
             tables = np.asarray(self.tables, dtype=np.float64).astype(np.float32)
+        # the largest subtrees first if there are more sites than mask bits
+        sites = sorted(self.cull, key=lambda r: -((r[2] - r[1]) + (r[4] - r[3])))[:_lip.MAX_SITES]
+        sites.sort(key=lambda r: r[0])
         return LoweredProgram(np.asarray(self.code, dtype=np.uint32).reshape(-1, 2), params, tables, vreg,
-                              self.n_creg, self.n_vreg)
+                              self.n_creg, self.n_vreg,
+                              np.asarray([r[:5] for r in sites], dtype=np.uint32).reshape(-1, 5),
+                              np.asarray([r[5] for r in sites], dtype=np.float32))
 
     # ---- coordinate helpers ----
     def writable(self, creg, mode):
@@ -203,13 +226,19 @@ class Lowerer:
             else:
                 raise KeyError(op)
         acc = None
+        first = len(self.code)
         for i, kid in enumerate(kids):
             last = (i == len(kids) - 1)
+            b_start = len(self.code)
             v = self.lower_node(kid, creg, OWNED if (last and mode == OWNED) else FROZEN)
             if acc is None:
                 acc = v
             else:
+                k = self.lip_v.get(acc, _lip.INF) + self.lip_v.get(v, _lip.INF)
+                idx = len(self.code)
                 self.emit(opcode, acc, acc, v, params=prm)
+                if opcode in _lip.CULLABLE and np.isfinite(k) and b_start > first and idx > b_start:
+                    self.cull.append((idx, first, b_start - 1, b_start, idx - 1, float(k)))
                 self.free_v(v)
         return acc
 

@@ -150,7 +150,7 @@ struct DevState {
 
 struct SpecKernel {
     hipModule_t mod = nullptr;
-    hipFunction_t v4 = nullptr, v1 = nullptr, g4 = nullptr, g1 = nullptr;
+    hipFunction_t v4 = nullptr, v1 = nullptr, g4 = nullptr, g1 = nullptr, tile = nullptr;
     bool failed = false;
     std::string error;
 };
@@ -163,6 +163,7 @@ struct sdfk_program {
     unsigned long long params_version = 1;
     std::string key;
     std::string source;
+    std::vector<sdfk_cullsite> sites;  // brick-culling sites (sdfk_program_set_cull)
     std::mutex mu;
     std::map<int, DevState> dev;
 };
@@ -339,11 +340,87 @@ extern "C" int sdfk_program_set_params(sdfk_program* p, const float* params, siz
     return 0;
 }
 
+// ---- brick culling sites ---------------------------------------------------------------------
+static void instr_fields(const sdfk_program* p, size_t i, unsigned* op, unsigned* a, unsigned* b, unsigned* c) {
+    const uint32_t w = p->code[2 * i];
+    *op = w & 255u; *a = (w >> 8) & 255u; *b = (w >> 16) & 255u; *c = w >> 24;
+}
+
+// May the instructions [lo, hi] be skipped when the combiner `comb` does not need the value they
+// produce? Only if nothing executed later reads a register they would have written.
+static bool range_skippable(const sdfk_program* p, uint32_t lo, uint32_t hi, uint32_t comb, unsigned result_vreg) {
+    const size_t n = p->code.size() / 2;
+    std::vector<char> wc(256, 0), wv(256, 0);
+    unsigned op, a, b, c;
+    for (size_t i = lo; i <= hi; ++i) {
+        instr_fields(p, i, &op, &a, &b, &c);
+        (g_ops[op].kind == SDFK_KIND_C_C ? wc : wv)[a] = 1;
+    }
+    instr_fields(p, hi, &op, &a, &b, &c);
+    if (g_ops[op].kind == SDFK_KIND_C_C || a != result_vreg) return false;  // range must end by producing the operand
+    for (size_t j = hi + 1; j < n; ++j) {
+        instr_fields(p, j, &op, &a, &b, &c);
+        const int kind = g_ops[op].kind;
+        if (kind == SDFK_KIND_C_C || kind == SDFK_KIND_V_C) {
+            if (wc[b]) return false;
+        } else if (kind == SDFK_KIND_V_V) {
+            if (wv[b]) return false;
+        } else {
+            const bool is_comb = (j == comb);
+            if (wv[b] && !(is_comb && b == result_vreg)) return false;
+            if (wv[c] && !(is_comb && c == result_vreg)) return false;
+        }
+        (kind == SDFK_KIND_C_C ? wc : wv)[a] = 0;   // redefined: later reads see the new value
+    }
+    return !wv[(unsigned)p->result_reg];
+}
+
+static bool is_cullable_op(unsigned op) {
+    return op == SDFK_OP_VMIN || op == SDFK_OP_VMAX || op == SDFK_OP_VSUBTRACT || op == SDFK_OP_SMIN2 ||
+           op == SDFK_OP_SMIN3 || op == SDFK_OP_SMAX3 || op == SDFK_OP_SSUB3;
+}
+
+extern "C" int sdfk_program_set_cull(sdfk_program* p, const uint32_t* rows, size_t n_sites, const float* k) {
+    if (!p) return fail(-1, "null program");
+    if (n_sites > 32) return fail(-2, "sdfk_program_set_cull: at most 32 sites");
+    if (n_sites && (!rows || !k)) return fail(-1, "sdfk_program_set_cull: null arrays");
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (!p->source.empty() || !p->dev.empty())
+        return fail(-2, "sdfk_program_set_cull: must be called before the program is first used");
+    const size_t n = p->code.size() / 2;
+    std::vector<sdfk_cullsite> sites;
+    for (size_t i = 0; i < n_sites; ++i) {
+        sdfk_cullsite t{rows[5 * i], rows[5 * i + 1], rows[5 * i + 2], rows[5 * i + 3], rows[5 * i + 4], k[i], 0, 0};
+        if (!(t.comb < n && t.a0 <= t.a1 && t.a1 + 1 == t.b0 && t.b0 <= t.b1 && t.b1 + 1 == t.comb))
+            return fail(-2, "sdfk_program_set_cull: malformed site ranges");
+        if (!(t.k >= 0.0f) || !std::isfinite(t.k)) return fail(-2, "sdfk_program_set_cull: bad Lipschitz sum");
+        unsigned op, a, b, c;
+        instr_fields(p, t.comb, &op, &a, &b, &c);
+        if (!is_cullable_op(op)) return fail(-2, "sdfk_program_set_cull: site is not at a min/max-type combiner");
+        if (i && rows[5 * i] <= rows[5 * (i - 1)]) return fail(-2, "sdfk_program_set_cull: sites must be sorted");
+        for (const sdfk_cullsite& u : sites) {   // spans [a0, comb] nest or are disjoint
+            const bool disjoint = u.comb < t.a0;
+            const bool nested = u.a0 >= t.a0 && (u.comb <= t.a1 || (u.a0 >= t.b0 && u.comb <= t.b1));
+            if (!disjoint && !nested) return fail(-2, "sdfk_program_set_cull: sites overlap without nesting");
+        }
+        t.skip_a_ok = range_skippable(p, t.a0, t.a1, t.comb, b) ? 1 : 0;
+        t.skip_b_ok = range_skippable(p, t.b0, t.b1, t.comb, c) ? 1 : 0;
+        sites.push_back(t);
+    }
+    p->sites = sites;
+    p->key.append("|cull");
+    for (const sdfk_cullsite& t : sites) {
+        p->key.append(reinterpret_cast<const char*>(&t), sizeof t);
+    }
+    return 0;
+}
+
 extern "C" const char* sdfk_program_source(sdfk_program* p) {
     if (!p) return nullptr;
     std::lock_guard<std::mutex> lk(p->mu);
     if (p->source.empty())
-        p->source = sdfk_generate_source(g_ops, SDFK_OP_COUNT, p->code.data(), p->code.size() / 2, p->result_reg);
+        p->source = sdfk_generate_source(g_ops, SDFK_OP_COUNT, p->code.data(), p->code.size() / 2, p->result_reg,
+                                         p->sites);
     return p->source.c_str();
 }
 
@@ -404,6 +481,7 @@ static std::shared_ptr<SpecKernel> get_spec(sdfk_program* p, int device) {
     if (e == hipSuccess) e = hipModuleGetFunction(&sk->v1, sk->mod, "sdfk_spec_v1");
     if (e == hipSuccess) e = hipModuleGetFunction(&sk->g4, sk->mod, "sdfk_spec_g4");
     if (e == hipSuccess) e = hipModuleGetFunction(&sk->g1, sk->mod, "sdfk_spec_g1");
+    if (e == hipSuccess && !p->sites.empty()) e = hipModuleGetFunction(&sk->tile, sk->mod, "sdfk_spec_t");
     if (e != hipSuccess) {
         sk->failed = true;
         sk->error = std::string("hipModuleLoadData/GetFunction: ") + hipGetErrorString(e);
@@ -475,6 +553,15 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
     const float* prm = d->d_params;
     const float* tab = d->d_tables;
     if (sk) {
+        if (arr && sk->tile && vec_ok && mode != SDFK_MODE_NOCULL) {
+            // brick-culling tile kernel: handles the ragged end itself
+            const float* co = arr->co;
+            long long stride = arr->stride;
+            void* args[] = {&prm, &tab, &co, &stride, &n, &d_out};
+            const unsigned tiles = (unsigned)((n + 2047) / 2048);
+            HIPCHK(hipModuleLaunchKernel(sk->tile, tiles, 1, 1, 256, 1, 1, 0, stream, args, nullptr));
+            return 0;
+        }
         if (arr) {
             const float* co = arr->co;
             long long stride = arr->stride;

@@ -1,7 +1,9 @@
 // sdfk_codegen.cpp — program -> HIP source for hiprtc (see sdfk_codegen.h).
 #include "sdfk_codegen.h"
 
+#include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <set>
 
 // text of sdfk_device.h / sdfk_access.h, generated at build time by __graft_entry__.build()
@@ -53,56 +55,277 @@ extern "C" __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_spec_g1(
 }
 )SDFKW";
 
-std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32_t* code, size_t n_instr,
-                                 int result_reg) {
-    std::string s;
-    s.reserve(sizeof(kEmbeddedDevice) + sizeof(kEmbeddedAccess) + sizeof(kWrappers) + 96 * n_instr + 512);
-    s += kEmbeddedDevice;
-    s += "\n";
-    s += kEmbeddedAccess;
-    s += "\ntemplate <typename T> static __device__ __forceinline__ T sdfk_point(V3T<T> C0, "
-         "const float* __restrict__ PRM, const float* __restrict__ TAB) {\n";
-    std::set<unsigned> cregs, vregs;
-    for (size_t i = 0; i < n_instr; ++i) {
-        const uint32_t w = code[2 * i];
-        const unsigned op = w & 255u, a = (w >> 8) & 255u;
-        if ((int)op >= n_ops) continue;
-        if (ops[op].kind == SDFK_KIND_C_C) cregs.insert(a);
-        else vregs.insert(a);
-    }
-    char buf[256];
-    for (unsigned c : cregs)
-        if (c != 0) {
-            snprintf(buf, sizeof buf, "    V3T<T> C%u;\n", c);
-            s += buf;
+// Brick-culling tile kernel (only emitted when the program has cull sites).
+//   phase A  the workgroup stages SDFK_TILE points (x, y, z rows) in LDS with 16-byte loads and
+//            reduces an axis-aligned bound per brick of SDFK_BRICK consecutive points
+//   phase B  one lane per brick evaluates the WHOLE tree at the brick centre and turns the
+//            operand gaps at every combiner into a skip mask (exact: see sdfk_probe)
+//   phase C  each wave evaluates its bricks, two points per lane (packed f2), jumping over the
+//            subtrees the mask proves irrelevant (mask is wave-uniform: scalar branches)
+static const char kTileKernel[] = R"SDFKT(
+#define SDFK_TILE 2048
+#define SDFK_TTHREADS 256
+#define SDFK_BRICK 128
+#define SDFK_NBRICK (SDFK_TILE / SDFK_BRICK)
+extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_t(
+    const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
+    long long n, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float sx[SDFK_TILE];
+    __shared__ __attribute__((aligned(16))) float sy[SDFK_TILE];
+    __shared__ __attribute__((aligned(16))) float sz[SDFK_TILE];
+    __shared__ float4 sbound[SDFK_NBRICK];
+    __shared__ unsigned long long smask[SDFK_NBRICK];
+    const long long tile_base = (long long)blockIdx.x * SDFK_TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- phase A ----
+#pragma unroll
+    for (int h = 0; h < SDFK_TILE / (4 * SDFK_TTHREADS); ++h) {
+        const int local = h * 4 * SDFK_TTHREADS + 4 * tid;
+        const long long i = tile_base + local;
+        float4 x, y, z;
+        if (i + 3 < n) {
+            x = *reinterpret_cast<const float4*>(co + i);
+            y = *reinterpret_cast<const float4*>(co + stride + i);
+            z = *reinterpret_cast<const float4*>(co + 2 * stride + i);
+        } else {   // ragged end of the array: repeat the last point (keeps the bounds valid)
+            const long long last = n - 1;
+            const long long i0 = i < last ? i : last, i1 = i + 1 < last ? i + 1 : last,
+                            i2 = i + 2 < last ? i + 2 : last, i3 = i + 3 < last ? i + 3 : last;
+            x = make_float4(co[i0], co[i1], co[i2], co[i3]);
+            y = make_float4(co[stride + i0], co[stride + i1], co[stride + i2], co[stride + i3]);
+            z = make_float4(co[2 * stride + i0], co[2 * stride + i1], co[2 * stride + i2], co[2 * stride + i3]);
         }
-    for (unsigned v : vregs) {
-        snprintf(buf, sizeof buf, "    T V%u;\n", v);
-        s += buf;
+        *reinterpret_cast<float4*>(sx + local) = x;
+        *reinterpret_cast<float4*>(sy + local) = y;
+        *reinterpret_cast<float4*>(sz + local) = z;
+        float lox = fminf(fminf(x.x, x.y), fminf(x.z, x.w)), hix = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
+        float loy = fminf(fminf(y.x, y.y), fminf(y.z, y.w)), hiy = fmaxf(fmaxf(y.x, y.y), fmaxf(y.z, y.w));
+        float loz = fminf(fminf(z.x, z.y), fminf(z.z, z.w)), hiz = fmaxf(fmaxf(z.x, z.y), fmaxf(z.z, z.w));
+#pragma unroll
+        for (int m = 1; m < SDFK_BRICK / 4; m <<= 1) {      // the SDFK_BRICK/4 lanes that hold one brick
+            lox = fminf(lox, __shfl_xor(lox, m)); hix = fmaxf(hix, __shfl_xor(hix, m));
+            loy = fminf(loy, __shfl_xor(loy, m)); hiy = fmaxf(hiy, __shfl_xor(hiy, m));
+            loz = fminf(loz, __shfl_xor(loz, m)); hiz = fmaxf(hiz, __shfl_xor(hiz, m));
+        }
+        if ((lane & (SDFK_BRICK / 4 - 1)) == 0) {
+            const float dx = hix - lox, dy = hiy - loy, dz = hiz - loz;
+            // centre of the box; radius = half diagonal, rounded up
+            sbound[local / SDFK_BRICK] = make_float4(0.5f * (lox + hix), 0.5f * (loy + hiy), 0.5f * (loz + hiz),
+                                                     0.50001f * sqrtf(dx * dx + dy * dy + dz * dz) + 1e-30f);
+        }
     }
-    for (size_t i = 0; i < n_instr; ++i) {
+    __syncthreads();
+    // ---- phase B ----
+    if (tid < SDFK_NBRICK) {
+        const float4 b = sbound[tid];
+        V3 c = {b.x, b.y, b.z};
+        smask[tid] = sdfk_probe(c, b.w, PRM, TAB);
+    }
+    __syncthreads();
+    // ---- phase C ----
+    for (int b = wave; b < SDFK_NBRICK; b += SDFK_TTHREADS / 64) {
+        const unsigned long long mv = smask[b];
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)mv);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(mv >> 32));
+        const unsigned long long mask = ((unsigned long long)hi << 32) | lo;     // wave-uniform (SGPRs)
+        const int local = b * SDFK_BRICK + 2 * lane;
+        V3P p = {*reinterpret_cast<const f2*>(sx + local), *reinterpret_cast<const f2*>(sy + local),
+                 *reinterpret_cast<const f2*>(sz + local)};
+        const f2 r = sdfk_point_culled<f2>(p, mask, PRM, TAB);
+        const long long i = tile_base + local;
+        if (i + 1 < n) *reinterpret_cast<f2*>(out + i) = r;
+        else if (i < n) out[i] = r.x;
+    }
+}
+)SDFKT";
+
+namespace {
+
+struct Gen {
+    const sdfk_opinfo* ops;
+    int n_ops;
+    const uint32_t* code;
+    size_t n_instr;
+    const std::vector<sdfk_cullsite>* sites;
+    std::string s;
+
+    void instr(size_t i, const char* indent) {
+        char buf[256];
         const uint32_t w = code[2 * i], poff = code[2 * i + 1];
         const unsigned op = w & 255u, a = (w >> 8) & 255u, b = (w >> 16) & 255u, c = w >> 24;
-        if ((int)op >= n_ops) continue;
+        if ((int)op >= n_ops) return;
         const sdfk_opinfo& o = ops[op];
         switch (o.kind) {
             case SDFK_KIND_C_C:
-                snprintf(buf, sizeof buf, "    C%u = %s(C%u, PRM + %u, TAB, %u);\n", a, o.func, b, poff, c);
+                snprintf(buf, sizeof buf, "%sC%u = %s(C%u, PRM + %u, TAB, %u);\n", indent, a, o.func, b, poff, c);
                 break;
             case SDFK_KIND_V_C:
-                snprintf(buf, sizeof buf, "    V%u = %s(C%u, PRM + %u, TAB);\n", a, o.func, b, poff);
+                snprintf(buf, sizeof buf, "%sV%u = %s(C%u, PRM + %u, TAB);\n", indent, a, o.func, b, poff);
                 break;
             case SDFK_KIND_V_V:
-                snprintf(buf, sizeof buf, "    V%u = %s(V%u, PRM + %u);\n", a, o.func, b, poff);
+                snprintf(buf, sizeof buf, "%sV%u = %s(V%u, PRM + %u);\n", indent, a, o.func, b, poff);
                 break;
             default:
-                snprintf(buf, sizeof buf, "    V%u = %s(V%u, V%u, PRM + %u);\n", a, o.func, b, c, poff);
+                snprintf(buf, sizeof buf, "%sV%u = %s(V%u, V%u, PRM + %u);\n", indent, a, o.func, b, c, poff);
                 break;
         }
         s += buf;
     }
+
+    void declare(const char* ctype, const char* vtype, bool zero_init) {
+        std::set<unsigned> cregs, vregs;
+        for (size_t i = 0; i < n_instr; ++i) {
+            const uint32_t w = code[2 * i];
+            const unsigned op = w & 255u, a = (w >> 8) & 255u;
+            if ((int)op >= n_ops) continue;
+            if (ops[op].kind == SDFK_KIND_C_C) cregs.insert(a);
+            else vregs.insert(a);
+        }
+        char buf[160];
+        for (unsigned c : cregs)
+            if (c != 0) {
+                snprintf(buf, sizeof buf, zero_init ? "    %s C%u = C0;\n" : "    %s C%u;\n", ctype, c);
+                s += buf;
+            }
+        for (unsigned v : vregs) {
+            snprintf(buf, sizeof buf, zero_init ? "    %s V%u = sp<%s>(0.0f);\n" : "    %s V%u;\n", vtype, v,
+                     vtype);
+            s += buf;
+        }
+    }
+
+    // which site (if any) opens at instruction i and closes no later than hi: the outermost one
+    int site_opening_at(size_t i, size_t hi) const {
+        int best = -1;
+        for (size_t k = 0; k < sites->size(); ++k) {
+            const sdfk_cullsite& t = (*sites)[k];
+            if (t.a0 == i && t.comb <= hi && (best < 0 || t.comb > (*sites)[best].comb)) best = (int)k;
+        }
+        return best;
+    }
+
+    // gap expressions at a site, by combiner
+    void site_ops(const sdfk_cullsite& t, char* gapB, char* gapA, char* wexpr, bool* neg_b, size_t cap) const {
+        const uint32_t w = code[2 * t.comb], poff = code[2 * t.comb + 1];
+        const unsigned b = (w >> 16) & 255u, c = w >> 24;
+        const char* name = ops[w & 255u].name;
+        *neg_b = false;
+        snprintf(wexpr, cap, "0.0f");
+        if (!strcmp(name, "VMIN") || !strcmp(name, "SMIN2") || !strcmp(name, "SMIN3")) {
+            snprintf(gapB, cap, "(V%u - V%u)", c, b);
+            snprintf(gapA, cap, "(V%u - V%u)", b, c);
+        } else if (!strcmp(name, "VMAX") || !strcmp(name, "SMAX3")) {
+            snprintf(gapB, cap, "(V%u - V%u)", b, c);
+            snprintf(gapA, cap, "(V%u - V%u)", c, b);
+        } else {  // VSUBTRACT, SSUB3: max(a, -b)
+            snprintf(gapB, cap, "(V%u + V%u)", b, c);
+            snprintf(gapA, cap, "(-V%u - V%u)", b, c);
+            *neg_b = true;
+        }
+        if (name[0] == 'S') snprintf(wexpr, cap, "PRM[%u]", poff);
+    }
+
+    // ---- probe: full evaluation at a brick centre + skip decisions ----
+    // For a brick of radius rho around the centre c and a combiner with operand fields a, b of
+    // Lipschitz constants L_a, L_b (k = L_a + L_b): gap(c) >= w + k*rho  =>  gap(p) >= w for every p
+    // of the brick, and then the (smooth) min / max returns the other operand bit-exactly.
+    void emit_probe() {
+        s += "\nstatic __device__ __forceinline__ unsigned long long sdfk_probe(V3 C0, float rho, "
+             "const float* __restrict__ PRM, const float* __restrict__ TAB) {\n";
+        declare("V3", "float", false);
+        s += "    unsigned long long mask = 0ull;\n";
+        char buf[512], gB[64], gA[64], wx[32];
+        for (size_t i = 0; i < n_instr; ++i) {
+            for (size_t k = 0; k < sites->size(); ++k) {   // decisions read the operands BEFORE the combiner
+                const sdfk_cullsite& t = (*sites)[k];      // overwrites its destination (dst may alias one)
+                if (t.comb != i) continue;
+                bool neg;
+                site_ops(t, gB, gA, wx, &neg, sizeof gB);
+                const uint32_t w = code[2 * i];
+                const unsigned b = (w >> 16) & 255u, c = w >> 24;
+                snprintf(buf, sizeof buf,
+                         "    { const float thr = %s + %.9gf * rho + 1e-6f * (1.0f + fabsf(V%u) + fabsf(V%u));\n"
+                         "      if (%d && %s >= thr) mask |= %lluull;\n"
+                         "      else if (%d && %s >= thr) mask |= %lluull; }\n",
+                         wx, (double)t.k * 1.0001, b, c, t.skip_b_ok, gB, 2ull << (2 * k), t.skip_a_ok, gA,
+                         1ull << (2 * k));
+                s += buf;
+            }
+            instr(i, "    ");
+        }
+        s += "    return mask;\n}\n";
+    }
+
+    // ---- culled evaluation ----
+    void emit_span(size_t lo, size_t hi, int depth) {
+        std::string ind(4 + 4 * depth, ' ');
+        char buf[512];
+        size_t i = lo;
+        while (i <= hi) {
+            const int k = site_opening_at(i, hi);
+            if (k < 0) {
+                instr(i, ind.c_str());
+                ++i;
+                continue;
+            }
+            const sdfk_cullsite& t = (*sites)[k];
+            // (inside [a0, a1] this site is out of reach: its combiner lies beyond a1)
+            snprintf(buf, sizeof buf, "%sif (!(mask & %lluull)) {\n", ind.c_str(), 1ull << (2 * k));
+            s += buf;
+            emit_span(t.a0, t.a1, depth + 1);
+            s += ind + "}\n";
+            snprintf(buf, sizeof buf, "%sif (!(mask & %lluull)) {\n", ind.c_str(), 2ull << (2 * k));
+            s += buf;
+            emit_span(t.b0, t.b1, depth + 1);
+            s += ind + "}\n";
+            const uint32_t w = code[2 * t.comb];
+            const unsigned a = (w >> 8) & 255u, b = (w >> 16) & 255u, c = w >> 24;
+            char gB[64], gA[64], wx[32];
+            bool neg;
+            site_ops(t, gB, gA, wx, &neg, sizeof gB);
+            snprintf(buf, sizeof buf, "%sif (mask & %lluull) V%u = %sV%u;\n%selse if (mask & %lluull) V%u = V%u;\n%selse {\n",
+                     ind.c_str(), 1ull << (2 * k), a, neg ? "-" : "", c, ind.c_str(), 2ull << (2 * k), a, b,
+                     ind.c_str());
+            s += buf;
+            instr(t.comb, (ind + "    ").c_str());
+            s += ind + "}\n";
+            i = t.comb + 1;
+        }
+    }
+
+    void emit_culled(int result_reg) {
+        s += "\ntemplate <typename T> static __device__ __forceinline__ T sdfk_point_culled(V3T<T> C0, "
+             "unsigned long long mask, const float* __restrict__ PRM, const float* __restrict__ TAB) {\n";
+        declare("V3T<T>", "T", true);
+        emit_span(0, n_instr - 1, 0);
+        char buf[64];
+        snprintf(buf, sizeof buf, "    return V%d;\n}\n", result_reg);
+        s += buf;
+    }
+};
+
+}  // namespace
+
+std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32_t* code, size_t n_instr,
+                                 int result_reg, const std::vector<sdfk_cullsite>& sites) {
+    Gen g{ops, n_ops, code, n_instr, &sites, std::string()};
+    g.s.reserve(sizeof(kEmbeddedDevice) + sizeof(kEmbeddedAccess) + sizeof(kWrappers) + sizeof(kTileKernel) +
+                400 * n_instr + 1024);
+    g.s += kEmbeddedDevice;
+    g.s += "\n";
+    g.s += kEmbeddedAccess;
+    g.s += "\ntemplate <typename T> static __device__ __forceinline__ T sdfk_point(V3T<T> C0, "
+           "const float* __restrict__ PRM, const float* __restrict__ TAB) {\n";
+    g.declare("V3T<T>", "T", false);
+    for (size_t i = 0; i < n_instr; ++i) g.instr(i, "    ");
+    char buf[64];
     snprintf(buf, sizeof buf, "    return V%d;\n}\n", result_reg);
-    s += buf;
-    s += kWrappers;
-    return s;
+    g.s += buf;
+    g.s += kWrappers;
+    if (!sites.empty()) {
+        g.emit_probe();
+        g.emit_culled(result_reg);
+        g.s += kTileKernel;
+    }
+    return g.s;
 }

@@ -4,6 +4,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <string>
+#include <vector>
 
 enum sdfk_kind { SDFK_KIND_C_C = 0, SDFK_KIND_V_C = 1, SDFK_KIND_V_V = 2, SDFK_KIND_V_VV = 3 };
 
@@ -14,10 +15,20 @@ struct sdfk_opinfo {
     const char* func;
 };
 
+// One brick-culling site: the V_VV combiner at instruction `comb` whose first operand is produced by
+// instructions [a0, a1] and whose second operand by [b0, b1] (b1 == comb - 1). k = L_a + L_b
+// (Lipschitz constants of the two operand fields w.r.t. the root point). skip_*_ok: skipping that
+// range has no side effect on registers read later (checked by sdfk_program_set_cull).
+struct sdfk_cullsite {
+    uint32_t comb, a0, a1, b0, b1;
+    float k;
+    int skip_a_ok, skip_b_ok;
+};
+
 // Specialised per TOPOLOGY: opcodes, register operands and parameter offsets are baked into the
 // text; parameter VALUES stay in the runtime table (PRM), so one compiled kernel serves every
 // tree of the same shape.
 std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32_t* code, size_t n_instr,
-                                 int result_reg);
+                                 int result_reg, const std::vector<sdfk_cullsite>& sites);
 
 #endif

@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--grid", type=int, default=1024, help="requested resolution per axis (odd-converted)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg5"])
-    ap.add_argument("--mode", default="auto", choices=["auto", "interpret"])
+    ap.add_argument("--mode", default="auto", choices=["auto", "interpret", "nocull"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-allgather", action="store_true")
     return ap.parse_args()
@@ -137,8 +137,9 @@ def main():
     _engine.grid_fill(co.data_ptr(), stride, axes, start, count, stream=stream)
 
     low = lower_geometry(tree)
-    prog = _engine.Program(low.code, low.params, low.tables, low.result_reg)
-    mode = _engine.MODE_INTERPRET if args.mode == "interpret" else _engine.MODE_SPECIALIZED
+    prog = _engine.Program.from_lowered(low)
+    mode = {"interpret": _engine.MODE_INTERPRET, "nocull": _engine.MODE_NOCULL}.get(args.mode, _engine.MODE_SPECIALIZED)
+    culled = mode == _engine.MODE_SPECIALIZED and len(low.cull_sites) > 0
 
     def step():
         prog.eval_device(co.data_ptr(), count, stride, out.data_ptr(), stream=stream, mode=mode)
@@ -220,8 +221,10 @@ def main():
             "config": {"workload": desc, "grid": "%dx%dx%d (request %d^3), size %s" % (res[0], res[1], res[2],
                                                                                       args.grid, tuple(size)),
                        "points": n_total, "points_per_gpu": count, "sharding": "contiguous x-slabs, no collective",
-                       "kernel": "sdfk_spec_v4 (hiprtc, topology-specialised)" if mode != _engine.MODE_INTERPRET
-                       else "sdfk_interp_kernel", "instructions": int(low.code.shape[0])},
+                       "kernel": ("sdfk_spec_t (hiprtc, topology-specialised, exact brick culling)" if culled else
+                                  "sdfk_spec_v4 (hiprtc, topology-specialised)") if mode != _engine.MODE_INTERPRET
+                       else "sdfk_interp_kernel", "instructions": int(low.code.shape[0]),
+                       "cull_sites": int(len(low.cull_sites)) if culled else 0},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel_ms": kernel_ms_max, "bytes_per_point": BYTES_PER_POINT,

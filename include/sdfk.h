@@ -29,6 +29,7 @@ extern "C" {
 #define SDFK_MODE_AUTO 0        /* topology-specialised kernel (hiprtc), built on first use and cached */
 #define SDFK_MODE_INTERPRET 1   /* generic register-machine interpreter kernel */
 #define SDFK_MODE_SPECIALIZED 2 /* as AUTO but fail instead of falling back if hiprtc fails */
+#define SDFK_MODE_NOCULL 3      /* specialised kernel with brick culling switched off (A/B runs, tests) */
 
 typedef struct sdfk_program sdfk_program;
 
@@ -53,6 +54,14 @@ sdfk_program* sdfk_program_create(const uint32_t* code, size_t n_instr, const fl
 void sdfk_program_destroy(sdfk_program* prog);
 /* Replace the parameter values of a program in place (same topology, new shape parameters). */
 int sdfk_program_set_params(sdfk_program* prog, const float* params, size_t n_params);
+/* Brick culling (optional, before first use of the program): n_sites rows {combiner index, a_start,
+ * a_end, b_start, b_end} naming, for min/max-type combiners, the instruction ranges that produce the
+ * two operands, and k[i] = L_a + L_b, the sum of the Lipschitz constants of the operand fields with
+ * respect to the input point. The specialised kernel then evaluates the tree once per brick of 128
+ * consecutive points and skips operand subtrees that provably cannot change the result on that brick;
+ * results are bit-identical to the un-culled evaluation. Sites whose ranges have side effects on
+ * registers read later are kept but never skipped. */
+int sdfk_program_set_cull(sdfk_program* prog, const uint32_t* sites, size_t n_sites, const float* k);
 /* Generated HIP source of the specialised kernel (for inspection / tests); NULL on error. */
 const char* sdfk_program_source(sdfk_program* prog);
 /* Compile the specialised kernel for gfx950 with hiprtc without needing a GPU (build check).

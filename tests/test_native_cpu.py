@@ -94,3 +94,27 @@ def test_in_place_modifications_write_through_only_where_the_reference_aliases()
     box = [w for w in low.code[:, 0] if _ops.OPS[w & 255].name == "P_BOX"][0]
     assert (sym >> 8) & 255 != (sym >> 16) & 255          # wrote a fresh register
     assert (box >> 16) & 255 == (sym >> 16) & 255          # sibling still reads the source register
+
+
+def test_cull_sites_are_validated(built):
+    low = lower_geometry(scenes.cfg2_tree(ns))
+    assert low.cull_sites.shape == (9, 5) and np.all(low.cull_k >= 2.0 - 1e-6)
+    prog = built.Program.from_lowered(low)
+    src = prog.source()
+    assert "sdfk_probe" in src and "sdfk_point_culled" in src and "sdfk_spec_t" in src
+    assert prog.compile_check() > 1000
+    bad = low.cull_sites.copy()
+    bad[0, 2] += 1                                           # a-range no longer adjacent to the b-range
+    with pytest.raises(built.SdfkError):
+        built.Program(low.code, low.params, low.tables, low.result_reg, bad, low.cull_k)
+    bad = low.cull_sites.copy()
+    bad[0, 0] -= 1                                           # not a combiner
+    with pytest.raises(built.SdfkError):
+        built.Program(low.code, low.params, low.tables, low.result_reg, bad, low.cull_k)
+    with pytest.raises(built.SdfkError):
+        built.Program(low.code, low.params, low.tables, low.result_reg, low.cull_sites, low.cull_k * np.inf)
+    # no Lipschitz bound -> no sites: twist / repetition / sign below a union
+    a = ns.Box(0.5, 0.3, 0.2)
+    a.twist(1.0)
+    u = ns.CombineGeometry("UNION2").combine(a, ns.Sphere(0.3))
+    assert len(lower_geometry(u).cull_sites) == 0
