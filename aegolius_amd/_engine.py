@@ -33,6 +33,7 @@ SIGNATURES = {
     "sdfk_eval_host": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _int, _int]),
     "sdfk_eval_grid": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _int]),
     "sdfk_set_default_mode": (None, [_int]),
+    "sdfk_debug_brick_masks": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "sdfk_linspace_f32": (_int, [_c.c_double, _c.c_double, _i64, _vp]),
     "sdfk_grid_fill": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp]),
     "sdfk_set_device": (_int, [_int]),

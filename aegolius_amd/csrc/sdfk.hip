@@ -150,7 +150,7 @@ struct DevState {
 
 struct SpecKernel {
     hipModule_t mod = nullptr;
-    hipFunction_t v4 = nullptr, v1 = nullptr, g4 = nullptr, g1 = nullptr, tile = nullptr;
+    hipFunction_t v4 = nullptr, v1 = nullptr, g4 = nullptr, g1 = nullptr, tile = nullptr, tmask = nullptr;
     bool failed = false;
     std::string error;
 };
@@ -424,14 +424,27 @@ extern "C" const char* sdfk_program_source(sdfk_program* p) {
     return p->source.c_str();
 }
 
+// tile geometry of the brick-culling kernel (overridable for experiments: SDFK_TILE / SDFK_TTHREADS)
+static int tile_points() {
+    static int v = [] { const char* e = getenv("SDFK_TILE"); int t = e ? atoi(e) : 2048; return (t >= 512 && t % 512 == 0 && t <= 8192) ? t : 2048; }();
+    return v;
+}
+static int tile_threads() {
+    static int v = [] { const char* e = getenv("SDFK_TTHREADS"); int t = e ? atoi(e) : 256; return (t >= 64 && t <= 1024 && t % 64 == 0) ? t : 256; }();
+    return v;
+}
+
 static int rtc_compile(const std::string& src, std::vector<char>* out, std::string* log) {
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "sdfk_spec.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
         *log = "hiprtcCreateProgram failed";
         return -1;
     }
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"};
-    hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+    char d_tile[48], d_thr[48];
+    snprintf(d_tile, sizeof d_tile, "-DSDFK_TILE=%d", tile_points());
+    snprintf(d_thr, sizeof d_thr, "-DSDFK_TTHREADS=%d", tile_threads());
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", d_tile, d_thr};
+    hiprtcResult r = hiprtcCompileProgram(prog, 6, opts);
     size_t ls = 0;
     hiprtcGetProgramLogSize(prog, &ls);
     if (ls > 1) {
@@ -482,6 +495,7 @@ static std::shared_ptr<SpecKernel> get_spec(sdfk_program* p, int device) {
     if (e == hipSuccess) e = hipModuleGetFunction(&sk->g4, sk->mod, "sdfk_spec_g4");
     if (e == hipSuccess) e = hipModuleGetFunction(&sk->g1, sk->mod, "sdfk_spec_g1");
     if (e == hipSuccess && !p->sites.empty()) e = hipModuleGetFunction(&sk->tile, sk->mod, "sdfk_spec_t");
+    if (e == hipSuccess && !p->sites.empty()) e = hipModuleGetFunction(&sk->tmask, sk->mod, "sdfk_spec_tmask");
     if (e != hipSuccess) {
         sk->failed = true;
         sk->error = std::string("hipModuleLoadData/GetFunction: ") + hipGetErrorString(e);
@@ -558,8 +572,8 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
             const float* co = arr->co;
             long long stride = arr->stride;
             void* args[] = {&prm, &tab, &co, &stride, &n, &d_out};
-            const unsigned tiles = (unsigned)((n + 2047) / 2048);
-            HIPCHK(hipModuleLaunchKernel(sk->tile, tiles, 1, 1, 256, 1, 1, 0, stream, args, nullptr));
+            const unsigned tiles = (unsigned)((n + tile_points() - 1) / tile_points());
+            HIPCHK(hipModuleLaunchKernel(sk->tile, tiles, 1, 1, tile_threads(), 1, 1, 0, stream, args, nullptr));
             return 0;
         }
         if (arr) {
@@ -625,6 +639,29 @@ extern "C" int sdfk_eval_device(sdfk_program* p, const float* d_co, int64_t n, i
     SrcArray a = {d_co, (long long)row_stride};
     bool vec_ok = aligned16(d_co) && aligned16(d_out) && (row_stride % 4 == 0);
     return run(p, &a, nullptr, n, d_out, stream, mode, vec_ok);
+}
+
+extern "C" int sdfk_debug_brick_masks(sdfk_program* p, const float* d_co, int64_t n, int64_t row_stride,
+                                      uint64_t* d_masks, void* stream_) {
+    if (!p || !d_co || !d_masks) return fail(-1, "sdfk_debug_brick_masks: null argument");
+    if (!(aligned16(d_co) && row_stride % 4 == 0 && row_stride >= n && n > 0))
+        return fail(-1, "sdfk_debug_brick_masks: needs 16-byte aligned rows");
+    if (p->sites.empty()) return fail(-2, "sdfk_debug_brick_masks: program has no cull sites");
+    hipStream_t stream = (hipStream_t)stream_;
+    int device = 0;
+    HIPCHK(hipGetDevice(&device));
+    DevState* d = nullptr;
+    int rc = ensure_resident(p, device, stream, &d);
+    if (rc) return rc;
+    std::shared_ptr<SpecKernel> sk = get_spec(p, device);
+    if (sk->failed || !sk->tmask) return fail(-3, "specialised kernel unavailable: " + sk->error);
+    const float* prm = d->d_params;
+    const float* tab = d->d_tables;
+    long long stride = row_stride, nn = n;
+    void* args[] = {&prm, &tab, &d_co, &stride, &nn, &d_masks};
+    HIPCHK(hipModuleLaunchKernel(sk->tmask, (unsigned)((n + tile_points() - 1) / tile_points()), 1, 1, tile_threads(),
+                                 1, 1, 0, stream, args, nullptr));
+    return 0;
 }
 
 // ---- grids -------------------------------------------------------------------------------------

@@ -57,26 +57,33 @@ extern "C" __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_spec_g1(
 
 // Brick-culling tile kernel (only emitted when the program has cull sites).
 //   phase A  the workgroup stages SDFK_TILE points (x, y, z rows) in LDS with 16-byte loads and
-//            reduces an axis-aligned bound per brick of SDFK_BRICK consecutive points
+//            reduces a bounding sphere per brick of SDFK_BRICK consecutive points
 //   phase B  one lane per brick evaluates the WHOLE tree at the brick centre and turns the
 //            operand gaps at every combiner into a skip mask (exact: see sdfk_probe)
 //   phase C  each wave evaluates its bricks, two points per lane (packed f2), jumping over the
 //            subtrees the mask proves irrelevant (mask is wave-uniform: scalar branches)
 static const char kTileKernel[] = R"SDFKT(
-#define SDFK_TILE 2048
+#ifndef SDFK_TILE
+#define SDFK_TILE 2048          // points staged per workgroup (host launch code must agree: sdfk.hip)
+#endif
+#ifndef SDFK_TTHREADS
 #define SDFK_TTHREADS 256
+#endif
 #define SDFK_BRICK 128
 #define SDFK_NBRICK (SDFK_TILE / SDFK_BRICK)
-extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_t(
-    const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
-    long long n, float* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float sx[SDFK_TILE];
-    __shared__ __attribute__((aligned(16))) float sy[SDFK_TILE];
-    __shared__ __attribute__((aligned(16))) float sz[SDFK_TILE];
-    __shared__ float4 sbound[SDFK_NBRICK];
-    __shared__ unsigned long long smask[SDFK_NBRICK];
+
+struct sdfk_tilebuf {
+    float x[SDFK_TILE], y[SDFK_TILE], z[SDFK_TILE];
+    float4 bound[SDFK_NBRICK];
+    unsigned long long mask[SDFK_NBRICK];
+};
+
+// phases A and B (shared by the evaluation kernel and the mask-dump kernel)
+static __device__ __forceinline__ void sdfk_tile_prepare(const float* __restrict__ PRM, const float* __restrict__ TAB,
+                                                         const float* __restrict__ co, long long stride, long long n,
+                                                         sdfk_tilebuf* buf) {
     const long long tile_base = (long long)blockIdx.x * SDFK_TILE;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     // ---- phase A ----
 #pragma unroll
     for (int h = 0; h < SDFK_TILE / (4 * SDFK_TTHREADS); ++h) {
@@ -95,42 +102,58 @@ extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_t(
             y = make_float4(co[stride + i0], co[stride + i1], co[stride + i2], co[stride + i3]);
             z = make_float4(co[2 * stride + i0], co[2 * stride + i1], co[2 * stride + i2], co[2 * stride + i3]);
         }
-        *reinterpret_cast<float4*>(sx + local) = x;
-        *reinterpret_cast<float4*>(sy + local) = y;
-        *reinterpret_cast<float4*>(sz + local) = z;
-        float lox = fminf(fminf(x.x, x.y), fminf(x.z, x.w)), hix = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
-        float loy = fminf(fminf(y.x, y.y), fminf(y.z, y.w)), hiy = fmaxf(fmaxf(y.x, y.y), fmaxf(y.z, y.w));
-        float loz = fminf(fminf(z.x, z.y), fminf(z.z, z.w)), hiz = fmaxf(fmaxf(z.x, z.y), fmaxf(z.z, z.w));
+        *reinterpret_cast<float4*>(buf->x + local) = x;
+        *reinterpret_cast<float4*>(buf->y + local) = y;
+        *reinterpret_cast<float4*>(buf->z + local) = z;
+        // bounding sphere of the brick (the SDFK_BRICK/4 lanes of this load): centre = midpoint of the brick's
+        // first and last point, radius = largest distance of any of its points from that centre
+        const int first = lane & ~(SDFK_BRICK / 4 - 1), lastl = first + SDFK_BRICK / 4 - 1;
+        const float cx = 0.5f * (__shfl(x.x, first) + __shfl(x.w, lastl));
+        const float cy = 0.5f * (__shfl(y.x, first) + __shfl(y.w, lastl));
+        const float cz = 0.5f * (__shfl(z.x, first) + __shfl(z.w, lastl));
+        const f2 xa = {x.x - cx, x.y - cx}, xb = {x.z - cx, x.w - cx}, ya = {y.x - cy, y.y - cy}, yb = {y.z - cy, y.w - cy},
+                 za = {z.x - cz, z.y - cz}, zb = {z.z - cz, z.w - cz};
+        const f2 da = sd_fma(xa, xa, sd_fma(ya, ya, za * za)), db = sd_fma(xb, xb, sd_fma(yb, yb, zb * zb));
+        float r2 = sd_rawmax(sd_rawmax(da.x, da.y), sd_rawmax(db.x, db.y));
 #pragma unroll
-        for (int m = 1; m < SDFK_BRICK / 4; m <<= 1) {      // the SDFK_BRICK/4 lanes that hold one brick
-            lox = fminf(lox, __shfl_xor(lox, m)); hix = fmaxf(hix, __shfl_xor(hix, m));
-            loy = fminf(loy, __shfl_xor(loy, m)); hiy = fmaxf(hiy, __shfl_xor(hiy, m));
-            loz = fminf(loz, __shfl_xor(loz, m)); hiz = fmaxf(hiz, __shfl_xor(hiz, m));
-        }
-        if ((lane & (SDFK_BRICK / 4 - 1)) == 0) {
-            const float dx = hix - lox, dy = hiy - loy, dz = hiz - loz;
-            // centre of the box; radius = half diagonal, rounded up
-            sbound[local / SDFK_BRICK] = make_float4(0.5f * (lox + hix), 0.5f * (loy + hiy), 0.5f * (loz + hiz),
-                                                     0.50001f * sqrtf(dx * dx + dy * dy + dz * dz) + 1e-30f);
-        }
+        for (int m = 1; m < SDFK_BRICK / 4; m <<= 1) r2 = sd_rawmax(r2, __shfl_xor(r2, m));
+        if ((lane & (SDFK_BRICK / 4 - 1)) == 0)
+            buf->bound[local / SDFK_BRICK] = make_float4(cx, cy, cz, 1.00001f * sqrtf(r2) + 1e-30f);
     }
     __syncthreads();
     // ---- phase B ----
     if (tid < SDFK_NBRICK) {
-        const float4 b = sbound[tid];
+        const float4 b = buf->bound[tid];
         V3 c = {b.x, b.y, b.z};
-        smask[tid] = sdfk_probe(c, b.w, PRM, TAB);
+        buf->mask[tid] = sdfk_probe(c, b.w, PRM, TAB);
     }
     __syncthreads();
+}
+// debugging / test aid: the skip masks of every brick (2 bits per site: bit 2k = skip first operand,
+// bit 2k+1 = skip second operand)
+extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_tmask(
+    const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
+    long long n, unsigned long long* __restrict__ masks) {
+    __shared__ __attribute__((aligned(16))) sdfk_tilebuf buf;
+    sdfk_tile_prepare(PRM, TAB, co, stride, n, &buf);
+    if (threadIdx.x < SDFK_NBRICK) masks[(long long)blockIdx.x * SDFK_NBRICK + threadIdx.x] = buf.mask[threadIdx.x];
+}
+extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_t(
+    const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
+    long long n, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) sdfk_tilebuf buf;
+    const long long tile_base = (long long)blockIdx.x * SDFK_TILE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    sdfk_tile_prepare(PRM, TAB, co, stride, n, &buf);
     // ---- phase C ----
     for (int b = wave; b < SDFK_NBRICK; b += SDFK_TTHREADS / 64) {
-        const unsigned long long mv = smask[b];
+        const unsigned long long mv = buf.mask[b];
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)mv);
         const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(mv >> 32));
         const unsigned long long mask = ((unsigned long long)hi << 32) | lo;     // wave-uniform (SGPRs)
         const int local = b * SDFK_BRICK + 2 * lane;
-        V3P p = {*reinterpret_cast<const f2*>(sx + local), *reinterpret_cast<const f2*>(sy + local),
-                 *reinterpret_cast<const f2*>(sz + local)};
+        V3P p = {*reinterpret_cast<const f2*>(buf.x + local), *reinterpret_cast<const f2*>(buf.y + local),
+                 *reinterpret_cast<const f2*>(buf.z + local)};
         const f2 r = sdfk_point_culled<f2>(p, mask, PRM, TAB);
         const long long i = tile_base + local;
         if (i + 1 < n) *reinterpret_cast<f2*>(out + i) = r;
@@ -173,6 +196,7 @@ struct Gen {
     }
 
     void declare(const char* ctype, const char* vtype, bool zero_init) {
+        zero_init = false;   // skipped subtrees never have their registers read (set_cull's liveness check)
         std::set<unsigned> cregs, vregs;
         for (size_t i = 0; i < n_instr; ++i) {
             const uint32_t w = code[2 * i];

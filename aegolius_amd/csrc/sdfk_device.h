@@ -55,6 +55,12 @@ SDFK_DEV float sd_min(float a, float b) { return __builtin_fminf(a, b); }
 SDFK_DEV f2 sd_min(f2 a, f2 b) { f2 r = {__builtin_fminf(a.x, b.x), __builtin_fminf(a.y, b.y)}; return r; }
 SDFK_DEV float sd_max(float a, float b) { return __builtin_fmaxf(a, b); }
 SDFK_DEV f2 sd_max(f2 a, f2 b) { f2 r = {__builtin_fmaxf(a.x, b.x), __builtin_fmaxf(a.y, b.y)}; return r; }
+// one v_max_f32, no canonicalising pre-op (inputs are plain loaded / computed numbers)
+SDFK_DEV float sd_rawmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 SDFK_DEV float sd_abs(float a) { return __builtin_fabsf(a); }
 SDFK_DEV f2 sd_abs(f2 a) { f2 r = {__builtin_fabsf(a.x), __builtin_fabsf(a.y)}; return r; }
 // np.sign: -1, 0, +1

@@ -86,6 +86,10 @@ int sdfk_eval_host(sdfk_program* prog, const void* co, int co_dtype, int64_t n, 
 int sdfk_eval_grid(sdfk_program* prog, const float* ax0, int64_t n0, const float* ax1, int64_t n1, const float* ax2,
                    int64_t n2, int64_t start, int64_t count, float* d_out, void* stream, int mode);
 void sdfk_set_default_mode(int mode);
+/* Test / diagnostics aid for brick culling: writes one 64-bit skip mask per brick of 128 consecutive
+ * points (ceil(n / 2048) * 16 entries; bit 2k = first operand of site k skipped, bit 2k+1 = second). */
+int sdfk_debug_brick_masks(sdfk_program* prog, const float* d_co, int64_t n, int64_t row_stride, uint64_t* d_masks,
+                           void* stream);
 
 /* ---- grid builder -----------------------------------------------------------------------------
  * numpy.linspace(lo, hi, n) in float64 (step = (hi-lo)/(n-1); y[i] = i*step + lo; y[n-1] = hi),
