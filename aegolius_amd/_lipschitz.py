@@ -59,7 +59,7 @@ V_VV = {
 }
 # combiners at which a whole operand subtree can be skipped
 CULLABLE = ("VMIN", "VMAX", "VSUBTRACT", "SMIN2", "SMIN3", "SMAX3", "SSUB3")
-MAX_SITES = 32
+MAX_SITES = 31     # two mask bits per site; bit 63 of the brick mask flags an x/y-constant run
 
 
 def factor(table, name, params):

@@ -382,7 +382,7 @@ static bool is_cullable_op(unsigned op) {
 
 extern "C" int sdfk_program_set_cull(sdfk_program* p, const uint32_t* rows, size_t n_sites, const float* k) {
     if (!p) return fail(-1, "null program");
-    if (n_sites > 32) return fail(-2, "sdfk_program_set_cull: at most 32 sites");
+    if (n_sites > 31) return fail(-2, "sdfk_program_set_cull: at most 31 sites");
     if (n_sites && (!rows || !k)) return fail(-1, "sdfk_program_set_cull: null arrays");
     std::lock_guard<std::mutex> lk(p->mu);
     if (!p->source.empty() || !p->dev.empty())
@@ -426,11 +426,11 @@ extern "C" const char* sdfk_program_source(sdfk_program* p) {
 
 // tile geometry of the brick-culling kernel (overridable for experiments: SDFK_TILE / SDFK_TTHREADS)
 static int tile_points() {
-    static int v = [] { const char* e = getenv("SDFK_TILE"); int t = e ? atoi(e) : 2048; return (t >= 512 && t % 512 == 0 && t <= 8192) ? t : 2048; }();
+    static int v = [] { const char* e = getenv("SDFK_TILE"); int t = e ? atoi(e) : 1024; return (t >= 512 && t % 512 == 0 && t <= 8192) ? t : 1024; }();
     return v;
 }
 static int tile_threads() {
-    static int v = [] { const char* e = getenv("SDFK_TTHREADS"); int t = e ? atoi(e) : 256; return (t >= 64 && t <= 1024 && t % 64 == 0) ? t : 256; }();
+    static int v = [] { const char* e = getenv("SDFK_TTHREADS"); int t = e ? atoi(e) : 128; return (t >= 64 && t <= 1024 && t % 64 == 0) ? t : 128; }();
     return v;
 }
 
@@ -443,8 +443,21 @@ static int rtc_compile(const std::string& src, std::vector<char>* out, std::stri
     char d_tile[48], d_thr[48];
     snprintf(d_tile, sizeof d_tile, "-DSDFK_TILE=%d", tile_points());
     snprintf(d_thr, sizeof d_thr, "-DSDFK_TTHREADS=%d", tile_threads());
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", d_tile, d_thr};
-    hiprtcResult r = hiprtcCompileProgram(prog, 6, opts);
+    std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", d_tile, d_thr};
+    // experiment hook: extra -D switches for the generated source (space separated), e.g. SDFK_RTC_DEFS="-DSDFK_NO_ZRUN"
+    std::vector<std::string> extra;
+    if (const char* e = getenv("SDFK_RTC_DEFS")) {
+        std::string all(e);
+        size_t pos = 0;
+        while (pos < all.size()) {
+            size_t sp = all.find(' ', pos);
+            if (sp == std::string::npos) sp = all.size();
+            if (sp > pos && all.compare(pos, 2, "-D") == 0) extra.push_back(all.substr(pos, sp - pos));
+            pos = sp + 1;
+        }
+    }
+    for (const std::string& x : extra) opts.push_back(x.c_str());
+    hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
     size_t ls = 0;
     hiprtcGetProgramLogSize(prog, &ls);
     if (ls > 1) {

@@ -64,18 +64,25 @@ extern "C" __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_spec_g1(
 //            subtrees the mask proves irrelevant (mask is wave-uniform: scalar branches)
 static const char kTileKernel[] = R"SDFKT(
 #ifndef SDFK_TILE
-#define SDFK_TILE 2048          // points staged per workgroup (host launch code must agree: sdfk.hip)
+#define SDFK_TILE 1024          // points staged per workgroup (host launch code must agree: sdfk.hip)
 #endif
 #ifndef SDFK_TTHREADS
-#define SDFK_TTHREADS 256
+#define SDFK_TTHREADS 128
 #endif
 #define SDFK_BRICK 128
 #define SDFK_NBRICK (SDFK_TILE / SDFK_BRICK)
+static_assert(SDFK_NBRICK <= SDFK_TTHREADS && SDFK_TILE % (4 * SDFK_TTHREADS) == 0, "tile geometry");
 
+// LDS image of one tile. Only z is staged per point: bricks whose points share x and y (rows of a regular
+// grid; detected bitwise) keep that pair once per brick, other bricks re-read their x / y rows from global
+// memory in phase C (L2-resident, they were loaded in phase A).
 struct sdfk_tilebuf {
-    float x[SDFK_TILE], y[SDFK_TILE], z[SDFK_TILE];
-    float4 bound[SDFK_NBRICK];
-    unsigned long long mask[SDFK_NBRICK];
+    float z[SDFK_TILE];
+    float4 bound[SDFK_NBRICK];              // bounding sphere: centre, radius
+    unsigned long long mask[SDFK_NBRICK];   // bits 0..61: two per cull site; bit 63: brick is an x/y-constant run
+    float2 xy[SDFK_NBRICK];                 // the shared x, y of such a run
+    float base[SDFK_NBRICK][3 * SDFK_NROOT];
+    unsigned zrun[SDFK_NBRICK];
 };
 
 // phases A and B (shared by the evaluation kernel and the mask-dump kernel)
@@ -85,7 +92,7 @@ static __device__ __forceinline__ void sdfk_tile_prepare(const float* __restrict
     const long long tile_base = (long long)blockIdx.x * SDFK_TILE;
     const int tid = threadIdx.x, lane = tid & 63;
     // ---- phase A ----
-#pragma unroll
+#pragma unroll 2
     for (int h = 0; h < SDFK_TILE / (4 * SDFK_TTHREADS); ++h) {
         const int local = h * 4 * SDFK_TTHREADS + 4 * tid;
         const long long i = tile_base + local;
@@ -102,14 +109,13 @@ static __device__ __forceinline__ void sdfk_tile_prepare(const float* __restrict
             y = make_float4(co[stride + i0], co[stride + i1], co[stride + i2], co[stride + i3]);
             z = make_float4(co[2 * stride + i0], co[2 * stride + i1], co[2 * stride + i2], co[2 * stride + i3]);
         }
-        *reinterpret_cast<float4*>(buf->x + local) = x;
-        *reinterpret_cast<float4*>(buf->y + local) = y;
         *reinterpret_cast<float4*>(buf->z + local) = z;
         // bounding sphere of the brick (the SDFK_BRICK/4 lanes of this load): centre = midpoint of the brick's
         // first and last point, radius = largest distance of any of its points from that centre
         const int first = lane & ~(SDFK_BRICK / 4 - 1), lastl = first + SDFK_BRICK / 4 - 1;
-        const float cx = 0.5f * (__shfl(x.x, first) + __shfl(x.w, lastl));
-        const float cy = 0.5f * (__shfl(y.x, first) + __shfl(y.w, lastl));
+        const float fx = __shfl(x.x, first), fy = __shfl(y.x, first);
+        const float cx = 0.5f * (fx + __shfl(x.w, lastl));
+        const float cy = 0.5f * (fy + __shfl(y.w, lastl));
         const float cz = 0.5f * (__shfl(z.x, first) + __shfl(z.w, lastl));
         const f2 xa = {x.x - cx, x.y - cx}, xb = {x.z - cx, x.w - cx}, ya = {y.x - cy, y.y - cy}, yb = {y.z - cy, y.w - cy},
                  za = {z.x - cz, z.y - cz}, zb = {z.z - cz, z.w - cz};
@@ -117,26 +123,38 @@ static __device__ __forceinline__ void sdfk_tile_prepare(const float* __restrict
         float r2 = sd_rawmax(sd_rawmax(da.x, da.y), sd_rawmax(db.x, db.y));
 #pragma unroll
         for (int m = 1; m < SDFK_BRICK / 4; m <<= 1) r2 = sd_rawmax(r2, __shfl_xor(r2, m));
-        if ((lane & (SDFK_BRICK / 4 - 1)) == 0)
-            buf->bound[local / SDFK_BRICK] = make_float4(cx, cy, cz, 1.00001f * sqrtf(r2) + 1e-30f);
+        // does every point of the brick share x and y (a row of a regular grid)? bitwise comparison
+        const bool same = x.x == x.y && x.y == x.z && x.z == x.w && x.x == fx && y.x == y.y && y.y == y.z &&
+                          y.z == y.w && y.x == fy;
+        const unsigned long long bal = __ballot(same);
+        if ((lane & (SDFK_BRICK / 4 - 1)) == 0) {
+            const int b = local / SDFK_BRICK;
+            buf->bound[b] = make_float4(cx, cy, cz, 1.00001f * sqrtf(r2) + 1e-30f);
+            const unsigned long long want = ((1ull << (SDFK_BRICK / 4)) - 1ull) << first;
+            buf->zrun[b] = ((bal & want) == want) ? 1u : 0u;
+            buf->xy[b] = make_float2(fx, fy);
+        }
     }
     __syncthreads();
     // ---- phase B ----
-    if (tid < SDFK_NBRICK) {
-        const float4 b = buf->bound[tid];
-        V3 c = {b.x, b.y, b.z};
-        buf->mask[tid] = sdfk_probe(c, b.w, PRM, TAB);
+    if (tid < SDFK_NBRICK) {                   // SDFK_NBRICK <= SDFK_TTHREADS (static_assert below)
+        const int b = tid;
+        const float4 bb = buf->bound[b];
+        V3T<float> c = {bb.x, bb.y, bb.z};     // for an x/y-constant run the midpoint has exactly that x and y
+        const unsigned long long m = sdfk_probe(c, bb.w, buf->base[b], PRM, TAB);
+        buf->mask[b] = m | ((unsigned long long)buf->zrun[b] << 63);
     }
     __syncthreads();
 }
 // debugging / test aid: the skip masks of every brick (2 bits per site: bit 2k = skip first operand,
-// bit 2k+1 = skip second operand)
+// bit 2k+1 = skip second operand; bit 63 = x/y-constant run)
 extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_tmask(
     const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
     long long n, unsigned long long* __restrict__ masks) {
     __shared__ __attribute__((aligned(16))) sdfk_tilebuf buf;
     sdfk_tile_prepare(PRM, TAB, co, stride, n, &buf);
-    if (threadIdx.x < SDFK_NBRICK) masks[(long long)blockIdx.x * SDFK_NBRICK + threadIdx.x] = buf.mask[threadIdx.x];
+    for (int b = threadIdx.x; b < SDFK_NBRICK; b += SDFK_TTHREADS)
+        masks[(long long)blockIdx.x * SDFK_NBRICK + b] = buf.mask[b];
 }
 extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_t(
     const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
@@ -148,14 +166,27 @@ extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_t(
     // ---- phase C ----
     for (int b = wave; b < SDFK_NBRICK; b += SDFK_TTHREADS / 64) {
         const unsigned long long mv = buf.mask[b];
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)mv);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)mv);            // wave-uniform (SGPRs)
         const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(mv >> 32));
-        const unsigned long long mask = ((unsigned long long)hi << 32) | lo;     // wave-uniform (SGPRs)
         const int local = b * SDFK_BRICK + 2 * lane;
-        V3P p = {*reinterpret_cast<const f2*>(buf.x + local), *reinterpret_cast<const f2*>(buf.y + local),
-                 *reinterpret_cast<const f2*>(buf.z + local)};
-        const f2 r = sdfk_point_culled<f2>(p, mask, PRM, TAB);
         const long long i = tile_base + local;
+        if (tile_base + (long long)b * SDFK_BRICK >= n) break;                        // bricks past the end
+        const f2 z = *reinterpret_cast<const f2*>(buf.z + local);
+        f2 r;
+#ifdef SDFK_NO_ZRUN
+        if (false) {
+#else
+        if (hi >> 31) {
+#endif
+            const float2 xy = buf.xy[b];
+            V3P p = {sp<f2>(xy.x), sp<f2>(xy.y), z};
+            r = sdfk_point_culled<f2, true>(p, lo, hi, buf.base[b], PRM, TAB);
+        } else {
+            const long long last = n - 1;
+            const long long i0 = i < last ? i : last, i1 = i + 1 < last ? i + 1 : last;
+            V3P p = {{co[i0], co[i1]}, {co[stride + i0], co[stride + i1]}, z};
+            r = sdfk_point_culled<f2, false>(p, lo, hi, buf.base[b], PRM, TAB);
+        }
         if (i + 1 < n) *reinterpret_cast<f2*>(out + i) = r;
         else if (i < n) out[i] = r.x;
     }
@@ -172,6 +203,48 @@ struct Gen {
     const std::vector<sdfk_cullsite>* sites;
     std::string s;
 
+    // "root transforms": XFORM instructions that read the untouched input point C0. slot[i] = their
+    // index (else -1). On a brick whose points share x and y their first six fmas are one value per
+    // brick (op_xform_base), computed by the probe lane and read back from LDS by the consumers.
+    std::vector<int> root_slot;
+    int n_root = 0;
+    void find_roots() {
+        root_slot.assign(n_instr, -1);
+        bool c0_intact = true;
+        for (size_t i = 0; i < n_instr; ++i) {
+            const uint32_t w = code[2 * i];
+            const unsigned op = w & 255u, a = (w >> 8) & 255u, b = (w >> 16) & 255u;
+            if ((int)op >= n_ops) continue;
+            if (ops[op].kind != SDFK_KIND_C_C) continue;
+            if (!strcmp(ops[op].name, "XFORM") && b == 0 && c0_intact && n_root < 64) root_slot[i] = n_root++;
+            if (a == 0) c0_intact = false;
+        }
+    }
+
+    // mode 0: plain; 1: probe (stores the base of root transforms); 2: culled (reads it when ZRUN)
+    void instr_x(size_t i, const char* indent, int mode) {
+        const int r = root_slot.empty() ? -1 : root_slot[i];
+        if (r < 0 || mode == 0) {
+            instr(i, indent);
+            return;
+        }
+        char buf[640];
+        const uint32_t w = code[2 * i], poff = code[2 * i + 1];
+        const unsigned a = (w >> 8) & 255u;
+        if (mode == 1) {
+            snprintf(buf, sizeof buf,
+                     "%s{ const V3T<float> bs = op_xform_base(C_0.x, C_0.y, PRM + %u); bases[%d] = bs.x; bases[%d] = bs.y; "
+                     "bases[%d] = bs.z;\n%s  C_%u = op_xform_z(bs, C_0.z, PRM + %u); }\n",
+                     indent, poff, 3 * r, 3 * r + 1, 3 * r + 2, indent, a, poff);
+        } else {
+            snprintf(buf, sizeof buf,
+                     "%sif constexpr (ZRUN) { const V3T<T> bs = {sp<T>(bases[%d]), sp<T>(bases[%d]), sp<T>(bases[%d])};\n"
+                     "%s  C_%u = op_xform_z(bs, C_0.z, PRM + %u); }\n%selse C_%u = op_xform(C_0, PRM + %u, TAB, 0);\n",
+                     indent, 3 * r, 3 * r + 1, 3 * r + 2, indent, a, poff, indent, a, poff);
+        }
+        s += buf;
+    }
+
     void instr(size_t i, const char* indent) {
         char buf[256];
         const uint32_t w = code[2 * i], poff = code[2 * i + 1];
@@ -180,16 +253,16 @@ struct Gen {
         const sdfk_opinfo& o = ops[op];
         switch (o.kind) {
             case SDFK_KIND_C_C:
-                snprintf(buf, sizeof buf, "%sC%u = %s(C%u, PRM + %u, TAB, %u);\n", indent, a, o.func, b, poff, c);
+                snprintf(buf, sizeof buf, "%sC_%u = %s(C_%u, PRM + %u, TAB, %u);\n", indent, a, o.func, b, poff, c);
                 break;
             case SDFK_KIND_V_C:
-                snprintf(buf, sizeof buf, "%sV%u = %s(C%u, PRM + %u, TAB);\n", indent, a, o.func, b, poff);
+                snprintf(buf, sizeof buf, "%sV_%u = %s(C_%u, PRM + %u, TAB);\n", indent, a, o.func, b, poff);
                 break;
             case SDFK_KIND_V_V:
-                snprintf(buf, sizeof buf, "%sV%u = %s(V%u, PRM + %u);\n", indent, a, o.func, b, poff);
+                snprintf(buf, sizeof buf, "%sV_%u = %s(V_%u, PRM + %u);\n", indent, a, o.func, b, poff);
                 break;
             default:
-                snprintf(buf, sizeof buf, "%sV%u = %s(V%u, V%u, PRM + %u);\n", indent, a, o.func, b, c, poff);
+                snprintf(buf, sizeof buf, "%sV_%u = %s(V_%u, V_%u, PRM + %u);\n", indent, a, o.func, b, c, poff);
                 break;
         }
         s += buf;
@@ -208,11 +281,11 @@ struct Gen {
         char buf[160];
         for (unsigned c : cregs)
             if (c != 0) {
-                snprintf(buf, sizeof buf, zero_init ? "    %s C%u = C0;\n" : "    %s C%u;\n", ctype, c);
+                snprintf(buf, sizeof buf, zero_init ? "    %s C_%u = C_0;\n" : "    %s C_%u;\n", ctype, c);
                 s += buf;
             }
         for (unsigned v : vregs) {
-            snprintf(buf, sizeof buf, zero_init ? "    %s V%u = sp<%s>(0.0f);\n" : "    %s V%u;\n", vtype, v,
+            snprintf(buf, sizeof buf, zero_init ? "    %s V_%u = sp<%s>(0.0f);\n" : "    %s V_%u;\n", vtype, v,
                      vtype);
             s += buf;
         }
@@ -236,14 +309,14 @@ struct Gen {
         *neg_b = false;
         snprintf(wexpr, cap, "0.0f");
         if (!strcmp(name, "VMIN") || !strcmp(name, "SMIN2") || !strcmp(name, "SMIN3")) {
-            snprintf(gapB, cap, "(V%u - V%u)", c, b);
-            snprintf(gapA, cap, "(V%u - V%u)", b, c);
+            snprintf(gapB, cap, "(V_%u - V_%u)", c, b);
+            snprintf(gapA, cap, "(V_%u - V_%u)", b, c);
         } else if (!strcmp(name, "VMAX") || !strcmp(name, "SMAX3")) {
-            snprintf(gapB, cap, "(V%u - V%u)", b, c);
-            snprintf(gapA, cap, "(V%u - V%u)", c, b);
+            snprintf(gapB, cap, "(V_%u - V_%u)", b, c);
+            snprintf(gapA, cap, "(V_%u - V_%u)", c, b);
         } else {  // VSUBTRACT, SSUB3: max(a, -b)
-            snprintf(gapB, cap, "(V%u + V%u)", b, c);
-            snprintf(gapA, cap, "(-V%u - V%u)", b, c);
+            snprintf(gapB, cap, "(V_%u + V_%u)", b, c);
+            snprintf(gapA, cap, "(-V_%u - V_%u)", b, c);
             *neg_b = true;
         }
         if (name[0] == 'S') snprintf(wexpr, cap, "PRM[%u]", poff);
@@ -254,7 +327,7 @@ struct Gen {
     // Lipschitz constants L_a, L_b (k = L_a + L_b): gap(c) >= w + k*rho  =>  gap(p) >= w for every p
     // of the brick, and then the (smooth) min / max returns the other operand bit-exactly.
     void emit_probe() {
-        s += "\nstatic __device__ __forceinline__ unsigned long long sdfk_probe(V3 C0, float rho, "
+        s += "\nstatic __device__ __forceinline__ unsigned long long sdfk_probe(V3T<float> C_0, float rho, float* bases, "
              "const float* __restrict__ PRM, const float* __restrict__ TAB) {\n";
         declare("V3", "float", false);
         s += "    unsigned long long mask = 0ull;\n";
@@ -268,19 +341,26 @@ struct Gen {
                 const uint32_t w = code[2 * i];
                 const unsigned b = (w >> 16) & 255u, c = w >> 24;
                 snprintf(buf, sizeof buf,
-                         "    { const float thr = %s + %.9gf * rho + 1e-6f * (1.0f + fabsf(V%u) + fabsf(V%u));\n"
+                         "    { const float thr = %s + %.9gf * rho + 1e-6f * (1.0f + fabsf(V_%u) + fabsf(V_%u));\n"
                          "      if (%d && %s >= thr) mask |= %lluull;\n"
                          "      else if (%d && %s >= thr) mask |= %lluull; }\n",
                          wx, (double)t.k * 1.0001, b, c, t.skip_b_ok, gB, 2ull << (2 * k), t.skip_a_ok, gA,
                          1ull << (2 * k));
                 s += buf;
             }
-            instr(i, "    ");
+            instr_x(i, "    ", 1);
         }
         s += "    return mask;\n}\n";
     }
 
     // ---- culled evaluation ----
+    // mask bit `bit` (0..63) as a test on one of the two 32-bit scalar halves
+    static std::string bit_test(unsigned bit) {
+        char b[48];
+        snprintf(b, sizeof b, "(%s & %uu)", bit < 32 ? "mlo" : "mhi", 1u << (bit & 31));
+        return b;
+    }
+
     void emit_span(size_t lo, size_t hi, int depth) {
         std::string ind(4 + 4 * depth, ' ');
         char buf[512];
@@ -288,18 +368,17 @@ struct Gen {
         while (i <= hi) {
             const int k = site_opening_at(i, hi);
             if (k < 0) {
-                instr(i, ind.c_str());
+                instr_x(i, ind.c_str(), 2);
                 ++i;
                 continue;
             }
             const sdfk_cullsite& t = (*sites)[k];
             // (inside [a0, a1] this site is out of reach: its combiner lies beyond a1)
-            snprintf(buf, sizeof buf, "%sif (!(mask & %lluull)) {\n", ind.c_str(), 1ull << (2 * k));
-            s += buf;
+            const std::string ta = bit_test(2 * k), tb = bit_test(2 * k + 1);
+            s += ind + "if (!" + ta + ") {\n";
             emit_span(t.a0, t.a1, depth + 1);
             s += ind + "}\n";
-            snprintf(buf, sizeof buf, "%sif (!(mask & %lluull)) {\n", ind.c_str(), 2ull << (2 * k));
-            s += buf;
+            s += ind + "if (!" + tb + ") {\n";
             emit_span(t.b0, t.b1, depth + 1);
             s += ind + "}\n";
             const uint32_t w = code[2 * t.comb];
@@ -307,9 +386,8 @@ struct Gen {
             char gB[64], gA[64], wx[32];
             bool neg;
             site_ops(t, gB, gA, wx, &neg, sizeof gB);
-            snprintf(buf, sizeof buf, "%sif (mask & %lluull) V%u = %sV%u;\n%selse if (mask & %lluull) V%u = V%u;\n%selse {\n",
-                     ind.c_str(), 1ull << (2 * k), a, neg ? "-" : "", c, ind.c_str(), 2ull << (2 * k), a, b,
-                     ind.c_str());
+            snprintf(buf, sizeof buf, "%sif %s V_%u = %sV_%u;\n%selse if %s V_%u = V_%u;\n%selse {\n", ind.c_str(), ta.c_str(),
+                     a, neg ? "-" : "", c, ind.c_str(), tb.c_str(), a, b, ind.c_str());
             s += buf;
             instr(t.comb, (ind + "    ").c_str());
             s += ind + "}\n";
@@ -318,12 +396,13 @@ struct Gen {
     }
 
     void emit_culled(int result_reg) {
-        s += "\ntemplate <typename T> static __device__ __forceinline__ T sdfk_point_culled(V3T<T> C0, "
-             "unsigned long long mask, const float* __restrict__ PRM, const float* __restrict__ TAB) {\n";
+        s += "\ntemplate <typename T, bool ZRUN> static __device__ __forceinline__ T sdfk_point_culled(V3T<T> C_0, "
+             "unsigned mlo, unsigned mhi, const float* bases, const float* __restrict__ PRM, "
+             "const float* __restrict__ TAB) {\n";
         declare("V3T<T>", "T", true);
         emit_span(0, n_instr - 1, 0);
         char buf[64];
-        snprintf(buf, sizeof buf, "    return V%d;\n}\n", result_reg);
+        snprintf(buf, sizeof buf, "    return V_%d;\n}\n", result_reg);
         s += buf;
     }
 };
@@ -338,15 +417,18 @@ std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32
     g.s += kEmbeddedDevice;
     g.s += "\n";
     g.s += kEmbeddedAccess;
-    g.s += "\ntemplate <typename T> static __device__ __forceinline__ T sdfk_point(V3T<T> C0, "
+    g.s += "\ntemplate <typename T> static __device__ __forceinline__ T sdfk_point(V3T<T> C_0, "
            "const float* __restrict__ PRM, const float* __restrict__ TAB) {\n";
     g.declare("V3T<T>", "T", false);
     for (size_t i = 0; i < n_instr; ++i) g.instr(i, "    ");
     char buf[64];
-    snprintf(buf, sizeof buf, "    return V%d;\n}\n", result_reg);
+    snprintf(buf, sizeof buf, "    return V_%d;\n}\n", result_reg);
     g.s += buf;
     g.s += kWrappers;
     if (!sites.empty()) {
+        g.find_roots();
+        snprintf(buf, sizeof buf, "\n#define SDFK_NROOT %d\n", g.n_root > 0 ? g.n_root : 1);
+        g.s += buf;
         g.emit_probe();
         g.emit_culled(result_reg);
         g.s += kTileKernel;

@@ -119,12 +119,23 @@ SDFK_DEV float sd_seg2_sq(float px, float py, const float* __restrict__ S) {
 template <typename T> SDFK_DEV V3T<T> op_movc(V3T<T> p, const float* __restrict__, const float* __restrict__, int) { return p; }
 
 // C/transformations.py:232-242  co' = (R^T co)/s - R^T t.  P = M(9, row major, R^T/s) , c(3) = R^T t
-template <typename T> SDFK_DEV V3T<T> op_xform(V3T<T> p, const float* __restrict__ P, const float* __restrict__, int) {
-    V3T<T> q;
-    q.x = sd_fma(sp<T>(P[0]), p.x, sd_fma(sp<T>(P[1]), p.y, sd_fma(sp<T>(P[2]), p.z, sp<T>(-P[9]))));
-    q.y = sd_fma(sp<T>(P[3]), p.x, sd_fma(sp<T>(P[4]), p.y, sd_fma(sp<T>(P[5]), p.z, sp<T>(-P[10]))));
-    q.z = sd_fma(sp<T>(P[6]), p.x, sd_fma(sp<T>(P[7]), p.y, sd_fma(sp<T>(P[8]), p.z, sp<T>(-P[11]))));
+// The sum is associated x, y first and z last, so that for a run of points sharing x and y (a grid row)
+// the first two thirds (op_xform_base) are one value per run and only op_xform_z depends on the point:
+// the culling kernel computes the base once per brick and evaluates 3 instead of 9 fmas per point, with
+// bit-identical results.
+template <typename T> SDFK_DEV V3T<T> op_xform_base(T x, T y, const float* __restrict__ P) {
+    V3T<T> b;
+    b.x = sd_fma(sp<T>(P[1]), y, sd_fma(sp<T>(P[0]), x, sp<T>(-P[9])));
+    b.y = sd_fma(sp<T>(P[4]), y, sd_fma(sp<T>(P[3]), x, sp<T>(-P[10])));
+    b.z = sd_fma(sp<T>(P[7]), y, sd_fma(sp<T>(P[6]), x, sp<T>(-P[11])));
+    return b;
+}
+template <typename T> SDFK_DEV V3T<T> op_xform_z(V3T<T> base, T z, const float* __restrict__ P) {
+    V3T<T> q = {sd_fma(sp<T>(P[2]), z, base.x), sd_fma(sp<T>(P[5]), z, base.y), sd_fma(sp<T>(P[8]), z, base.z)};
     return q;
+}
+template <typename T> SDFK_DEV V3T<T> op_xform(V3T<T> p, const float* __restrict__ P, const float* __restrict__, int) {
+    return op_xform_z(op_xform_base(p.x, p.y, P), p.z, P);
 }
 // R = I, s = 1 (I·co and co/1.0 are exact in the reference): q = p - t.  Also move_sdf C/modifications.py:1283
 template <typename T> SDFK_DEV V3T<T> op_xlate(V3T<T> p, const float* __restrict__ P, const float* __restrict__, int) {

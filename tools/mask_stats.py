@@ -25,7 +25,7 @@ def main(grid=512):
     n = res[0] * res[1] * res[2]
     stride = (n + 255) // 256 * 256
     d_co = lib.sdfk_malloc(3 * stride * 4)
-    nb = (n + 2047) // 2048 * 16
+    nb = (n + 1023) // 1024 * 8
     d_m = lib.sdfk_malloc(nb * 8)
     _engine.grid_fill(d_co, stride, axes, 0, n)
     _engine.check(lib.sdfk_debug_brick_masks(prog.handle, ctypes.c_void_p(d_co), n, stride, ctypes.c_void_p(d_m), None),
@@ -42,7 +42,7 @@ def main(grid=512):
     for k in range(ns_sites):
         alive[k + 1] &= ~skip_b[k]
         alive[:k + 1] &= ~skip_a[k]
-    print("grid %d^3: %d bricks, %d sites" % (res[0], m.size, ns_sites))
+    print("grid %d^3: %d bricks, %d sites; x/y-constant runs: %.3f" % (res[0], m.size, ns_sites, ((m >> np.uint64(63)) & np.uint64(1)).mean()))
     print("skip_b rate per site:", np.round(skip_b.mean(axis=1), 3))
     print("skip_a rate per site:", np.round(skip_a.mean(axis=1), 3))
     print("primitive evaluations still needed: %.3f of un-culled" % alive.mean())
