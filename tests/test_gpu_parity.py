@@ -335,7 +335,7 @@ def test_brick_masks_are_conservative(engine):
     tree = scenes.cfg2_tree(ns)
     low = lower_geometry(tree)
     prog = engine.Program.from_lowered(low)
-    co, _ = ns.generate_grid((2, 2, 2), (128, 128, 128))
+    co, _ = ns.generate_grid((2, 2, 2), (32, 32, 1024))      # rows of 1025 points: bricks are 1/8 of a row
     co32 = co.astype(np.float32)
     n = co32.shape[1]
     stride = (n + 255) // 256 * 256
@@ -380,5 +380,5 @@ def test_brick_masks_are_conservative(engine):
         n_skipped += int(skip_b.sum()) + int(skip_a.sum())
         acc = sdf_oracle.smin_poly(acc, d[k], w, 3)
     assert n_skipped > 0.3 * masks.size * 9          # and the probe is not vacuous
-    # rows of this grid are 129 points long: most bricks are x/y-constant runs
-    assert 0.4 < ((masks >> np.uint64(63)) & np.uint64(1)).mean() < 1.0
+    # 7 of every ~8 bricks lie inside one row (x/y-constant runs), the others straddle a row end
+    assert 0.8 < ((masks >> np.uint64(63)) & np.uint64(1)).mean() < 0.95
