@@ -71,18 +71,21 @@ static const char kTileKernel[] = R"SDFKT(
 #endif
 #define SDFK_BRICK 128
 #define SDFK_NBRICK (SDFK_TILE / SDFK_BRICK)
-static_assert(SDFK_NBRICK <= SDFK_TTHREADS && SDFK_TILE % (4 * SDFK_TTHREADS) == 0, "tile geometry");
+static_assert(2 * SDFK_NBRICK <= SDFK_TTHREADS && SDFK_TILE % (4 * SDFK_TTHREADS) == 0, "tile geometry");
 
-// LDS image of one tile. Only z is staged per point: bricks whose points share x and y (rows of a regular
-// grid; detected bitwise) keep that pair once per brick, other bricks re-read their x / y rows from global
-// memory in phase C (L2-resident, they were loaded in phase A).
+// LDS image of one tile. Only z is staged per point. A brick is classified (bitwise comparisons) as
+//   kind 1  all points share x and y                      (inside one row of a regular grid)
+//   kind 2  two consecutive runs, each sharing its x, y   (a brick straddling the end of a row)
+//   kind 0  anything else: one bounding sphere, x / y re-read from global memory in phase C
+// Kinds 1 and 2 keep their x, y once per run; kind 2 is probed once per run (tight spheres) and a subtree
+// is skipped only if both runs allow it.
 struct sdfk_tilebuf {
     float z[SDFK_TILE];
-    float4 bound[SDFK_NBRICK];              // bounding sphere: centre, radius
-    unsigned long long mask[SDFK_NBRICK];   // bits 0..61: two per cull site; bit 63: brick is an x/y-constant run
-    float2 xy[SDFK_NBRICK];                 // the shared x, y of such a run
-    float base[SDFK_NBRICK][3 * SDFK_NROOT];
-    unsigned zrun[SDFK_NBRICK];
+    float4 bound[SDFK_NBRICK], bound2[SDFK_NBRICK];   // bounding spheres: centre, radius (second run of kind 2)
+    unsigned long long mask[SDFK_NBRICK], mask2[SDFK_NBRICK];
+    float2 xy[SDFK_NBRICK], xy2[SDFK_NBRICK];
+    float base[SDFK_NBRICK][3 * SDFK_NROOT], base2[SDFK_NBRICK][3 * SDFK_NROOT];
+    unsigned kind[SDFK_NBRICK], split[SDFK_NBRICK];   // split = index of the first point of the second run
 };
 
 // phases A and B (shared by the evaluation kernel and the mask-dump kernel)
@@ -91,6 +94,7 @@ static __device__ __forceinline__ void sdfk_tile_prepare(const float* __restrict
                                                          sdfk_tilebuf* buf) {
     const long long tile_base = (long long)blockIdx.x * SDFK_TILE;
     const int tid = threadIdx.x, lane = tid & 63;
+    constexpr int BL = SDFK_BRICK / 4;        // lanes per brick in phase A
     // ---- phase A ----
 #pragma unroll 2
     for (int h = 0; h < SDFK_TILE / (4 * SDFK_TTHREADS); ++h) {
@@ -110,51 +114,103 @@ static __device__ __forceinline__ void sdfk_tile_prepare(const float* __restrict
             z = make_float4(co[2 * stride + i0], co[2 * stride + i1], co[2 * stride + i2], co[2 * stride + i3]);
         }
         *reinterpret_cast<float4*>(buf->z + local) = z;
-        // bounding sphere of the brick (the SDFK_BRICK/4 lanes of this load): centre = midpoint of the brick's
+        // generic bounding sphere of the brick (the BL lanes of this load): centre = midpoint of the brick's
         // first and last point, radius = largest distance of any of its points from that centre
-        const int first = lane & ~(SDFK_BRICK / 4 - 1), lastl = first + SDFK_BRICK / 4 - 1;
-        const float fx = __shfl(x.x, first), fy = __shfl(y.x, first);
+        const int first = lane & ~(BL - 1), lastl = first + BL - 1, li = lane - first;
+        const float fx = __shfl(x.x, first), fy = __shfl(y.x, first), fz = __shfl(z.x, first), lz = __shfl(z.w, lastl);
         const float cx = 0.5f * (fx + __shfl(x.w, lastl));
         const float cy = 0.5f * (fy + __shfl(y.w, lastl));
-        const float cz = 0.5f * (__shfl(z.x, first) + __shfl(z.w, lastl));
+        const float cz = 0.5f * (fz + lz);
         const f2 xa = {x.x - cx, x.y - cx}, xb = {x.z - cx, x.w - cx}, ya = {y.x - cy, y.y - cy}, yb = {y.z - cy, y.w - cy},
                  za = {z.x - cz, z.y - cz}, zb = {z.z - cz, z.w - cz};
         const f2 da = sd_fma(xa, xa, sd_fma(ya, ya, za * za)), db = sd_fma(xb, xb, sd_fma(yb, yb, zb * zb));
         float r2 = sd_rawmax(sd_rawmax(da.x, da.y), sd_rawmax(db.x, db.y));
 #pragma unroll
-        for (int m = 1; m < SDFK_BRICK / 4; m <<= 1) r2 = sd_rawmax(r2, __shfl_xor(r2, m));
-        // does every point of the brick share x and y (a row of a regular grid)? bitwise comparison
-        const bool same = x.x == x.y && x.y == x.z && x.z == x.w && x.x == fx && y.x == y.y && y.y == y.z &&
-                          y.z == y.w && y.x == fy;
-        const unsigned long long bal = __ballot(same);
-        if ((lane & (SDFK_BRICK / 4 - 1)) == 0) {
+        for (int m = 1; m < BL; m <<= 1) r2 = sd_rawmax(r2, __shfl_xor(r2, m));
+        // how many leading points of this lane share the brick's first x, y (bitwise)?
+        const bool e0 = x.x == fx && y.x == fy, e1 = x.y == fx && y.y == fy, e2 = x.z == fx && y.z == fy,
+                   e3 = x.w == fx && y.w == fy;
+        const int c1 = e0 ? (e1 ? (e2 ? (e3 ? 4 : 3) : 2) : 1) : 0;
+        const unsigned full = (unsigned)(__ballot(c1 == 4) >> first);       // BL == 32 bits of this brick
+        const int lead = (full == 0xffffffffu) ? BL : __builtin_ctz(~full);  // leading lanes that are all-equal
+        unsigned kind = (lead == BL) ? 1u : 0u;
+        float4 bnd = make_float4(cx, cy, cz, 1.00001f * sqrtf(r2) + 1e-30f);
+        float4 bnd2 = bnd;
+        float2 xy2 = make_float2(fx, fy);
+        unsigned split = SDFK_BRICK;
+        if (__ballot(lead < BL) != 0ull) {                                    // some brick of this wave is not one run
+            const int sl = first + (lead < BL ? lead : 0);                    // lane holding the first different point
+            const int cs = __shfl(c1, sl);
+            const int s = 4 * lead + cs;                                       // its index in the brick
+            const float xo = c1 == 0 ? x.x : c1 == 1 ? x.y : c1 == 2 ? x.z : x.w;
+            const float yo = c1 == 0 ? y.x : c1 == 1 ? y.y : c1 == 2 ? y.z : y.w;
+            const float zo = c1 == 0 ? z.x : c1 == 1 ? z.y : c1 == 2 ? z.z : z.w;
+            const float zup = __shfl_up(z.w, 1);                               // last z of the previous lane
+            const float zpo = c1 == 0 ? zup : c1 == 1 ? z.x : c1 == 2 ? z.y : z.z;
+            const float x2 = __shfl(xo, sl), y2 = __shfl(yo, sl), zs = __shfl(zo, sl), zp = __shfl(zpo, sl);
+            const int i0 = 4 * li;
+            const bool k0 = (i0 < s) ? e0 : (x.x == x2 && y.x == y2), k1 = (i0 + 1 < s) ? e1 : (x.y == x2 && y.y == y2),
+                       k2 = (i0 + 2 < s) ? e2 : (x.z == x2 && y.z == y2), k3 = (i0 + 3 < s) ? e3 : (x.w == x2 && y.w == y2);
+            const unsigned okb = (unsigned)(__ballot(k0 && k1 && k2 && k3) >> first);
+            const bool two = lead < BL && s > 0 && okb == 0xffffffffu;
+            const float c1z = 0.5f * (fz + zp), c2z = 0.5f * (zs + lz);
+            float ra = sd_rawmax(sd_rawmax(i0 < s ? sd_abs(z.x - c1z) : 0.0f, i0 + 1 < s ? sd_abs(z.y - c1z) : 0.0f),
+                                 sd_rawmax(i0 + 2 < s ? sd_abs(z.z - c1z) : 0.0f, i0 + 3 < s ? sd_abs(z.w - c1z) : 0.0f));
+            float rb = sd_rawmax(sd_rawmax(i0 < s ? 0.0f : sd_abs(z.x - c2z), i0 + 1 < s ? 0.0f : sd_abs(z.y - c2z)),
+                                 sd_rawmax(i0 + 2 < s ? 0.0f : sd_abs(z.z - c2z), i0 + 3 < s ? 0.0f : sd_abs(z.w - c2z)));
+#pragma unroll
+            for (int m = 1; m < BL; m <<= 1) {
+                ra = sd_rawmax(ra, __shfl_xor(ra, m));
+                rb = sd_rawmax(rb, __shfl_xor(rb, m));
+            }
+            if (two) {
+                kind = 2u;
+                bnd = make_float4(fx, fy, c1z, 1.00001f * ra + 1e-30f);
+                bnd2 = make_float4(x2, y2, c2z, 1.00001f * rb + 1e-30f);
+                xy2 = make_float2(x2, y2);
+                split = (unsigned)s;
+            }
+        }
+        if (li == 0) {
             const int b = local / SDFK_BRICK;
-            buf->bound[b] = make_float4(cx, cy, cz, 1.00001f * sqrtf(r2) + 1e-30f);
-            const unsigned long long want = ((1ull << (SDFK_BRICK / 4)) - 1ull) << first;
-            buf->zrun[b] = ((bal & want) == want) ? 1u : 0u;
+            buf->bound[b] = bnd;
+            buf->bound2[b] = bnd2;
+            buf->kind[b] = kind;
+            buf->split[b] = split;
             buf->xy[b] = make_float2(fx, fy);
+            buf->xy2[b] = xy2;
         }
     }
     __syncthreads();
-    // ---- phase B ----
-    if (tid < SDFK_NBRICK) {                   // SDFK_NBRICK <= SDFK_TTHREADS (static_assert below)
-        const int b = tid;
-        const float4 bb = buf->bound[b];
-        V3T<float> c = {bb.x, bb.y, bb.z};     // for an x/y-constant run the midpoint has exactly that x and y
-        const unsigned long long m = sdfk_probe(c, bb.w, buf->base[b], PRM, TAB);
-        buf->mask[b] = m | ((unsigned long long)buf->zrun[b] << 63);
+    // ---- phase B: one lane per run ----
+    if (tid < 2 * SDFK_NBRICK) {
+        const int b = tid % SDFK_NBRICK, second = tid / SDFK_NBRICK;
+        const unsigned kind = buf->kind[b];
+        if (!second || kind == 2u) {
+            const float4 bb = second ? buf->bound2[b] : buf->bound[b];
+            V3T<float> c = {bb.x, bb.y, bb.z};     // for an x/y-constant run the centre has exactly that x and y
+            const unsigned long long m = sdfk_probe(c, bb.w, second ? buf->base2[b] : buf->base[b], PRM, TAB);
+            if (second) buf->mask2[b] = m;
+            else buf->mask[b] = m | ((unsigned long long)(kind == 1u) << 63) | ((unsigned long long)(kind == 2u) << 62);
+        }
     }
     __syncthreads();
 }
+// skip bits of a brick: both runs of a two-run brick must agree
+static __device__ __forceinline__ unsigned long long sdfk_brick_mask(const sdfk_tilebuf* buf, int b) {
+    unsigned long long m = buf->mask[b];
+    if ((m >> 62) & 1ull) m &= buf->mask2[b] | (3ull << 62);
+    return m;
+}
 // debugging / test aid: the skip masks of every brick (2 bits per site: bit 2k = skip first operand,
-// bit 2k+1 = skip second operand; bit 63 = x/y-constant run)
+// bit 2k+1 = skip second operand; bit 63 = x/y-constant run, bit 62 = two such runs)
 extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_tmask(
     const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
     long long n, unsigned long long* __restrict__ masks) {
     __shared__ __attribute__((aligned(16))) sdfk_tilebuf buf;
     sdfk_tile_prepare(PRM, TAB, co, stride, n, &buf);
     for (int b = threadIdx.x; b < SDFK_NBRICK; b += SDFK_TTHREADS)
-        masks[(long long)blockIdx.x * SDFK_NBRICK + b] = buf.mask[b];
+        masks[(long long)blockIdx.x * SDFK_NBRICK + b] = sdfk_brick_mask(&buf, b);
 }
 extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_t(
     const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
@@ -165,26 +221,30 @@ extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_t(
     sdfk_tile_prepare(PRM, TAB, co, stride, n, &buf);
     // ---- phase C ----
     for (int b = wave; b < SDFK_NBRICK; b += SDFK_TTHREADS / 64) {
-        const unsigned long long mv = buf.mask[b];
+        if (tile_base + (long long)b * SDFK_BRICK >= n) break;                        // bricks past the end
+        const unsigned long long mv = sdfk_brick_mask(&buf, b);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)mv);            // wave-uniform (SGPRs)
         const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(mv >> 32));
         const int local = b * SDFK_BRICK + 2 * lane;
         const long long i = tile_base + local;
-        if (tile_base + (long long)b * SDFK_BRICK >= n) break;                        // bricks past the end
         const f2 z = *reinterpret_cast<const f2*>(buf.z + local);
         f2 r;
-#ifdef SDFK_NO_ZRUN
-        if (false) {
-#else
-        if (hi >> 31) {
-#endif
+        if (hi >> 31) {                                                               // one run
             const float2 xy = buf.xy[b];
             V3P p = {sp<f2>(xy.x), sp<f2>(xy.y), z};
             r = sdfk_point_culled<f2, true>(p, lo, hi, buf.base[b], PRM, TAB);
         } else {
-            const long long last = n - 1;
-            const long long i0 = i < last ? i : last, i1 = i + 1 < last ? i + 1 : last;
-            V3P p = {{co[i0], co[i1]}, {co[stride + i0], co[stride + i1]}, z};
+            V3P p;
+            if ((hi >> 30) & 1u) {                                                    // two runs
+                const float2 xa = buf.xy[b], xb = buf.xy2[b];
+                const int s = (int)buf.split[b];
+                const bool a0 = 2 * lane < s, a1 = 2 * lane + 1 < s;
+                p = {{a0 ? xa.x : xb.x, a1 ? xa.x : xb.x}, {a0 ? xa.y : xb.y, a1 ? xa.y : xb.y}, z};
+            } else {                                                                  // arbitrary points
+                const long long last = n - 1;
+                const long long i0 = i < last ? i : last, i1 = i + 1 < last ? i + 1 : last;
+                p = {{co[i0], co[i1]}, {co[stride + i0], co[stride + i1]}, z};
+            }
             r = sdfk_point_culled<f2, false>(p, lo, hi, buf.base[b], PRM, TAB);
         }
         if (i + 1 < n) *reinterpret_cast<f2*>(out + i) = r;
