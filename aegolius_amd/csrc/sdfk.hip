@@ -424,16 +424,24 @@ extern "C" const char* sdfk_program_source(sdfk_program* p) {
     return p->source.c_str();
 }
 
-// tile geometry of the brick-culling kernel (overridable for experiments: SDFK_TILE / SDFK_TTHREADS)
-static int tile_points() {
-    static int v = [] { const char* e = getenv("SDFK_TILE"); int t = e ? atoi(e) : 1024; return (t >= 512 && t % 512 == 0 && t <= 8192) ? t : 1024; }();
+// tile geometry of the brick-culling kernel: SDFK_TWAVES waves x SDFK_WBRICKS bricks of 128 points per
+// workgroup (overridable through the environment for experiments)
+static int tile_waves() {
+    static int v = [] { const char* e = getenv("SDFK_TWAVES"); int t = e ? atoi(e) : 4; return (t >= 1 && t <= 16) ? t : 4; }();
     return v;
 }
-static int tile_threads() {
-    static int v = [] { const char* e = getenv("SDFK_TTHREADS"); int t = e ? atoi(e) : 128; return (t >= 64 && t <= 1024 && t % 64 == 0) ? t : 128; }();
+static int tile_wbricks() {
+    static int v = [] {
+        const char* e = getenv("SDFK_WBRICKS");
+        int t = e ? atoi(e) : 4;
+        if (t < 1 || t > 32) t = 4;
+        if (t > 32) t = 32;   // one probe lane per run: 2 * waves * bricks <= 64 * waves
+        return t;
+    }();
     return v;
 }
-
+static int tile_points() { return tile_waves() * tile_wbricks() * 128; }
+static int tile_threads() { return 64 * tile_waves(); }
 static int rtc_compile(const std::string& src, std::vector<char>* out, std::string* log) {
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "sdfk_spec.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
@@ -441,8 +449,8 @@ static int rtc_compile(const std::string& src, std::vector<char>* out, std::stri
         return -1;
     }
     char d_tile[48], d_thr[48];
-    snprintf(d_tile, sizeof d_tile, "-DSDFK_TILE=%d", tile_points());
-    snprintf(d_thr, sizeof d_thr, "-DSDFK_TTHREADS=%d", tile_threads());
+    snprintf(d_tile, sizeof d_tile, "-DSDFK_TWAVES=%d", tile_waves());
+    snprintf(d_thr, sizeof d_thr, "-DSDFK_WBRICKS=%d", tile_wbricks());
     std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", d_tile, d_thr};
     // experiment hook: extra -D switches for the generated source (space separated), e.g. SDFK_RTC_DEFS="-DSDFK_NO_ZRUN"
     std::vector<std::string> extra;

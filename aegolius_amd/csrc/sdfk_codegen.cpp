@@ -56,31 +56,35 @@ extern "C" __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_spec_g1(
 )SDFKW";
 
 // Brick-culling tile kernel (only emitted when the program has cull sites).
-//   phase A  the workgroup stages SDFK_TILE points (x, y, z rows) in LDS with 16-byte loads and
-//            reduces a bounding sphere per brick of SDFK_BRICK consecutive points
-//   phase B  one lane per brick evaluates the WHOLE tree at the brick centre and turns the
-//            operand gaps at every combiner into a skip mask (exact: see sdfk_probe)
-//   phase C  each wave evaluates its bricks, two points per lane (packed f2), jumping over the
-//            subtrees the mask proves irrelevant (mask is wave-uniform: scalar branches)
+// A brick = SDFK_BRICK (128) consecutive points = one wave x one packed f2 lane value. A workgroup of
+// SDFK_TWAVES waves owns SDFK_TWAVES * SDFK_WBRICKS bricks (a "tile").
+//   phase A  every wave loads its bricks (8-byte loads: a lane holds the same two points it will evaluate, so
+//            z stays in registers), classifies each brick and reduces its bounding sphere(s) (wave-wide DPP)
+//   phase B  one lane per run evaluates the WHOLE tree at the run's centre and turns the operand gaps at
+//            every combiner into a skip mask (exact: see sdfk_probe); LDS carries only per-brick metadata
+//   phase C  every wave evaluates its bricks, jumping over the subtrees the mask proves irrelevant
+//            (the mask is wave-uniform: scalar branches)
+// Brick kinds (bitwise comparisons of the coordinates):
+//   1  all points share x and y (inside one row of a regular grid): x, y kept once, the first two thirds of
+//      every root transform are computed once by the probe lane (op_xform_base)
+//   2  two consecutive runs of kind 1 (a brick straddling the end of a row): probed once per run, a subtree
+//      is skipped only if both runs allow it
+//   0  anything else: one bounding sphere, x / y re-read from global memory in phase C
 static const char kTileKernel[] = R"SDFKT(
-#ifndef SDFK_TILE
-#define SDFK_TILE 1024          // points staged per workgroup (host launch code must agree: sdfk.hip)
+#ifndef SDFK_TWAVES
+#define SDFK_TWAVES 4           // waves per workgroup           (host launch code must agree: sdfk.hip)
 #endif
-#ifndef SDFK_TTHREADS
-#define SDFK_TTHREADS 128
+#ifndef SDFK_WBRICKS
+#define SDFK_WBRICKS 4          // bricks per wave
 #endif
 #define SDFK_BRICK 128
-#define SDFK_NBRICK (SDFK_TILE / SDFK_BRICK)
-static_assert(2 * SDFK_NBRICK <= SDFK_TTHREADS && SDFK_TILE % (4 * SDFK_TTHREADS) == 0, "tile geometry");
+#define SDFK_NBRICK (SDFK_TWAVES * SDFK_WBRICKS)
+#define SDFK_TILE (SDFK_NBRICK * SDFK_BRICK)
+#define SDFK_TTHREADS (64 * SDFK_TWAVES)
+static_assert(2 * SDFK_NBRICK <= SDFK_TTHREADS, "one probe lane per run");
 
-// LDS image of one tile. Only z is staged per point. A brick is classified (bitwise comparisons) as
-//   kind 1  all points share x and y                      (inside one row of a regular grid)
-//   kind 2  two consecutive runs, each sharing its x, y   (a brick straddling the end of a row)
-//   kind 0  anything else: one bounding sphere, x / y re-read from global memory in phase C
-// Kinds 1 and 2 keep their x, y once per run; kind 2 is probed once per run (tight spheres) and a subtree
-// is skipped only if both runs allow it.
-struct sdfk_tilebuf {
-    float z[SDFK_TILE];
+struct sdfk_tilemeta {
+    float z[SDFK_TILE];                                // z of every point, written and read by the owning wave
     float4 bound[SDFK_NBRICK], bound2[SDFK_NBRICK];   // bounding spheres: centre, radius (second run of kind 2)
     unsigned long long mask[SDFK_NBRICK], mask2[SDFK_NBRICK];
     float2 xy[SDFK_NBRICK], xy2[SDFK_NBRICK];
@@ -88,156 +92,150 @@ struct sdfk_tilebuf {
     unsigned kind[SDFK_NBRICK], split[SDFK_NBRICK];   // split = index of the first point of the second run
 };
 
-// phases A and B (shared by the evaluation kernel and the mask-dump kernel)
-static __device__ __forceinline__ void sdfk_tile_prepare(const float* __restrict__ PRM, const float* __restrict__ TAB,
-                                                         const float* __restrict__ co, long long stride, long long n,
-                                                         sdfk_tilebuf* buf) {
-    const long long tile_base = (long long)blockIdx.x * SDFK_TILE;
-    const int tid = threadIdx.x, lane = tid & 63;
-    constexpr int BL = SDFK_BRICK / 4;        // lanes per brick in phase A
-    // ---- phase A ----
-#pragma unroll 2
-    for (int h = 0; h < SDFK_TILE / (4 * SDFK_TTHREADS); ++h) {
-        const int local = h * 4 * SDFK_TTHREADS + 4 * tid;
-        const long long i = tile_base + local;
-        float4 x, y, z;
-        if (i + 3 < n) {
-            x = *reinterpret_cast<const float4*>(co + i);
-            y = *reinterpret_cast<const float4*>(co + stride + i);
-            z = *reinterpret_cast<const float4*>(co + 2 * stride + i);
-        } else {   // ragged end of the array: repeat the last point (keeps the bounds valid)
-            const long long last = n - 1;
-            const long long i0 = i < last ? i : last, i1 = i + 1 < last ? i + 1 : last,
-                            i2 = i + 2 < last ? i + 2 : last, i3 = i + 3 < last ? i + 3 : last;
-            x = make_float4(co[i0], co[i1], co[i2], co[i3]);
-            y = make_float4(co[stride + i0], co[stride + i1], co[stride + i2], co[stride + i3]);
-            z = make_float4(co[2 * stride + i0], co[2 * stride + i1], co[2 * stride + i2], co[2 * stride + i3]);
-        }
-        *reinterpret_cast<float4*>(buf->z + local) = z;
-        // generic bounding sphere of the brick (the BL lanes of this load): centre = midpoint of the brick's
-        // first and last point, radius = largest distance of any of its points from that centre
-        const int first = lane & ~(BL - 1), lastl = first + BL - 1, li = lane - first;
-        const float fx = __shfl(x.x, first), fy = __shfl(y.x, first), fz = __shfl(z.x, first), lz = __shfl(z.w, lastl);
-        const float cx = 0.5f * (fx + __shfl(x.w, lastl));
-        const float cy = 0.5f * (fy + __shfl(y.w, lastl));
+// wave-wide max of a non-negative value (DPP: row_shr 1,2,4,8, row_bcast 15 / 31); result valid in every lane
+static __device__ __forceinline__ float sdfk_wave_max(float v) {
+    v = sd_rawmax(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false)));
+    v = sd_rawmax(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, false)));
+    v = sd_rawmax(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, false)));
+    v = sd_rawmax(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, false)));
+    v = sd_rawmax(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false)));
+    v = sd_rawmax(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false)));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+static __device__ __forceinline__ float sdfk_lane(float v, int l) {     // l wave-uniform
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+// phase A for one brick: classify and bound; lane 0 publishes the metadata
+static __device__ __forceinline__ void sdfk_brick_bounds(f2 x, f2 y, f2 z, int lane, sdfk_tilemeta* meta, int b) {
+    const float fx = sdfk_lane(x.x, 0), fy = sdfk_lane(y.x, 0), fz = sdfk_lane(z.x, 0), lz = sdfk_lane(z.y, 63);
+    const bool e0 = x.x == fx && y.x == fy, e1 = x.y == fx && y.y == fy;
+    const unsigned long long q0 = __ballot(e0), q1 = __ballot(e1);
+    unsigned kind;
+    unsigned split = SDFK_BRICK;
+    float4 bnd, bnd2;
+    float2 xy2 = make_float2(fx, fy);
+    if ((q0 & q1) == ~0ull) {                                   // one run: 1-D bound
+        kind = 1u;
         const float cz = 0.5f * (fz + lz);
-        const f2 xa = {x.x - cx, x.y - cx}, xb = {x.z - cx, x.w - cx}, ya = {y.x - cy, y.y - cy}, yb = {y.z - cy, y.w - cy},
-                 za = {z.x - cz, z.y - cz}, zb = {z.z - cz, z.w - cz};
-        const f2 da = sd_fma(xa, xa, sd_fma(ya, ya, za * za)), db = sd_fma(xb, xb, sd_fma(yb, yb, zb * zb));
-        float r2 = sd_rawmax(sd_rawmax(da.x, da.y), sd_rawmax(db.x, db.y));
-#pragma unroll
-        for (int m = 1; m < BL; m <<= 1) r2 = sd_rawmax(r2, __shfl_xor(r2, m));
-        // how many leading points of this lane share the brick's first x, y (bitwise)?
-        const bool e0 = x.x == fx && y.x == fy, e1 = x.y == fx && y.y == fy, e2 = x.z == fx && y.z == fy,
-                   e3 = x.w == fx && y.w == fy;
-        const int c1 = e0 ? (e1 ? (e2 ? (e3 ? 4 : 3) : 2) : 1) : 0;
-        const unsigned full = (unsigned)(__ballot(c1 == 4) >> first);       // BL == 32 bits of this brick
-        const int lead = (full == 0xffffffffu) ? BL : __builtin_ctz(~full);  // leading lanes that are all-equal
-        unsigned kind = (lead == BL) ? 1u : 0u;
-        float4 bnd = make_float4(cx, cy, cz, 1.00001f * sqrtf(r2) + 1e-30f);
-        float4 bnd2 = bnd;
-        float2 xy2 = make_float2(fx, fy);
-        unsigned split = SDFK_BRICK;
-        if (__ballot(lead < BL) != 0ull) {                                    // some brick of this wave is not one run
-            const int sl = first + (lead < BL ? lead : 0);                    // lane holding the first different point
-            const int cs = __shfl(c1, sl);
-            const int s = 4 * lead + cs;                                       // its index in the brick
-            const float xo = c1 == 0 ? x.x : c1 == 1 ? x.y : c1 == 2 ? x.z : x.w;
-            const float yo = c1 == 0 ? y.x : c1 == 1 ? y.y : c1 == 2 ? y.z : y.w;
-            const float zo = c1 == 0 ? z.x : c1 == 1 ? z.y : c1 == 2 ? z.z : z.w;
-            const float zup = __shfl_up(z.w, 1);                               // last z of the previous lane
-            const float zpo = c1 == 0 ? zup : c1 == 1 ? z.x : c1 == 2 ? z.y : z.z;
-            const float x2 = __shfl(xo, sl), y2 = __shfl(yo, sl), zs = __shfl(zo, sl), zp = __shfl(zpo, sl);
-            const int i0 = 4 * li;
-            const bool k0 = (i0 < s) ? e0 : (x.x == x2 && y.x == y2), k1 = (i0 + 1 < s) ? e1 : (x.y == x2 && y.y == y2),
-                       k2 = (i0 + 2 < s) ? e2 : (x.z == x2 && y.z == y2), k3 = (i0 + 3 < s) ? e3 : (x.w == x2 && y.w == y2);
-            const unsigned okb = (unsigned)(__ballot(k0 && k1 && k2 && k3) >> first);
-            const bool two = lead < BL && s > 0 && okb == 0xffffffffu;
+        const float r = sdfk_wave_max(sd_rawmax(sd_abs(z.x - cz), sd_abs(z.y - cz)));
+        bnd = make_float4(fx, fy, cz, 1.00001f * r + 1e-30f);
+        bnd2 = bnd;
+    } else {
+        // index of the first point that differs from the first one
+        const int s0 = (~q0 == 0ull) ? 64 : __builtin_ctzll(~q0), s1 = (~q1 == 0ull) ? 64 : __builtin_ctzll(~q1);
+        const int s = (2 * s0 < 2 * s1 + 1) ? 2 * s0 : 2 * s1 + 1;
+        const int sl = s >> 1, pl = (s - 1) >> 1;
+        const float x2 = (s & 1) ? sdfk_lane(x.y, sl) : sdfk_lane(x.x, sl), y2 = (s & 1) ? sdfk_lane(y.y, sl) : sdfk_lane(y.x, sl);
+        const float zs = (s & 1) ? sdfk_lane(z.y, sl) : sdfk_lane(z.x, sl);
+        const float zp = s > 0 ? (((s - 1) & 1) ? sdfk_lane(z.y, pl) : sdfk_lane(z.x, pl)) : fz;
+        const bool k0 = (2 * lane < s) ? e0 : (x.x == x2 && y.x == y2), k1 = (2 * lane + 1 < s) ? e1 : (x.y == x2 && y.y == y2);
+        const bool two = s > 0 && (__ballot(k0 && k1) == ~0ull);
+        if (two) {
+            kind = 2u;
+            split = (unsigned)s;
             const float c1z = 0.5f * (fz + zp), c2z = 0.5f * (zs + lz);
-            float ra = sd_rawmax(sd_rawmax(i0 < s ? sd_abs(z.x - c1z) : 0.0f, i0 + 1 < s ? sd_abs(z.y - c1z) : 0.0f),
-                                 sd_rawmax(i0 + 2 < s ? sd_abs(z.z - c1z) : 0.0f, i0 + 3 < s ? sd_abs(z.w - c1z) : 0.0f));
-            float rb = sd_rawmax(sd_rawmax(i0 < s ? 0.0f : sd_abs(z.x - c2z), i0 + 1 < s ? 0.0f : sd_abs(z.y - c2z)),
-                                 sd_rawmax(i0 + 2 < s ? 0.0f : sd_abs(z.z - c2z), i0 + 3 < s ? 0.0f : sd_abs(z.w - c2z)));
+            const float ra = sdfk_wave_max(sd_rawmax(2 * lane < s ? sd_abs(z.x - c1z) : 0.0f, 2 * lane + 1 < s ? sd_abs(z.y - c1z) : 0.0f));
+            const float rb = sdfk_wave_max(sd_rawmax(2 * lane < s ? 0.0f : sd_abs(z.x - c2z), 2 * lane + 1 < s ? 0.0f : sd_abs(z.y - c2z)));
+            bnd = make_float4(fx, fy, c1z, 1.00001f * ra + 1e-30f);
+            bnd2 = make_float4(x2, y2, c2z, 1.00001f * rb + 1e-30f);
+            xy2 = make_float2(x2, y2);
+        } else {                                                // arbitrary points: sphere around the midpoint of the
+            kind = 0u;                                          // first and the last point
+            const float cx = 0.5f * (fx + sdfk_lane(x.y, 63)), cy = 0.5f * (fy + sdfk_lane(y.y, 63)), cz = 0.5f * (fz + lz);
+            const f2 dx = x - cx, dy = y - cy, dz = z - cz;
+            const f2 d2 = sd_fma(dx, dx, sd_fma(dy, dy, dz * dz));
+            const float r2 = sdfk_wave_max(sd_rawmax(d2.x, d2.y));
+            bnd = make_float4(cx, cy, cz, 1.00001f * sqrtf(r2) + 1e-30f);
+            bnd2 = bnd;
+        }
+    }
+    if (lane == 0) {
+        meta->bound[b] = bnd;
+        meta->bound2[b] = bnd2;
+        meta->kind[b] = kind;
+        meta->split[b] = split;
+        meta->xy[b] = make_float2(fx, fy);
+        meta->xy2[b] = xy2;
+    }
+}
+
+struct sdfk_tileregs {
+    f2 x[SDFK_WBRICKS], y[SDFK_WBRICKS], z[SDFK_WBRICKS];
+};
+// issue the loads of one tile (this wave's bricks); they are consumed an iteration later
+static __device__ __forceinline__ void sdfk_tile_load(const float* __restrict__ co, long long stride, long long n,
+                                                      long long tile_base, int lane, int wave, sdfk_tileregs& r) {
 #pragma unroll
-            for (int m = 1; m < BL; m <<= 1) {
-                ra = sd_rawmax(ra, __shfl_xor(ra, m));
-                rb = sd_rawmax(rb, __shfl_xor(rb, m));
-            }
-            if (two) {
-                kind = 2u;
-                bnd = make_float4(fx, fy, c1z, 1.00001f * ra + 1e-30f);
-                bnd2 = make_float4(x2, y2, c2z, 1.00001f * rb + 1e-30f);
-                xy2 = make_float2(x2, y2);
-                split = (unsigned)s;
-            }
-        }
-        if (li == 0) {
-            const int b = local / SDFK_BRICK;
-            buf->bound[b] = bnd;
-            buf->bound2[b] = bnd2;
-            buf->kind[b] = kind;
-            buf->split[b] = split;
-            buf->xy[b] = make_float2(fx, fy);
-            buf->xy2[b] = xy2;
+    for (int j = 0; j < SDFK_WBRICKS; ++j) {
+        const long long i = tile_base + (long long)(wave * SDFK_WBRICKS + j) * SDFK_BRICK + 2 * lane;
+        if (i + 1 < n) {
+            r.x[j] = *reinterpret_cast<const f2*>(co + i);
+            r.y[j] = *reinterpret_cast<const f2*>(co + stride + i);
+            r.z[j] = *reinterpret_cast<const f2*>(co + 2 * stride + i);
+        } else {   // ragged end of the array / beyond it: repeat the last point (keeps the bounds valid)
+            const long long last = n - 1;
+            const long long i0 = i < last ? i : last;
+            r.x[j] = {co[i0], co[last]};
+            r.y[j] = {co[stride + i0], co[stride + last]};
+            r.z[j] = {co[2 * stride + i0], co[2 * stride + last]};
         }
     }
-    __syncthreads();
-    // ---- phase B: one lane per run ----
-    if (tid < 2 * SDFK_NBRICK) {
-        const int b = tid % SDFK_NBRICK, second = tid / SDFK_NBRICK;
-        const unsigned kind = buf->kind[b];
+}
+// phase A: bounds of this wave's bricks from registers, z to LDS
+static __device__ __forceinline__ void sdfk_tile_bounds(const sdfk_tileregs& r, sdfk_tilemeta* meta, int lane, int wave) {
+#pragma unroll
+    for (int j = 0; j < SDFK_WBRICKS; ++j) {
+        const int b = wave * SDFK_WBRICKS + j;
+        *reinterpret_cast<f2*>(meta->z + b * SDFK_BRICK + 2 * lane) = r.z[j];
+        sdfk_brick_bounds(r.x[j], r.y[j], r.z[j], lane, meta, b);
+    }
+}
+// phase B: one lane per run (pl = index of the lane among the probing lanes)
+static __device__ __forceinline__ void sdfk_tile_probe(const float* __restrict__ PRM, const float* __restrict__ TAB,
+                                                       sdfk_tilemeta* meta, int pl) {
+    if (pl < 2 * SDFK_NBRICK) {
+        const int b = pl % SDFK_NBRICK, second = pl / SDFK_NBRICK;
+        const unsigned kind = meta->kind[b];
         if (!second || kind == 2u) {
-            const float4 bb = second ? buf->bound2[b] : buf->bound[b];
+            const float4 bb = second ? meta->bound2[b] : meta->bound[b];
             V3T<float> c = {bb.x, bb.y, bb.z};     // for an x/y-constant run the centre has exactly that x and y
-            const unsigned long long m = sdfk_probe(c, bb.w, second ? buf->base2[b] : buf->base[b], PRM, TAB);
-            if (second) buf->mask2[b] = m;
-            else buf->mask[b] = m | ((unsigned long long)(kind == 1u) << 63) | ((unsigned long long)(kind == 2u) << 62);
+            const unsigned long long m = sdfk_probe(c, bb.w, second ? meta->base2[b] : meta->base[b], PRM, TAB);
+            if (second) meta->mask2[b] = m;
+            else meta->mask[b] = m | ((unsigned long long)(kind == 1u) << 63) | ((unsigned long long)(kind == 2u) << 62);
         }
     }
-    __syncthreads();
 }
 // skip bits of a brick: both runs of a two-run brick must agree
-static __device__ __forceinline__ unsigned long long sdfk_brick_mask(const sdfk_tilebuf* buf, int b) {
-    unsigned long long m = buf->mask[b];
-    if ((m >> 62) & 1ull) m &= buf->mask2[b] | (3ull << 62);
+static __device__ __forceinline__ unsigned long long sdfk_brick_mask(const sdfk_tilemeta* meta, int b) {
+    unsigned long long m = meta->mask[b];
+    if ((m >> 62) & 1ull) m &= meta->mask2[b] | (3ull << 62);
     return m;
 }
-// debugging / test aid: the skip masks of every brick (2 bits per site: bit 2k = skip first operand,
-// bit 2k+1 = skip second operand; bit 63 = x/y-constant run, bit 62 = two such runs)
-extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_tmask(
-    const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
-    long long n, unsigned long long* __restrict__ masks) {
-    __shared__ __attribute__((aligned(16))) sdfk_tilebuf buf;
-    sdfk_tile_prepare(PRM, TAB, co, stride, n, &buf);
-    for (int b = threadIdx.x; b < SDFK_NBRICK; b += SDFK_TTHREADS)
-        masks[(long long)blockIdx.x * SDFK_NBRICK + b] = sdfk_brick_mask(&buf, b);
-}
-extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_t(
-    const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
-    long long n, float* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) sdfk_tilebuf buf;
-    const long long tile_base = (long long)blockIdx.x * SDFK_TILE;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    sdfk_tile_prepare(PRM, TAB, co, stride, n, &buf);
-    // ---- phase C ----
-    for (int b = wave; b < SDFK_NBRICK; b += SDFK_TTHREADS / 64) {
+// phase C: evaluate this wave's bricks of the prepared tile
+static __device__ __forceinline__ void sdfk_tile_evaluate(const float* __restrict__ PRM, const float* __restrict__ TAB,
+                                                          const float* __restrict__ co, long long stride, long long n,
+                                                          long long tile_base, const sdfk_tilemeta* meta,
+                                                          float* __restrict__ out, int lane, int wave) {
+#pragma unroll 1
+    for (int j = 0; j < SDFK_WBRICKS; ++j) {
+        const int b = wave * SDFK_WBRICKS + j;
+        const long long i = tile_base + (long long)b * SDFK_BRICK + 2 * lane;
         if (tile_base + (long long)b * SDFK_BRICK >= n) break;                        // bricks past the end
-        const unsigned long long mv = sdfk_brick_mask(&buf, b);
+        const unsigned long long mv = sdfk_brick_mask(meta, b);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)mv);            // wave-uniform (SGPRs)
         const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(mv >> 32));
-        const int local = b * SDFK_BRICK + 2 * lane;
-        const long long i = tile_base + local;
-        const f2 z = *reinterpret_cast<const f2*>(buf.z + local);
+        const f2 z = *reinterpret_cast<const f2*>(meta->z + b * SDFK_BRICK + 2 * lane);
         f2 r;
         if (hi >> 31) {                                                               // one run
-            const float2 xy = buf.xy[b];
+            const float2 xy = meta->xy[b];
             V3P p = {sp<f2>(xy.x), sp<f2>(xy.y), z};
-            r = sdfk_point_culled<f2, true>(p, lo, hi, buf.base[b], PRM, TAB);
+            r = sdfk_point_culled<f2, true>(p, lo, hi, meta->base[b], PRM, TAB);
         } else {
             V3P p;
             if ((hi >> 30) & 1u) {                                                    // two runs
-                const float2 xa = buf.xy[b], xb = buf.xy2[b];
-                const int s = (int)buf.split[b];
+                const float2 xa = meta->xy[b], xb = meta->xy2[b];
+                const int s = (int)meta->split[b];
                 const bool a0 = 2 * lane < s, a1 = 2 * lane + 1 < s;
                 p = {{a0 ? xa.x : xb.x, a1 ? xa.x : xb.x}, {a0 ? xa.y : xb.y, a1 ? xa.y : xb.y}, z};
             } else {                                                                  // arbitrary points
@@ -245,11 +243,45 @@ extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_t(
                 const long long i0 = i < last ? i : last, i1 = i + 1 < last ? i + 1 : last;
                 p = {{co[i0], co[i1]}, {co[stride + i0], co[stride + i1]}, z};
             }
-            r = sdfk_point_culled<f2, false>(p, lo, hi, buf.base[b], PRM, TAB);
+            r = sdfk_point_culled<f2, false>(p, lo, hi, meta->base[b], PRM, TAB);
         }
         if (i + 1 < n) *reinterpret_cast<f2*>(out + i) = r;
         else if (i < n) out[i] = r.x;
     }
+}
+// phases A and B of one tile (two workgroup barriers)
+static __device__ __forceinline__ void sdfk_tile_prepare(const float* __restrict__ PRM, const float* __restrict__ TAB,
+                                                         const float* __restrict__ co, long long stride, long long n,
+                                                         sdfk_tilemeta* meta) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    sdfk_tileregs r;
+    sdfk_tile_load(co, stride, n, (long long)blockIdx.x * SDFK_TILE, lane, wave, r);
+    sdfk_tile_bounds(r, meta, lane, wave);
+    __syncthreads();
+    sdfk_tile_probe(PRM, TAB, meta, threadIdx.x);
+    __syncthreads();
+}
+// debugging / test aid: the skip masks of every brick (2 bits per site: bit 2k = skip first operand,
+// bit 2k+1 = skip second operand; bit 63 = x/y-constant run, bit 62 = two such runs)
+extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_tmask(
+    const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
+    long long n, unsigned long long* __restrict__ masks) {
+    __shared__ __attribute__((aligned(16))) sdfk_tilemeta meta;
+    sdfk_tile_prepare(PRM, TAB, co, stride, n, &meta);
+    for (int b = threadIdx.x; b < SDFK_NBRICK; b += SDFK_TTHREADS)
+        masks[(long long)blockIdx.x * SDFK_NBRICK + b] = sdfk_brick_mask(&meta, b);
+}
+// One tile per workgroup; many short-lived workgroups per CU sit in different phases at any time, which is
+// what overlaps the memory phase (A) with the VALU phases (B, C). Two persistent variants (register prefetch
+// of the next tile; a dedicated probing wave) were measured 1.5-2.5x slower: with few long-lived workgroups
+// per CU the phases run in lockstep and the single-wave probe leaves the CU idle.
+extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_t(
+    const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
+    long long n, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) sdfk_tilemeta meta;
+    sdfk_tile_prepare(PRM, TAB, co, stride, n, &meta);
+    sdfk_tile_evaluate(PRM, TAB, co, stride, n, (long long)blockIdx.x * SDFK_TILE, &meta, out, threadIdx.x & 63,
+                       threadIdx.x >> 6);
 }
 )SDFKT";
 

@@ -87,7 +87,7 @@ int sdfk_eval_grid(sdfk_program* prog, const float* ax0, int64_t n0, const float
                    int64_t n2, int64_t start, int64_t count, float* d_out, void* stream, int mode);
 void sdfk_set_default_mode(int mode);
 /* Test / diagnostics aid for brick culling: writes one 64-bit skip mask per brick of 128 consecutive
- * points (ceil(n / 1024) * 8 entries; bit 2k = first operand of site k skipped, bit 2k+1 = second operand,
+ * points (ceil(n / 2048) * 16 entries; bit 2k = first operand of site k skipped, bit 2k+1 = second operand,
  * bit 63 = all points of the brick share x and y). */
 int sdfk_debug_brick_masks(sdfk_program* prog, const float* d_co, int64_t n, int64_t row_stride, uint64_t* d_masks,
                            void* stream);

@@ -340,7 +340,7 @@ def test_brick_masks_are_conservative(engine):
     n = co32.shape[1]
     stride = (n + 255) // 256 * 256
     lib = engine.lib()
-    nb = (n + 1023) // 1024 * 8
+    nb = (n + 2047) // 2048 * 16
     d_co, d_m = lib.sdfk_malloc(3 * stride * 4), lib.sdfk_malloc(nb * 8)
     try:
         host = np.zeros((3, stride), dtype=np.float32)

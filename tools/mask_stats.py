@@ -25,7 +25,7 @@ def main(grid=512):
     n = res[0] * res[1] * res[2]
     stride = (n + 255) // 256 * 256
     d_co = lib.sdfk_malloc(3 * stride * 4)
-    nb = (n + 1023) // 1024 * 8
+    nb = (n + 2047) // 2048 * 16
     d_m = lib.sdfk_malloc(nb * 8)
     _engine.grid_fill(d_co, stride, axes, 0, n)
     _engine.check(lib.sdfk_debug_brick_masks(prog.handle, ctypes.c_void_p(d_co), n, stride, ctypes.c_void_p(d_m), None),
