@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--grid", type=int, default=1024, help="requested resolution per axis (odd-converted)")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg5"])
+    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--mode", default="auto", choices=["auto", "interpret", "nocull"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-allgather", action="store_true")
@@ -52,6 +52,8 @@ def build_workload(name, ns, scenes):
         return scenes.cfg2_tree(ns), (2, 2, 2), "cfg2: 10-primitive left-deep SMOOTH_UNION2(0.1) chain, rng 1234"
     if name == "cfg3":
         return scenes.cfg3_chain(ns), (4, 4, 4), "cfg3: Box + elongation/twist/bend/infinite_repetition"
+    if name == "cfg4":
+        return scenes.cfg4_scene2d(ns), (10, 10), "cfg4: 2-D n-ary UNION of 50 onion/rounded primitives, rng 7"
     return scenes.cfg5_tree(ns), (3, 3, 3), "cfg5: 20-primitive 3-level tree, rng 2049"
 
 
@@ -122,9 +124,9 @@ def main():
     _engine.lib()  # fail loudly if the HIP extension is missing
 
     tree, size, desc = build_workload(args.workload, ns, scenes)
-    axes64, res = grid_axes(size, (args.grid,) * 3)
+    axes64, res = grid_axes(size, (args.grid,) * len(size))
     axes = [a.astype(np.float32) for a in axes64]           # fp32-rounded float64 linspace ("identical grids")
-    n_total = int(res[0]) * int(res[1]) * int(res[2])
+    n_total = int(axes[0].size) * int(axes[1].size) * int(axes[2].size)
     # contiguous slabs of the flat index (x-slabs); remainder to the last rank
     per = n_total // world
     start = rank * per
@@ -218,8 +220,8 @@ def main():
             "value": value, "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "grid": "%dx%dx%d (request %d^3), size %s" % (res[0], res[1], res[2],
-                                                                                      args.grid, tuple(size)),
+            "config": {"workload": desc, "grid": "%dx%dx%d (request %d per axis), size %s" % (
+                axes[0].size, axes[1].size, axes[2].size, args.grid, tuple(size)),
                        "points": n_total, "points_per_gpu": count, "sharding": "contiguous x-slabs, no collective",
                        "kernel": ("sdfk_spec_t (hiprtc, topology-specialised, exact brick culling)" if culled else
                                   "sdfk_spec_v4 (hiprtc, topology-specialised)") if mode != _engine.MODE_INTERPRET
