@@ -452,7 +452,7 @@ static int rtc_compile(const std::string& src, std::vector<char>* out, std::stri
     snprintf(d_tile, sizeof d_tile, "-DSDFK_TWAVES=%d", tile_waves());
     snprintf(d_thr, sizeof d_thr, "-DSDFK_WBRICKS=%d", tile_wbricks());
     std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", d_tile, d_thr};
-    // experiment hook: extra -D switches for the generated source (space separated), e.g. SDFK_RTC_DEFS="-DSDFK_NO_ZRUN"
+    // experiment hook: extra -D switches for the generated source (space separated), e.g. SDFK_RTC_DEFS="-DSDFK_TWAVES=2"
     std::vector<std::string> extra;
     if (const char* e = getenv("SDFK_RTC_DEFS")) {
         std::string all(e);
