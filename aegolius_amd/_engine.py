@@ -32,6 +32,7 @@ SIGNATURES = {
     "sdfk_eval_device": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _int]),
     "sdfk_eval_host": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _int, _int]),
     "sdfk_eval_grid": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _int]),
+    "sdfk_eval_grid_host": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _int, _int]),
     "sdfk_set_default_mode": (None, [_int]),
     "sdfk_debug_brick_masks": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "sdfk_linspace_f32": (_int, [_c.c_double, _c.c_double, _i64, _vp]),
@@ -169,6 +170,17 @@ class Program:
         ax = [np.ascontiguousarray(a, dtype=np.float32) for a in axes]
         check(lib().sdfk_eval_grid(self._h, _ptr(ax[0]), ax[0].size, _ptr(ax[1]), ax[1].size, _ptr(ax[2]),
                                    ax[2].size, start, count, _vp(d_out), _vp(stream or 0), mode), "sdfk_eval_grid")
+
+    def eval_grid_host(self, axes, start=0, count=None, device=0, mode=MODE_AUTO):
+        """Field of the grid spanned by three per-axis tables (flat index z fastest), straight to a host array."""
+        require_gpu()
+        ax = [np.ascontiguousarray(a, dtype=np.float32) for a in axes]
+        total = ax[0].size * ax[1].size * ax[2].size
+        count = total - start if count is None else count
+        out = np.empty(count, dtype=np.float32)
+        check(lib().sdfk_eval_grid_host(self._h, _ptr(ax[0]), ax[0].size, _ptr(ax[1]), ax[1].size, _ptr(ax[2]),
+                                        ax[2].size, start, count, _ptr(out), device, mode), "sdfk_eval_grid_host")
+        return out
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

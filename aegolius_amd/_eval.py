@@ -18,6 +18,8 @@ class Config:
     mode = _engine.MODE_AUTO      # MODE_AUTO (specialised, hiprtc) | MODE_INTERPRET | MODE_SPECIALIZED
     output_dtype = np.float32     # the reference returns float64; set to np.float64 to get an upcast copy
     cache_size = 128
+    grid_fast_path = True         # generate_grid tags its (read-only) result; create() then evaluates the grid
+                                  # from the per-axis tables on the GPU instead of uploading 12 B/point
 
 
 config = Config()
@@ -42,7 +44,11 @@ def program_for(lowered):
 
 
 def _run(lowered, co):
-    out = program_for(lowered).eval_host(co, device=config.device, mode=config.mode)
+    axes = getattr(co, "grid_axes", None) if config.grid_fast_path else None
+    if axes is not None:
+        out = program_for(lowered).eval_grid_host(axes, device=config.device, mode=config.mode)
+    else:
+        out = program_for(lowered).eval_host(co, device=config.device, mode=config.mode)
     if config.output_dtype is not np.float32:
         out = out.astype(config.output_dtype)
     return out

@@ -34,15 +34,42 @@ def grid_axes(size, resolution):
     return axes, res
 
 
+class GridCoords(np.ndarray):
+    """The (3, N) array returned by generate_grid, tagged with the per-axis tables it was built from.
+
+    `create(co)` recognises the tag and evaluates the grid straight from the three small tables on the
+    GPU (no 12 B/point upload, no device coordinate array). The tag is only trusted while the array
+    cannot have changed: the array is handed out read-only, and every view, slice, copy or ufunc result is
+    a plain untagged ndarray. `co.setflags(write=True)` (or `config.grid_fast_path = False`) opts out."""
+
+    def __array_finalize__(self, obj):
+        self._grid_axes = None          # views / copies / results never inherit the tag
+
+    def __reduce__(self):               # pickles as a plain array
+        return np.asarray(self).__reduce__()
+
+    @property
+    def grid_axes(self):
+        """The float64 axis tables if this array is still guaranteed to be the untouched grid, else None."""
+        if self._grid_axes is not None and not self.flags.writeable:
+            return self._grid_axes
+        return None
+
+
 def generate_grid(size, resolution):
     """Grid of points centred at zero: (co (3, N) float64, (res0, res1, res2))."""
+    from .._eval import config
     axes, res = grid_axes(size, resolution)
     n = [a.size for a in axes]
-    co = np.empty((3, n[0] * n[1] * n[2]))
-    shaped = co.reshape(3, *n)
+    shape = (3, n[0] * n[1] * n[2])
+    co = GridCoords(shape, dtype=np.float64) if config.grid_fast_path else np.empty(shape)
+    shaped = np.asarray(co).reshape(3, *n)
     shaped[0] = axes[0][:, None, None]
     shaped[1] = axes[1][None, :, None]
     shaped[2] = axes[2][None, None, :]
+    if config.grid_fast_path:
+        co._grid_axes = [a.copy() for a in axes]
+        co.setflags(write=False)
     return co, res
 
 

@@ -150,7 +150,7 @@ struct DevState {
 
 struct SpecKernel {
     hipModule_t mod = nullptr;
-    hipFunction_t v4 = nullptr, v1 = nullptr, g4 = nullptr, g1 = nullptr, tile = nullptr, tmask = nullptr;
+    hipFunction_t v4 = nullptr, v1 = nullptr, g4 = nullptr, g1 = nullptr, tile = nullptr, tile_grid = nullptr, tmask = nullptr;
     bool failed = false;
     std::string error;
 };
@@ -517,6 +517,7 @@ static std::shared_ptr<SpecKernel> get_spec(sdfk_program* p, int device) {
     if (e == hipSuccess) e = hipModuleGetFunction(&sk->g1, sk->mod, "sdfk_spec_g1");
     if (e == hipSuccess && !p->sites.empty()) e = hipModuleGetFunction(&sk->tile, sk->mod, "sdfk_spec_t");
     if (e == hipSuccess && !p->sites.empty()) e = hipModuleGetFunction(&sk->tmask, sk->mod, "sdfk_spec_tmask");
+    if (e == hipSuccess && !p->sites.empty()) e = hipModuleGetFunction(&sk->tile_grid, sk->mod, "sdfk_spec_tg");
     if (e != hipSuccess) {
         sk->failed = true;
         sk->error = std::string("hipModuleLoadData/GetFunction: ") + hipGetErrorString(e);
@@ -595,6 +596,13 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
             void* args[] = {&prm, &tab, &co, &stride, &n, &d_out};
             const unsigned tiles = (unsigned)((n + tile_points() - 1) / tile_points());
             HIPCHK(hipModuleLaunchKernel(sk->tile, tiles, 1, 1, tile_threads(), 1, 1, 0, stream, args, nullptr));
+            return 0;
+        }
+        if (grid && sk->tile_grid && vec_ok && mode != SDFK_MODE_NOCULL) {
+            SrcGrid g = *grid;
+            void* args[] = {&prm, &tab, &g, &n, &d_out};
+            const unsigned tiles = (unsigned)((n + tile_points() - 1) / tile_points());
+            HIPCHK(hipModuleLaunchKernel(sk->tile_grid, tiles, 1, 1, tile_threads(), 1, 1, 0, stream, args, nullptr));
             return 0;
         }
         if (arr) {
@@ -742,6 +750,33 @@ extern "C" int sdfk_eval_grid(sdfk_program* p, const float* ax0, int64_t n0, con
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));  // the axis tables are freed on return
     return 0;
+}
+
+// Host-buffer convenience for grids: evaluate flat indices [start, start+count) of the grid in device chunks
+// and copy the field back; no coordinate array ever exists (host or device).
+extern "C" int sdfk_eval_grid_host(sdfk_program* p, const float* ax0, int64_t n0, const float* ax1, int64_t n1,
+                                   const float* ax2, int64_t n2, int64_t start, int64_t count, float* out, int device,
+                                   int mode) {
+    if (!p) return fail(-1, "null program");
+    if (count < 0 || (count > 0 && !out)) return fail(-1, "sdfk_eval_grid_host: bad arguments");
+    if (start < 0 || start + count > n0 * n1 * n2) return fail(-1, "sdfk_eval_grid_host: range outside the grid");
+    if (count == 0) return 0;
+    HIPCHK(hipSetDevice(device));
+    const int64_t chunk = std::min<int64_t>(count, (int64_t)1 << 27);   // 128 Mi points = 512 MiB of device memory
+    float* d_out = nullptr;
+    HIPCHK(hipMalloc(&d_out, (size_t)chunk * sizeof(float)));
+    AxisTables t;
+    SrcGrid g;
+    int rc = upload_axes(ax0, n0, ax1, n1, ax2, n2, nullptr, &t, &g, start);
+    for (int64_t s = 0; s < count && rc == 0; s += chunk) {
+        const int64_t m = std::min(chunk, count - s);
+        g.start = start + s;
+        rc = run(p, nullptr, &g, m, d_out, nullptr, mode, true);
+        if (rc == 0 && hipMemcpy(out + s, d_out, (size_t)m * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(-6, "sdfk_eval_grid_host: device-to-host copy failed");
+    }
+    (void)hipFree(d_out);
+    return rc;
 }
 
 extern "C" int sdfk_grid_fill(float* d_co, int64_t row_stride, const float* ax0, int64_t n0, const float* ax1,

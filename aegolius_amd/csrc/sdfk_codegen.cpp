@@ -163,24 +163,58 @@ static __device__ __forceinline__ void sdfk_brick_bounds(f2 x, f2 y, f2 z, int l
 struct sdfk_tileregs {
     f2 x[SDFK_WBRICKS], y[SDFK_WBRICKS], z[SDFK_WBRICKS];
 };
-// issue the loads of one tile (this wave's bricks); they are consumed an iteration later
-static __device__ __forceinline__ void sdfk_tile_load(const float* __restrict__ co, long long stride, long long n,
-                                                      long long tile_base, int lane, int wave, sdfk_tileregs& r) {
-#pragma unroll
-    for (int j = 0; j < SDFK_WBRICKS; ++j) {
-        const long long i = tile_base + (long long)(wave * SDFK_WBRICKS + j) * SDFK_BRICK + 2 * lane;
-        if (i + 1 < n) {
-            r.x[j] = *reinterpret_cast<const f2*>(co + i);
-            r.y[j] = *reinterpret_cast<const f2*>(co + stride + i);
-            r.z[j] = *reinterpret_cast<const f2*>(co + 2 * stride + i);
-        } else {   // ragged end of the array / beyond it: repeat the last point (keeps the bounds valid)
-            const long long last = n - 1;
-            const long long i0 = i < last ? i : last;
-            r.x[j] = {co[i0], co[last]};
-            r.y[j] = {co[stride + i0], co[stride + last]};
-            r.z[j] = {co[2 * stride + i0], co[2 * stride + last]};
-        }
+// points (i, i+1) of a brick whose first point has index brick_base (wave-uniform); indices beyond n-1 repeat the
+// last point (keeps the bounds valid at the ragged end)
+static __device__ __forceinline__ void sdfk_pair(const SrcArray& s, long long brick_base, int lane, long long n,
+                                                 f2& x, f2& y, f2& z) {
+    const long long i = brick_base + 2 * lane;
+    if (i + 1 < n) {
+        x = *reinterpret_cast<const f2*>(s.co + i);
+        y = *reinterpret_cast<const f2*>(s.co + s.stride + i);
+        z = *reinterpret_cast<const f2*>(s.co + 2 * s.stride + i);
+    } else {
+        const long long last = n - 1;
+        const long long i0 = i < last ? i : last;
+        x = {s.co[i0], s.co[last]};
+        y = {s.co[s.stride + i0], s.co[s.stride + last]};
+        z = {s.co[2 * s.stride + i0], s.co[2 * s.stride + last]};
     }
+}
+// regular grid: the 64-bit divisions act on the wave-uniform brick base (scalar unit), the per-lane part is 32-bit
+static __device__ __forceinline__ void sdfk_pair(const SrcGrid& s, long long brick_base, int lane, long long n,
+                                                 f2& x, f2& y, f2& z) {
+    const long long last = n - 1;
+    const long long bb = brick_base < last ? brick_base : last;
+    const unsigned long long base = (unsigned long long)(s.start + bb);
+    const unsigned long long row = base / s.n2;
+    const unsigned iz0 = (unsigned)(base - row * s.n2);
+    const unsigned long long ix0 = row / s.n1;
+    const unsigned iy0 = (unsigned)(row - ix0 * s.n1);
+    const unsigned room = (unsigned)(last - bb);               // points of the array after the brick base
+    float px[2], py[2], pz[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        unsigned off = 2u * (unsigned)lane + (unsigned)k;
+        off = off < room ? off : room;
+        const unsigned t = iz0 + off;
+        const unsigned cz = t / s.n2, iz = t - cz * s.n2;
+        const unsigned ty = iy0 + cz;
+        const unsigned cy = ty / s.n1, iy = ty - cy * s.n1;
+        px[k] = s.ax0[ix0 + cy];
+        py[k] = s.ax1[iy];
+        pz[k] = s.ax2[iz];
+    }
+    x = {px[0], px[1]};
+    y = {py[0], py[1]};
+    z = {pz[0], pz[1]};
+}
+// issue the loads of one tile (this wave's bricks)
+template <typename SRC>
+static __device__ __forceinline__ void sdfk_tile_load(const SRC& src, long long n, long long tile_base, int lane, int wave,
+                                                      sdfk_tileregs& r) {
+#pragma unroll
+    for (int j = 0; j < SDFK_WBRICKS; ++j)
+        sdfk_pair(src, tile_base + (long long)(wave * SDFK_WBRICKS + j) * SDFK_BRICK, lane, n, r.x[j], r.y[j], r.z[j]);
 }
 // phase A: bounds of this wave's bricks from registers, z to LDS
 static __device__ __forceinline__ void sdfk_tile_bounds(const sdfk_tileregs& r, sdfk_tilemeta* meta, int lane, int wave) {
@@ -213,10 +247,11 @@ static __device__ __forceinline__ unsigned long long sdfk_brick_mask(const sdfk_
     return m;
 }
 // phase C: evaluate this wave's bricks of the prepared tile
+template <typename SRC>
 static __device__ __forceinline__ void sdfk_tile_evaluate(const float* __restrict__ PRM, const float* __restrict__ TAB,
-                                                          const float* __restrict__ co, long long stride, long long n,
-                                                          long long tile_base, const sdfk_tilemeta* meta,
-                                                          float* __restrict__ out, int lane, int wave) {
+                                                          const SRC& src, long long n, long long tile_base,
+                                                          const sdfk_tilemeta* meta, float* __restrict__ out, int lane,
+                                                          int wave) {
 #pragma unroll 1
     for (int j = 0; j < SDFK_WBRICKS; ++j) {
         const int b = wave * SDFK_WBRICKS + j;
@@ -238,10 +273,10 @@ static __device__ __forceinline__ void sdfk_tile_evaluate(const float* __restric
                 const int s = (int)meta->split[b];
                 const bool a0 = 2 * lane < s, a1 = 2 * lane + 1 < s;
                 p = {{a0 ? xa.x : xb.x, a1 ? xa.x : xb.x}, {a0 ? xa.y : xb.y, a1 ? xa.y : xb.y}, z};
-            } else {                                                                  // arbitrary points
-                const long long last = n - 1;
-                const long long i0 = i < last ? i : last, i1 = i + 1 < last ? i + 1 : last;
-                p = {{co[i0], co[i1]}, {co[stride + i0], co[stride + i1]}, z};
+            } else {                                                                  // arbitrary points: x, y again
+                f2 zz;                                                                // (L2-resident: loaded in phase A)
+                sdfk_pair(src, tile_base + (long long)b * SDFK_BRICK, lane, n, p.x, p.y, zz);
+                p.z = z;
             }
             r = sdfk_point_culled<f2, false>(p, lo, hi, meta->base[b], PRM, TAB);
         }
@@ -250,16 +285,39 @@ static __device__ __forceinline__ void sdfk_tile_evaluate(const float* __restric
     }
 }
 // phases A and B of one tile (two workgroup barriers)
+template <typename SRC>
 static __device__ __forceinline__ void sdfk_tile_prepare(const float* __restrict__ PRM, const float* __restrict__ TAB,
-                                                         const float* __restrict__ co, long long stride, long long n,
-                                                         sdfk_tilemeta* meta) {
+                                                         const SRC& src, long long n, sdfk_tilemeta* meta) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     sdfk_tileregs r;
-    sdfk_tile_load(co, stride, n, (long long)blockIdx.x * SDFK_TILE, lane, wave, r);
+    sdfk_tile_load(src, n, (long long)blockIdx.x * SDFK_TILE, lane, wave, r);
     sdfk_tile_bounds(r, meta, lane, wave);
     __syncthreads();
     sdfk_tile_probe(PRM, TAB, meta, threadIdx.x);
     __syncthreads();
+}
+// One tile per workgroup; many short-lived workgroups per CU sit in different phases at any time, which is
+// what overlaps the memory phase (A) with the VALU phases (B, C). Two persistent variants (register prefetch
+// of the next tile; a dedicated probing wave) were measured 1.5-2.5x slower: with few long-lived workgroups
+// per CU the phases run in lockstep and the single-wave probe leaves the CU idle.
+template <typename SRC>
+static __device__ __forceinline__ void sdfk_tile_kernel(const float* __restrict__ PRM, const float* __restrict__ TAB,
+                                                        const SRC& src, long long n, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) sdfk_tilemeta meta;
+    sdfk_tile_prepare(PRM, TAB, src, n, &meta);
+    sdfk_tile_evaluate(PRM, TAB, src, n, (long long)blockIdx.x * SDFK_TILE, &meta, out, threadIdx.x & 63,
+                       threadIdx.x >> 6);
+}
+extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_t(
+    const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
+    long long n, float* __restrict__ out) {
+    const SrcArray s = {co, stride};
+    sdfk_tile_kernel(PRM, TAB, s, n, out);
+}
+// the same on a regular grid expanded from three per-axis tables: no coordinate array at all (4 B/point)
+extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_tg(
+    const float* __restrict__ PRM, const float* __restrict__ TAB, SrcGrid g, long long n, float* __restrict__ out) {
+    sdfk_tile_kernel(PRM, TAB, g, n, out);
 }
 // debugging / test aid: the skip masks of every brick (2 bits per site: bit 2k = skip first operand,
 // bit 2k+1 = skip second operand; bit 63 = x/y-constant run, bit 62 = two such runs)
@@ -267,21 +325,10 @@ extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_tmask(
     const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
     long long n, unsigned long long* __restrict__ masks) {
     __shared__ __attribute__((aligned(16))) sdfk_tilemeta meta;
-    sdfk_tile_prepare(PRM, TAB, co, stride, n, &meta);
+    const SrcArray s = {co, stride};
+    sdfk_tile_prepare(PRM, TAB, s, n, &meta);
     for (int b = threadIdx.x; b < SDFK_NBRICK; b += SDFK_TTHREADS)
         masks[(long long)blockIdx.x * SDFK_NBRICK + b] = sdfk_brick_mask(&meta, b);
-}
-// One tile per workgroup; many short-lived workgroups per CU sit in different phases at any time, which is
-// what overlaps the memory phase (A) with the VALU phases (B, C). Two persistent variants (register prefetch
-// of the next tile; a dedicated probing wave) were measured 1.5-2.5x slower: with few long-lived workgroups
-// per CU the phases run in lockstep and the single-wave probe leaves the CU idle.
-extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_t(
-    const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
-    long long n, float* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) sdfk_tilemeta meta;
-    sdfk_tile_prepare(PRM, TAB, co, stride, n, &meta);
-    sdfk_tile_evaluate(PRM, TAB, co, stride, n, (long long)blockIdx.x * SDFK_TILE, &meta, out, threadIdx.x & 63,
-                       threadIdx.x >> 6);
 }
 )SDFKT";
 

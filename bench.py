@@ -186,6 +186,21 @@ def main():
         step()                                                # restore `out`
         torch.cuda.synchronize()
 
+    # the same evaluation straight from the per-axis tables (no coordinate array: 4 B/point) -- a separate line
+    grid_path = None
+    if rank == 0:
+        for _ in range(2):
+            prog.eval_grid(axes, start, count, out.data_ptr(), stream=stream, mode=mode)
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        for _ in range(5):
+            prog.eval_grid(axes, start, count, out.data_ptr(), stream=stream, mode=mode)
+        torch.cuda.synchronize()
+        gms = (time.perf_counter() - g0) / 5 * 1e3
+        grid_path = {"ms": gms, "mpoints_per_s": count / gms / 1e3, "bytes_per_point": 4,
+                     "note": "sdfk_eval_grid: coordinates expanded in-kernel from three axis tables; includes the "
+                             "per-call table upload and stream sync"}
+
     allgather = None
     if world > 1 and not args.no_allgather:
         pad = (n_total - (world - 1) * per)                   # largest slab
@@ -232,6 +247,8 @@ def main():
                          "kernel_ms": kernel_ms_max, "bytes_per_point": BYTES_PER_POINT,
                          "stream_probe_gbps": probe_gbps},
         }
+        if grid_path:
+            line["grid_path"] = grid_path
         if allgather:
             line["allgather"] = allgather
         if world == 1 and args.cpu_seconds > 0:

@@ -85,6 +85,10 @@ int sdfk_eval_host(sdfk_program* prog, const void* co, int co_dtype, int64_t n, 
  * Replaces generate_grid + create (cores/helper_functions.py:23-93). Axis tables are HOST pointers. */
 int sdfk_eval_grid(sdfk_program* prog, const float* ax0, int64_t n0, const float* ax1, int64_t n1, const float* ax2,
                    int64_t n2, int64_t start, int64_t count, float* d_out, void* stream, int mode);
+/* Same, field copied back to a HOST buffer in device-sized chunks: the whole generate_grid + create round
+ * trip without a coordinate array on either side. */
+int sdfk_eval_grid_host(sdfk_program* prog, const float* ax0, int64_t n0, const float* ax1, int64_t n1,
+                        const float* ax2, int64_t n2, int64_t start, int64_t count, float* out, int device, int mode);
 void sdfk_set_default_mode(int mode);
 /* Test / diagnostics aid for brick culling: writes one 64-bit skip mask per brick of 128 consecutive
  * points (ceil(n / 2048) * 16 entries; bit 2k = first operand of site k skipped, bit 2k+1 = second operand,

@@ -180,3 +180,26 @@ def test_callable_recognition():
     b.shear(0.1, 0, 0)
     with pytest.raises(ValueError):
         lower_geometry(b)
+
+
+def test_generate_grid_tag_is_only_trusted_while_the_array_cannot_change():
+    import pickle
+    import aegolius_amd
+    from aegolius_amd.cores.helper_functions import GridCoords
+    co, res = ns.generate_grid((2, 2, 2), (8, 8, 8))
+    assert isinstance(co, GridCoords) and isinstance(co, np.ndarray) and co.dtype == np.float64
+    assert not co.flags.writeable and co.grid_axes is not None and [a.size for a in co.grid_axes] == [9, 9, 9]
+    with pytest.raises(ValueError):
+        co[0, 0] = 1.0                                   # read-only: the tag cannot go stale
+    for derived in (co[:, :10], co * 1.0, co.copy(), co.astype(np.float32), co.T, co.reshape(3, 9, 9, 9),
+                    np.asarray(co), pickle.loads(pickle.dumps(co))):
+        assert getattr(derived, "grid_axes", None) is None
+    co.setflags(write=True)                              # opting out drops the trust
+    assert co.grid_axes is None
+    try:
+        aegolius_amd.config.grid_fast_path = False
+        plain, _ = ns.generate_grid((2, 2, 2), (8, 8, 8))
+        assert type(plain) is np.ndarray and plain.flags.writeable
+        np.testing.assert_array_equal(plain, np.asarray(co))
+    finally:
+        aegolius_amd.config.grid_fast_path = True

@@ -270,6 +270,18 @@ def test_sdf_function_called_directly(engine, golden_inputs):
     check("mod_rounding", out, ref)
 
 
+def test_create_on_a_tagged_grid_equals_create_on_the_plain_array(engine):
+    """generate_grid's read-only tagged array takes the table-driven path; a plain copy takes the upload path."""
+    for build, size, res in ((scenes.cfg2_tree, (2, 2, 2), (40, 52, 300)), (scenes.cfg3_chain, (4, 4, 4), (30, 30, 30)),
+                             (scenes.cfg4_scene2d, (10, 10), (300, 500))):
+        co, _ = ns.generate_grid(size, res)
+        assert co.grid_axes is not None
+        fast = build(ns).create(co)
+        slow = build(ns).create(np.array(co))
+        assert fast.dtype == np.float32
+        np.testing.assert_array_equal(fast, slow)
+
+
 def test_output_dtype_option_and_point_cloud(engine, golden_inputs):
     s = ns.Sphere(0.83)                      # no input point within rounding of the surface
     try:
@@ -320,6 +332,10 @@ def test_brick_culling_is_bit_exact(name, engine):
     culled = _device_eval(engine, prog, co32[:, :n], n, stride, 0, engine.MODE_SPECIALIZED)
     plain = _device_eval(engine, prog, co32[:, :n], n, stride, 0, engine.MODE_NOCULL)
     np.testing.assert_array_equal(culled, plain)
+    # the grid flavour of the culling kernel (coordinates expanded from the per-axis tables) agrees as well
+    axes = [a.astype(np.float32) for a in co.grid_axes]
+    for start, count in ((0, n), (12345, 700001)):
+        np.testing.assert_array_equal(prog.eval_grid_host(axes, start, count), plain[start:start + count])
     # and the plain one is right (sampled against the oracle)
     idx = np.random.default_rng(5).choice(n, 4000, replace=False)
     with np.errstate(all="ignore"):
