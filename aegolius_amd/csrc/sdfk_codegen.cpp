@@ -190,7 +190,15 @@ static __device__ __forceinline__ void sdfk_pair(const SrcGrid& s, long long bri
     const unsigned iz0 = (unsigned)(base - row * s.n2);
     const unsigned long long ix0 = row / s.n1;
     const unsigned iy0 = (unsigned)(row - ix0 * s.n1);
-    const unsigned room = (unsigned)(last - bb);               // points of the array after the brick base
+    const long long room64 = last - bb;                        // points of the array after the brick base
+    const unsigned room = room64 > 0x7fffffffLL ? 0x7fffffffu : (unsigned)room64;
+    if (iz0 + SDFK_BRICK <= s.n2 && room >= SDFK_BRICK - 1) {  // the whole brick lies inside one grid row (uniform)
+        const float gx = s.ax0[ix0], gy = s.ax1[iy0];          // scalar loads
+        x = {gx, gx};
+        y = {gy, gy};
+        z = {s.ax2[iz0 + 2 * lane], s.ax2[iz0 + 2 * lane + 1]};
+        return;
+    }
     float px[2], py[2], pz[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
