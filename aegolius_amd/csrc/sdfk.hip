@@ -451,7 +451,10 @@ static int rtc_compile(const std::string& src, std::vector<char>* out, std::stri
     char d_tile[48], d_thr[48];
     snprintf(d_tile, sizeof d_tile, "-DSDFK_TWAVES=%d", tile_waves());
     snprintf(d_thr, sizeof d_thr, "-DSDFK_WBRICKS=%d", tile_wbricks());
-    std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", d_tile, d_thr};
+    // -fno-honor-nans -mno-amdgpu-ieee: v_min/v_max without the canonicalising pre-op (same flags as the
+    // hipcc build of the interpreter kernel, so both flavours stay bit-identical)
+    std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17",
+                                     "-fno-honor-nans", "-mno-amdgpu-ieee", d_tile, d_thr};
     // experiment hook: extra -D switches for the generated source (space separated), e.g. SDFK_RTC_DEFS="-DSDFK_TWAVES=2"
     std::vector<std::string> extra;
     if (const char* e = getenv("SDFK_RTC_DEFS")) {

@@ -25,7 +25,7 @@ def main(scene="tree_cfg2_smooth_union10", kernel="sdfk_spec_v4", outdir="/tmp/i
     with open(src, "w") as f:
         f.write("#include <hip/hip_runtime.h>\n" + prog.source())
     asm = os.path.join(outdir, scene + ".s")
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-S",
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-honor-nans", "-mno-amdgpu-ieee", "-std=c++17", "-S",
                     "--cuda-device-only", "-Wno-unused-command-line-argument", src, "-o", asm], check=True)
     text = open(asm).read()
     body = text[text.index(kernel + ":"):]
