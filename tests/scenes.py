@@ -498,3 +498,118 @@ def _(ns):
     for p in reversed(prims[:-1]):
         acc = ns.CombineGeometry("SMOOTH_UNION2_2").combine_parametric(p, acc, parameters=0.12)
     return acc
+
+
+# -------------------------------------------------------------------------------------------------
+# seeded random trees: compositions nobody thought of (aliasing modes, nested transforms, register reuse)
+# -------------------------------------------------------------------------------------------------
+def _random_leaf(ns, rng):
+    u = lambda a, b: float(rng.uniform(a, b))      # noqa: E731
+    kind = int(rng.integers(0, 12))
+    if kind == 0:
+        return ns.Sphere(u(0.2, 0.6))
+    if kind == 1:
+        return ns.Box(u(0.3, 0.9), u(0.2, 0.7), u(0.2, 0.6))
+    if kind == 2:
+        return ns.Cylinder(u(0.15, 0.4), u(0.3, 1.0))
+    if kind == 3:
+        return ns.Torus(u(0.3, 0.6), u(0.05, 0.15))
+    if kind == 4:
+        return ns.Cone(u(0.4, 0.9), u(0.2, 0.6))
+    if kind == 5:
+        return ns.ChainLink(u(0.2, 0.4), u(0.05, 0.1), u(0.4, 0.9))
+    if kind == 6:
+        return ns.Line((u(-0.6, 0), u(-0.5, 0.5), u(-0.5, 0.5)), (u(0, 0.6), u(-0.5, 0.5), u(-0.5, 0.5)))
+    if kind == 7:
+        c = ns.Circle(u(0.2, 0.5))
+        c.extrusion(u(0.2, 0.8))
+        return c
+    if kind == 8:
+        r = ns.Rectangle(u(0.2, 0.4), u(0.1, 0.3))
+        r.revolution(u(0.3, 0.6))
+        return r
+    if kind == 9:
+        return ns.Plane((u(-1, 1), u(-1, 1), u(0.2, 1)), u(0.05, 0.3))
+    if kind == 10:
+        return ns.InfiniteCylinder(u(0.1, 0.4))
+    return ns.Arc3D(u(0.4, 0.7), u(0.05, 0.15), u(0, 1), u(1.5, 3))
+
+
+def _random_mods(obj, ns, rng):
+    u = lambda a, b: float(rng.uniform(a, b))      # noqa: E731
+    for _ in range(int(rng.integers(0, 4))):
+        m = int(rng.integers(0, 14))
+        if m == 0:
+            obj.rounding(u(0.01, 0.08))
+        elif m == 1:
+            obj.onion(u(0.01, 0.05))
+        elif m == 2:
+            obj.elongation((u(0, 0.4), u(0, 0.3), u(0, 0.2)))
+        elif m == 3:
+            obj.symmetry(int(rng.integers(0, 3)))
+        elif m == 4:
+            obj.twist(u(-1.5, 1.5))
+        elif m == 5:
+            obj.mirror((u(-0.6, -0.1), u(-0.3, 0.3), u(-0.2, 0.2)), (u(0.1, 0.6), u(-0.3, 0.3), u(-0.2, 0.2)))
+        elif m == 6:
+            obj.displacement(ns.sdf_x, (u(-0.2, 0.2),))
+        elif m == 7:
+            obj.scale_sdf(u(0.6, 1.5))
+        elif m == 8:
+            obj.move_sdf((u(-0.3, 0.3), u(-0.3, 0.3), u(-0.3, 0.3)))
+        elif m == 9:
+            obj.concentric(u(0.05, 0.2))
+        elif m == 10:
+            obj.shear_xz(u(-0.4, 0.4))
+        elif m == 11:
+            obj.rounding_cs(u(0.01, 0.05), u(0.8, 1.5))
+        elif m == 12:
+            other = ns.Sphere(u(0.3, 0.7))
+            obj.displacement(other.propagate, ())
+        else:
+            obj.invert()
+            obj.invert()
+    return obj
+
+
+def _random_place(obj, rng):
+    u = lambda a, b: float(rng.uniform(a, b))      # noqa: E731
+    t = int(rng.integers(0, 5))
+    if t >= 1:
+        obj.move((u(-0.6, 0.6), u(-0.6, 0.6), u(-0.6, 0.6)))
+    if t >= 2:
+        obj.rotate(u(0, np.pi), rng.normal(0, 1, 3))
+    if t == 4:
+        obj.set_scale(u(0.6, 1.6))
+    return obj
+
+
+_RANDOM_BINARY = ["UNION2", "SUBTRACT2", "INTERSECT2", "SUM", "DIFFERENCE"]
+_RANDOM_PARAMETRIC = ["SMOOTH_UNION2_2", "SMOOTH_UNION2", "SMOOTH_INTERSECT2", "SMOOTH_SUBTRACT2",
+                      "SMOOTH_INTERSECT2_BOLTZMANN"]
+
+
+def _random_tree(ns, rng, depth):
+    if depth == 0 or rng.uniform() < 0.25:
+        return _random_place(_random_mods(_random_leaf(ns, rng), ns, rng), rng)
+    c = int(rng.integers(0, 3))
+    if c == 0:
+        kids = [_random_tree(ns, rng, depth - 1) for _ in range(int(rng.integers(2, 5)))]
+        node = ns.CombineGeometry(["UNION", "INTERSECT"][int(rng.integers(0, 2))]).combine(*kids)
+    elif c == 1:
+        node = ns.CombineGeometry(_RANDOM_BINARY[int(rng.integers(0, len(_RANDOM_BINARY)))]).combine(
+            _random_tree(ns, rng, depth - 1), _random_tree(ns, rng, depth - 1))
+    else:
+        node = ns.CombineGeometry(_RANDOM_PARAMETRIC[int(rng.integers(0, len(_RANDOM_PARAMETRIC)))]).combine_parametric(
+            _random_tree(ns, rng, depth - 1), _random_tree(ns, rng, depth - 1), parameters=float(rng.uniform(0.05, 0.3)))
+    if rng.uniform() < 0.4:
+        node = ns.GenericGeometry(node.propagate, ())          # freeze, then modify the frozen node
+    return _random_place(_random_mods(node, ns, rng), rng)
+
+
+def random_tree(ns, seed, depth=3):
+    return _random_tree(ns, np.random.default_rng(seed), depth)
+
+
+for _seed in range(48):
+    scene("random_tree_%02d" % _seed, True)(lambda ns, s=_seed: random_tree(ns, 1000 + s))
