@@ -63,6 +63,8 @@ class Lowerer:
         self.lip_c = {0: 1.0}      # Lipschitz bound of each register w.r.t. the root point (_lipschitz.py)
         self.lip_v = {}
         self.cull = []             # (combiner index, a_start, a_end, b_start, b_end, K)
+        self._fold_floor = 0       # instructions below this index are never merged into (range boundaries)
+        self._affine = {}          # instruction index -> (A (3,3), c (3,)) of an affine coordinate op, float64
 
     # ---- registers ----
     def new_c(self):
@@ -92,11 +94,50 @@ class Lowerer:
         self._v_used.discard(i)
 
     # ---- emission ----
-    def emit(self, opname, a, b=0, c=0, params=()):
+    _AFFINE = ("XFORM", "XLATE", "LIN3", "CSCALE")
+
+    @staticmethod
+    def _as_affine(opname, p):
+        """q = A p - c of the affine coordinate ops (float64)."""
+        p = np.asarray(p, dtype=np.float64)
+        if opname == "XFORM":
+            return p[:9].reshape(3, 3), p[9:12].copy()
+        if opname == "XLATE":
+            return np.eye(3), p[:3].copy()
+        if opname == "LIN3":
+            return p[:9].reshape(3, 3), np.zeros(3)
+        return np.eye(3) * p[0], np.zeros(3)      # CSCALE
+
+    def _emit_affine(self, a, b, A, c):
+        if np.array_equal(A, np.eye(3)):
+            name, prm = "XLATE", c
+        else:
+            name, prm = "XFORM", np.concatenate([A.ravel(), c])
+        self._affine[len(self.code)] = (A, c)
+        self.emit(name, a, b, params=prm, _fold=False)
+
+    def emit(self, opname, a, b=0, c=0, params=(), _fold=True):
         info = _ops.BY_NAME[opname]
         params = [float(x) for x in np.asarray(params, dtype=np.float64).ravel()]
         if len(params) != info.nparams:
             raise LoweringError("%s expects %d parameters, got %d" % (opname, info.nparams, len(params)))
+        if _fold and opname in self._AFFINE:
+            # Consecutive affine maps on the same register (nested Euclidean transforms, move_sdf / scale_sdf /
+            # shear chains) are composed here in float64 and rounded ONCE: g(f(p)) = A2 A1 p - (A2 c1 + c2).
+            # Only the in-place continuation `C[a] = g(C[a])` right after `C[a] = f(C[b])` is merged: the
+            # intermediate value is overwritten anyway, so nothing else can have read it.
+            A2, c2 = self._as_affine(opname, params)
+            last = len(self.code) - 1
+            if a == b and last >= self._fold_floor and last in self._affine:
+                lw, lpoff = self.code[last]
+                if (lw >> 8) & 255 == a and all(np.isfinite(A2.ravel())) and all(np.isfinite(c2)):
+                    A1, c1 = self._affine.pop(last)
+                    src = (lw >> 16) & 255
+                    self.code.pop()
+                    del self.params[lpoff:]
+                    self._emit_affine(a, src, A2.dot(A1), A2.dot(c1) + c2)
+                    return
+            self._affine[len(self.code)] = (A2, c2)
         poff = len(self.params)
         self.params.extend(params)
         self.code.append((info.code | (a << 8) | (b << 16) | (c << 24), poff))
@@ -230,6 +271,7 @@ class Lowerer:
         for i, kid in enumerate(kids):
             last = (i == len(kids) - 1)
             b_start = len(self.code)
+            self._fold_floor = b_start                     # never merge across an operand-range boundary
             v = self.lower_node(kid, creg, OWNED if (last and mode == OWNED) else FROZEN)
             if acc is None:
                 acc = v

@@ -34,6 +34,33 @@ def evaluate(node, co):
     return eval_node(node, co)
 
 
+_MAGNITUDE = None      # per-point running max of |intermediate|, only inside evaluate_with_magnitude
+
+
+def _note(values):
+    if _MAGNITUDE is not None:
+        v = np.abs(np.asarray(values, dtype=np.float64))
+        if v.ndim == 2:
+            v = v.max(axis=0)
+        if v.shape == _MAGNITUDE.shape:
+            np.maximum(_MAGNITUDE, np.where(np.isfinite(v), v, 0.0), out=_MAGNITUDE)
+
+
+def evaluate_with_magnitude(node, co):
+    """(field, magnitude): `magnitude[i]` is the largest absolute value among the node-local coordinates
+    and the node / operand fields met while evaluating point i — the scale against which a rounding
+    error of an fp32 evaluation of the same tree has to be judged when the tree adds and subtracts
+    fields (SUM, DIFFERENCE, displacement), where the result can be far smaller than its operands."""
+    global _MAGNITUDE
+    co = np.asarray(co, dtype=np.float64)
+    _MAGNITUDE = np.zeros(co.shape[1])
+    try:
+        field = eval_node(node, co)
+        return field, _MAGNITUDE
+    finally:
+        _MAGNITUDE = None
+
+
 def eval_node(node, co):
     # C/transformations.py:232-242
     rm = np.asarray(node.rotation_matrix, dtype=np.float64).T
@@ -41,7 +68,10 @@ def eval_node(node, co):
     c = rm.dot(co)
     c = c / sm
     c = np.subtract(c.T, rm.dot(np.asarray(node.center, dtype=np.float64))).T
-    return sm * eval_expr(node.modified_object, c, node._geo_parameters)
+    _note(c)
+    out = sm * eval_expr(node.modified_object, c, node._geo_parameters)
+    _note(out)
+    return out
 
 
 def eval_expr(expr, co, params):

@@ -40,6 +40,15 @@ def main():
         if len(outs) == 2:
             same = np.array_equal(outs[0], outs[1], equal_nan=True)
             row.append("interp==spec" if same else "INTERP!=SPEC (%d)" % int((outs[0] != outs[1]).sum()))
+        if name.startswith("random_tree_") and outs:
+            from oracle import sdf_oracle
+            _, mag = sdf_oracle.evaluate_with_magnitude(build(ns), co)
+            e = np.abs(outs[-1] - ref)
+            e2 = e / np.maximum(np.maximum(1.0, np.abs(ref)), mag)
+            row.append("scaled max %.2e bad %d (magnitude max %.1f)" % (np.nanmax(e2), int((~(e2 <= 1e-6)).sum()),
+                                                                       mag.max()))
+            for i in np.argsort(-e / np.maximum(1.0, np.abs(ref)))[:3]:
+                row.append("[ref %.4f err %.2e mag %.2f]" % (ref[i], e[i], mag[i]))
         print("%-42s %s" % (row[0], " | ".join(row[1:])), flush=True)
     print("total %.1fs" % (time.time() - t0))
 
