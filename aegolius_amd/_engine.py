@@ -30,6 +30,8 @@ SIGNATURES = {
     "sdfk_program_source": (_c.c_char_p, [_vp]),
     "sdfk_program_compile_check": (_int, [_vp, _c.POINTER(_sz)]),
     "sdfk_eval_device": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _int]),
+    "sdfk_eval_device_rows": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int]),
+    "sdfk_debug_row_masks": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _c.POINTER(_i64), _c.POINTER(_int), _vp]),
     "sdfk_eval_host": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _int, _int]),
     "sdfk_eval_grid": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _int]),
     "sdfk_eval_grid_host": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _int, _int]),
@@ -161,8 +163,14 @@ class Program:
                                    mode), "sdfk_eval_host")
         return out
 
-    def eval_device(self, d_co, n, row_stride, d_out, stream=None, mode=MODE_AUTO):
-        """Device pointers (ints). Asynchronous on `stream` (a hipStream_t as int, None = default)."""
+    def eval_device(self, d_co, n, row_stride, d_out, stream=None, mode=MODE_AUTO, row_len=None):
+        """Device pointers (ints). Asynchronous on `stream` (a hipStream_t as int, None = default).
+        `row_len`: layout hint — the points are consecutive rows of that many points (the last grid
+        dimension of a generate_grid array); speeds up brick culling, never changes the field."""
+        if row_len:
+            check(lib().sdfk_eval_device_rows(self._h, _vp(d_co), n, row_stride, int(row_len), _vp(d_out),
+                                              _vp(stream or 0), mode), "sdfk_eval_device_rows")
+            return
         check(lib().sdfk_eval_device(self._h, _vp(d_co), n, row_stride, _vp(d_out), _vp(stream or 0), mode),
               "sdfk_eval_device")
 

@@ -59,7 +59,7 @@ V_VV = {
 }
 # combiners at which a whole operand subtree can be skipped
 CULLABLE = ("VMIN", "VMAX", "VSUBTRACT", "SMIN2", "SMIN3", "SMAX3", "SSUB3")
-MAX_SITES = 31     # two mask bits per site; bit 63 of the brick mask flags an x/y-constant run
+MAX_SITES = 64     # two mask bits per site in two 64-bit words (the flat tile kernel uses the 31 widest)
 
 
 def factor(table, name, params):

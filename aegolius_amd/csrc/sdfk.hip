@@ -150,7 +150,8 @@ struct DevState {
 
 struct SpecKernel {
     hipModule_t mod = nullptr;
-    hipFunction_t v4 = nullptr, v1 = nullptr, g4 = nullptr, g1 = nullptr, tile = nullptr, tile_grid = nullptr, tmask = nullptr;
+    hipFunction_t v4 = nullptr, v1 = nullptr, g4 = nullptr, g1 = nullptr, tile = nullptr, tile_grid = nullptr, tmask = nullptr, rows = nullptr,
+                  rows_grid = nullptr, rmask = nullptr;
     bool failed = false;
     std::string error;
 };
@@ -382,7 +383,7 @@ static bool is_cullable_op(unsigned op) {
 
 extern "C" int sdfk_program_set_cull(sdfk_program* p, const uint32_t* rows, size_t n_sites, const float* k) {
     if (!p) return fail(-1, "null program");
-    if (n_sites > 31) return fail(-2, "sdfk_program_set_cull: at most 31 sites");
+    if (n_sites > 64) return fail(-2, "sdfk_program_set_cull: at most 64 sites");
     if (n_sites && (!rows || !k)) return fail(-1, "sdfk_program_set_cull: null arrays");
     std::lock_guard<std::mutex> lk(p->mu);
     if (!p->source.empty() || !p->dev.empty())
@@ -441,6 +442,37 @@ static int tile_wbricks() {
     return v;
 }
 static int tile_points() { return tile_waves() * tile_wbricks() * 128; }
+// row-block kernel: SDFK_NP packed pairs per lane (brick = 32 points x 4*NP rows), SDFK_RWBRICKS bricks per wave
+static int rows_np() {
+    static int v = [] { const char* e = getenv("SDFK_NP"); int t = e ? atoi(e) : 4; return (t == 2 || t == 4) ? t : 4; }();
+    return v;
+}
+static int rows_wbricks() {
+    static int v = [] { const char* e = getenv("SDFK_RWBRICKS"); int t = e ? atoi(e) : 2; return (t >= 1 && t <= 16) ? t : 2; }();
+    return v;
+}
+struct RowGeom {           // mirrors sdfk_rowgeom of the generated source
+    unsigned L, nchunk, nbricks;
+    long long R;
+    long long row0;
+    int yrows;
+};
+// can the row-block kernel take n points in rows of row_len? (brick ids are 32-bit)
+static bool rows_geometry(long long n, long long row_len, RowGeom* g) {
+    if (row_len < 32 || row_len > 0x7fffffffLL || n <= 0 || n % row_len != 0) return false;
+    const long long R = n / row_len, brows = 4 * rows_np();
+    // windows of 32 points aligned in the flat array: one more than ceil(L / 32) can overlap a row
+    const long long nchunk = (row_len % 32 == 0) ? row_len / 32 : (row_len + 62) / 32;
+    const long long nb = nchunk * ((R + brows - 1) / brows);
+    if (nb > 0x7fffffffLL - 1024) return false;
+    g->L = (unsigned)row_len;
+    g->nchunk = (unsigned)nchunk;
+    g->nbricks = (unsigned)nb;
+    g->R = R;
+    g->row0 = 0;
+    g->yrows = 0;
+    return true;
+}
 static int tile_threads() { return 64 * tile_waves(); }
 static int rtc_compile(const std::string& src, std::vector<char>* out, std::string* log) {
     hiprtcProgram prog;
@@ -448,13 +480,15 @@ static int rtc_compile(const std::string& src, std::vector<char>* out, std::stri
         *log = "hiprtcCreateProgram failed";
         return -1;
     }
-    char d_tile[48], d_thr[48];
+    char d_tile[48], d_thr[48], d_np[48], d_rwb[48];
     snprintf(d_tile, sizeof d_tile, "-DSDFK_TWAVES=%d", tile_waves());
     snprintf(d_thr, sizeof d_thr, "-DSDFK_WBRICKS=%d", tile_wbricks());
+    snprintf(d_np, sizeof d_np, "-DSDFK_NP=%d", rows_np());
+    snprintf(d_rwb, sizeof d_rwb, "-DSDFK_RWBRICKS=%d", rows_wbricks());
     // -fno-honor-nans -mno-amdgpu-ieee: v_min/v_max without the canonicalising pre-op (same flags as the
     // hipcc build of the interpreter kernel, so both flavours stay bit-identical)
     std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17",
-                                     "-fno-honor-nans", "-mno-amdgpu-ieee", d_tile, d_thr};
+                                     "-fno-honor-nans", "-mno-amdgpu-ieee", d_tile, d_thr, d_np, d_rwb};
     // experiment hook: extra -D switches for the generated source (space separated), e.g. SDFK_RTC_DEFS="-DSDFK_TWAVES=2"
     std::vector<std::string> extra;
     if (const char* e = getenv("SDFK_RTC_DEFS")) {
@@ -521,6 +555,9 @@ static std::shared_ptr<SpecKernel> get_spec(sdfk_program* p, int device) {
     if (e == hipSuccess && !p->sites.empty()) e = hipModuleGetFunction(&sk->tile, sk->mod, "sdfk_spec_t");
     if (e == hipSuccess && !p->sites.empty()) e = hipModuleGetFunction(&sk->tmask, sk->mod, "sdfk_spec_tmask");
     if (e == hipSuccess && !p->sites.empty()) e = hipModuleGetFunction(&sk->tile_grid, sk->mod, "sdfk_spec_tg");
+    if (e == hipSuccess && !p->sites.empty()) e = hipModuleGetFunction(&sk->rows, sk->mod, "sdfk_spec_r");
+    if (e == hipSuccess && !p->sites.empty()) e = hipModuleGetFunction(&sk->rows_grid, sk->mod, "sdfk_spec_rg");
+    if (e == hipSuccess && !p->sites.empty()) e = hipModuleGetFunction(&sk->rmask, sk->mod, "sdfk_spec_rmask");
     if (e != hipSuccess) {
         sk->failed = true;
         sk->error = std::string("hipModuleLoadData/GetFunction: ") + hipGetErrorString(e);
@@ -555,7 +592,7 @@ static inline unsigned blocks_for(long long n, int vec) {
 }
 
 static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long long n, float* d_out, void* stream_,
-               int mode, bool vec_ok) {
+               int mode, bool vec_ok, long long row_len = 0) {
     if (!p) return fail(-1, "null program");
     if (n < 0) return fail(-1, "negative point count");
     if (n == 0) return 0;
@@ -592,6 +629,17 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
     const float* prm = d->d_params;
     const float* tab = d->d_tables;
     if (sk) {
+        RowGeom rg;
+        if (arr && sk->rows && mode != SDFK_MODE_NOCULL && rows_geometry(n, row_len, &rg)) {
+            // row-block culling kernel: rows need no alignment beyond 4 bytes
+            const float* co = arr->co;
+            long long stride = arr->stride;
+            void* args[] = {&prm, &tab, &co, &stride, &rg, &d_out};
+            const unsigned per_tile = (unsigned)(tile_waves() * rows_wbricks());
+            const unsigned tiles = (rg.nbricks + per_tile - 1) / per_tile;
+            HIPCHK(hipModuleLaunchKernel(sk->rows, tiles, 1, 1, tile_threads(), 1, 1, 0, stream, args, nullptr));
+            return 0;
+        }
         if (arr && sk->tile && vec_ok && mode != SDFK_MODE_NOCULL) {
             // brick-culling tile kernel: handles the ragged end itself
             const float* co = arr->co;
@@ -599,6 +647,19 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
             void* args[] = {&prm, &tab, &co, &stride, &n, &d_out};
             const unsigned tiles = (unsigned)((n + tile_points() - 1) / tile_points());
             HIPCHK(hipModuleLaunchKernel(sk->tile, tiles, 1, 1, tile_threads(), 1, 1, 0, stream, args, nullptr));
+            return 0;
+        }
+        // rows of the grid: along the third axis, or along the second one when the grid is flat (n2 == 1)
+        const long long grow = grid ? (grid->n2 > 1 ? (long long)grid->n2 : (long long)grid->n1) : 0;
+        if (grid && sk->rows_grid && mode != SDFK_MODE_NOCULL && grid->start % grow == 0 && rows_geometry(n, grow, &rg)) {
+            // whole grid rows (x-slabs of a sharded evaluation always are): row-block culling kernel
+            SrcGrid g = *grid;
+            rg.row0 = grid->start / grow;
+            rg.yrows = grid->n2 > 1 ? 0 : 1;
+            void* args[] = {&prm, &tab, &g, &rg, &d_out};
+            const unsigned per_tile = (unsigned)(tile_waves() * rows_wbricks());
+            const unsigned tiles = (rg.nbricks + per_tile - 1) / per_tile;
+            HIPCHK(hipModuleLaunchKernel(sk->rows_grid, tiles, 1, 1, tile_threads(), 1, 1, 0, stream, args, nullptr));
             return 0;
         }
         if (grid && sk->tile_grid && vec_ok && mode != SDFK_MODE_NOCULL) {
@@ -671,6 +732,45 @@ extern "C" int sdfk_eval_device(sdfk_program* p, const float* d_co, int64_t n, i
     SrcArray a = {d_co, (long long)row_stride};
     bool vec_ok = aligned16(d_co) && aligned16(d_out) && (row_stride % 4 == 0);
     return run(p, &a, nullptr, n, d_out, stream, mode, vec_ok);
+}
+
+extern "C" int sdfk_eval_device_rows(sdfk_program* p, const float* d_co, int64_t n, int64_t row_stride, int64_t row_len,
+                                     float* d_out, void* stream, int mode) {
+    if (!d_co || !d_out) return fail(-1, "sdfk_eval_device_rows: null device pointer");
+    if (row_stride < n) return fail(-1, "sdfk_eval_device_rows: row stride smaller than the point count");
+    if (row_len < 1 || (n > 0 && n % row_len != 0))
+        return fail(-1, "sdfk_eval_device_rows: the point count is not a multiple of the row length");
+    SrcArray a = {d_co, (long long)row_stride};
+    bool vec_ok = aligned16(d_co) && aligned16(d_out) && (row_stride % 4 == 0);
+    return run(p, &a, nullptr, n, d_out, stream, mode, vec_ok, row_len);
+}
+
+extern "C" int sdfk_debug_row_masks(sdfk_program* p, const float* d_co, int64_t n, int64_t row_stride, int64_t row_len,
+                                    uint64_t* d_masks, int64_t* n_bricks, int* brick_rows, void* stream_) {
+    if (!p || !d_co) return fail(-1, "sdfk_debug_row_masks: null argument");
+    if (p->sites.empty()) return fail(-2, "sdfk_debug_row_masks: program has no cull sites");
+    RowGeom rg;
+    if (row_stride < n || !rows_geometry(n, row_len, &rg))
+        return fail(-1, "sdfk_debug_row_masks: the row-block kernel does not take this shape");
+    if (n_bricks) *n_bricks = rg.nbricks;
+    if (brick_rows) *brick_rows = 4 * rows_np();
+    if (!d_masks) return 0;                      // size query
+    hipStream_t stream = (hipStream_t)stream_;
+    int device = 0;
+    HIPCHK(hipGetDevice(&device));
+    DevState* d = nullptr;
+    int rc = ensure_resident(p, device, stream, &d);
+    if (rc) return rc;
+    std::shared_ptr<SpecKernel> sk = get_spec(p, device);
+    if (sk->failed || !sk->rmask) return fail(-3, "specialised kernel unavailable: " + sk->error);
+    const float* prm = d->d_params;
+    const float* tab = d->d_tables;
+    long long stride = row_stride;
+    void* args[] = {&prm, &tab, &d_co, &stride, &rg, &d_masks};
+    const unsigned per_tile = (unsigned)(tile_waves() * rows_wbricks());
+    HIPCHK(hipModuleLaunchKernel(sk->rmask, (rg.nbricks + per_tile - 1) / per_tile, 1, 1, tile_threads(), 1, 1, 0, stream,
+                                 args, nullptr));
+    return 0;
 }
 
 extern "C" int sdfk_debug_brick_masks(sdfk_program* p, const float* d_co, int64_t n, int64_t row_stride,
@@ -765,7 +865,9 @@ extern "C" int sdfk_eval_grid_host(sdfk_program* p, const float* ax0, int64_t n0
     if (start < 0 || start + count > n0 * n1 * n2) return fail(-1, "sdfk_eval_grid_host: range outside the grid");
     if (count == 0) return 0;
     HIPCHK(hipSetDevice(device));
-    const int64_t chunk = std::min<int64_t>(count, (int64_t)1 << 27);   // 128 Mi points = 512 MiB of device memory
+    int64_t chunk = std::min<int64_t>(count, (int64_t)1 << 27);   // 128 Mi points = 512 MiB of device memory
+    const int64_t grow = n2 > 1 ? n2 : n1;                         // whole grid rows per chunk (row-block kernel)
+    if (start % grow == 0 && chunk > grow) chunk = chunk / grow * grow;
     float* d_out = nullptr;
     HIPCHK(hipMalloc(&d_out, (size_t)chunk * sizeof(float)));
     AxisTables t;

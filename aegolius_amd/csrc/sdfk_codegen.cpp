@@ -340,6 +340,284 @@ extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_tmask(
 }
 )SDFKT";
 
+
+// Row-block culling kernel (only emitted when the program has cull sites). The caller states that the
+// points come as consecutive ROWS of L points (the last axis of a generate_grid meshgrid; any L dividing
+// n is valid). A brick = SDFK_RZ (32) consecutive points of SDFK_RROWS (16) consecutive rows: on a
+// regular grid a 32 x 16 x 1 block whose bounding sphere is 4x smaller than that of 128 points in a line,
+// so far fewer subtrees survive the probe. Everything is still derived from the coordinates actually
+// read — a wrong or meaningless L costs speed, never correctness.
+//   phase A  8 rows x 32 points per load instruction (rows need only 4-byte alignment); bounding sphere
+//            around the midpoint of the first and last point; "uniform" = every row has one x and one y
+//   phase B  one lane per brick evaluates the whole tree at the centre -> skip mask (up to 64 sites)
+//   phase C  a lane owns 2*SDFK_NP consecutive points of ONE row: on uniform bricks the x/y part of every
+//            root transform is computed once per lane (op_xform_base) and shared by its points; control
+//            flow, parameter loads and branches are shared by SDFK_NP packed pairs per lane
+static const char kRowsKernel[] = R"SDFKR(
+#ifndef SDFK_RWBRICKS
+#define SDFK_RWBRICKS 2
+#endif
+#define SDFK_RZ 32
+#define SDFK_RLPR (SDFK_RZ / (2 * SDFK_NP))     // lanes per row in phase C
+#define SDFK_RROWS (64 / SDFK_RLPR)             // rows per brick
+#define SDFK_RBRICK (SDFK_RZ * SDFK_RROWS)
+#define SDFK_RLOADS (SDFK_RROWS / 8)            // load instructions per array and brick
+#define SDFK_RNBRICK (SDFK_TWAVES * SDFK_RWBRICKS)
+static_assert(SDFK_NP == 2 || SDFK_NP == 4, "2 or 4 packed pairs per lane");
+static_assert(SDFK_RNBRICK <= 64 * SDFK_TWAVES, "one probe lane per brick");
+
+typedef float sdfk_f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+struct sdfk_rowmeta {
+    float z[SDFK_RNBRICK][SDFK_RBRICK];         // [row of the brick][point of the window]
+    float2 xy[SDFK_RNBRICK][SDFK_RROWS];
+    float4 bound[SDFK_RNBRICK];
+    unsigned long long mask0[SDFK_RNBRICK], mask1[SDFK_RNBRICK];
+    unsigned uniform[SDFK_RNBRICK];
+};
+struct sdfk_rowgeom {
+    unsigned L, nchunk, nbricks;                // row length, windows per row, bricks in total
+    long long R;                                // rows
+    long long row0;                             // grid flavour: global row index of the first row of the slab
+    int yrows;                                  // grid flavour, 2-D grid (n2 == 1): rows run along the second axis
+};
+
+// Rows are cut into WINDOWS of 32 points that are aligned in the flat array (128-byte lines when the array is):
+// window k of a row starts at flat index 32 * (floor(row * L / 32) + k), i.e. up to 31 points before the row
+// when L is no multiple of 32. Misaligned 128-byte segments cost 20-35 % of the streaming rate on MI355X
+// (tools/rowstream.hip), whole lines cost nothing. Elements outside the row are replaced by the nearest point
+// of the row (duplicates keep bounds and the uniformity test valid) and never stored; that only happens in the
+// first and the last windows of a row ("edge" chunks, wave-uniform).
+static __device__ __forceinline__ bool sdfk_interior(unsigned L, unsigned k) {      // wave-uniform
+    return (L & 31u) == 0u || (k >= 1u && 32u * k + 32u <= L);
+}
+static __device__ __forceinline__ float4 sdfk_win_quad(const float* __restrict__ rowp, int z, int last, bool interior) {
+    if (interior) {
+        const sdfk_f4u v = *reinterpret_cast<const sdfk_f4u*>(rowp + z);
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return make_float4(rowp[min(max(z, 0), last)], rowp[min(max(z + 1, 0), last)], rowp[min(max(z + 2, 0), last)],
+                       rowp[min(max(z + 3, 0), last)]);
+}
+// the 4 points [z, z+4) of row `row` (row = r0 + dr, r0 wave-uniform) as three quads
+static __device__ __forceinline__ void sdfk_rows_fetch(const SrcArray& s, const sdfk_rowgeom& g, long long r0, int dr, int z,
+                                                       bool interior, float4& X, float4& Y, float4& Z) {
+    const float* p = s.co + (r0 + dr) * (long long)g.L;
+    const int last = (int)g.L - 1;
+    X = sdfk_win_quad(p, z, last, interior);
+    Y = sdfk_win_quad(p + s.stride, z, last, interior);
+    Z = sdfk_win_quad(p + 2 * s.stride, z, last, interior);
+}
+// regular grid: row -> (ix, iy) with one wave-uniform division per brick; z from the third axis table
+static __device__ __forceinline__ void sdfk_rows_fetch(const SrcGrid& s, const sdfk_rowgeom& g, long long r0, int dr, int z,
+                                                       bool interior, float4& X, float4& Y, float4& Z) {
+    const unsigned long long g0 = (unsigned long long)(g.row0 + r0);
+    if (g.yrows) {                                                 // (x, y, z) = (ax0[row], ax1[point], ax2[0])
+        const float x = s.ax0[g0 + (unsigned)dr], zc = s.ax2[0];
+        X = make_float4(x, x, x, x);
+        Y = sdfk_win_quad(s.ax1, z, (int)g.L - 1, interior);
+        Z = make_float4(zc, zc, zc, zc);
+        return;
+    }
+    unsigned long long ix = g0 / s.n1;
+    unsigned iy = (unsigned)(g0 - ix * s.n1) + (unsigned)dr;
+    while (iy >= s.n1) { iy -= s.n1; ++ix; }
+    const float x = s.ax0[ix], y = s.ax1[iy];
+    X = make_float4(x, x, x, x);
+    Y = make_float4(y, y, y, y);
+    Z = sdfk_win_quad(s.ax2, z, (int)g.L - 1, interior);
+}
+static __device__ __forceinline__ float sdfk_prev_lane(float v) {   // value of lane-1 within a row of 16 lanes
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
+}
+// point index (in its row) of the first point of window k of local row `row`, plus e0
+static __device__ __forceinline__ int sdfk_win_z(long long row, unsigned L, unsigned k, int e0, long long* flat) {
+    const long long rl = row * (long long)L;
+    const long long f = (((rl >> 5) + k) << 5) + e0;
+    *flat = f;
+    return (int)(f - rl);
+}
+
+// phase A, part 1: issue the loads of one brick (wave-uniform r0, k); 8 rows x 32 points per instruction
+struct sdfk_rowregs {
+    float4 X[SDFK_RLOADS], Y[SDFK_RLOADS], Z[SDFK_RLOADS];
+};
+template <typename SRC>
+static __device__ __forceinline__ void sdfk_rows_load(const SRC& s, const sdfk_rowgeom& g, long long r0, unsigned k, int lane,
+                                                      sdfk_rowregs& r) {
+    const bool interior = sdfk_interior(g.L, k);
+#pragma unroll
+    for (int t = 0; t < SDFK_RLOADS; ++t) {
+        int dr = 8 * t + (lane >> 3);
+        if (r0 + dr >= g.R) dr = (int)(g.R - 1 - r0);
+        long long flat;
+        const int z = sdfk_win_z(r0 + dr, g.L, k, 4 * (lane & 7), &flat);
+        sdfk_rows_fetch(s, g, r0, dr, z, interior, r.X[t], r.Y[t], r.Z[t]);
+    }
+}
+// phase A, part 2: z and the row heads to LDS, "every row has one x and one y", bounding sphere
+static __device__ __forceinline__ void sdfk_rows_bounds(const sdfk_rowregs& r, int lane, sdfk_rowmeta* meta, int b) {
+    bool uni = true;
+#pragma unroll
+    for (int t = 0; t < SDFK_RLOADS; ++t) {
+        *reinterpret_cast<float4*>(&meta->z[b][(8 * t + (lane >> 3)) * SDFK_RZ + 4 * (lane & 7)]) = r.Z[t];
+        const float px = sdfk_prev_lane(r.X[t].x), py = sdfk_prev_lane(r.Y[t].x);
+        const bool head = (lane & 7) == 0;
+        uni = uni && r.X[t].x == r.X[t].y && r.X[t].x == r.X[t].z && r.X[t].x == r.X[t].w && r.Y[t].x == r.Y[t].y &&
+              r.Y[t].x == r.Y[t].z && r.Y[t].x == r.Y[t].w && (head || (px == r.X[t].x && py == r.Y[t].x));
+        if (head) meta->xy[b][8 * t + (lane >> 3)] = make_float2(r.X[t].x, r.Y[t].x);
+    }
+    const bool uniform = __ballot(uni) == ~0ull;
+    const float cx = 0.5f * (sdfk_lane(r.X[0].x, 0) + sdfk_lane(r.X[SDFK_RLOADS - 1].w, 63));
+    const float cy = 0.5f * (sdfk_lane(r.Y[0].x, 0) + sdfk_lane(r.Y[SDFK_RLOADS - 1].w, 63));
+    const float cz = 0.5f * (sdfk_lane(r.Z[0].x, 0) + sdfk_lane(r.Z[SDFK_RLOADS - 1].w, 63));
+    float d2 = 0.0f;
+#pragma unroll
+    for (int t = 0; t < SDFK_RLOADS; ++t) {
+        const f2 xa = {r.X[t].x, r.X[t].y}, xb = {r.X[t].z, r.X[t].w}, ya = {r.Y[t].x, r.Y[t].y}, yb = {r.Y[t].z, r.Y[t].w};
+        const f2 za = {r.Z[t].x, r.Z[t].y}, zb = {r.Z[t].z, r.Z[t].w};
+        const f2 ax = xa - cx, ay = ya - cy, az = za - cz, bx = xb - cx, by = yb - cy, bz = zb - cz;
+        const f2 da = sd_fma(ax, ax, sd_fma(ay, ay, az * az)), db = sd_fma(bx, bx, sd_fma(by, by, bz * bz));
+        d2 = sd_rawmax(d2, sd_rawmax(sd_rawmax(da.x, da.y), sd_rawmax(db.x, db.y)));
+    }
+    const float r2 = sdfk_wave_max(d2);
+    if (lane == 0) {
+        meta->bound[b] = make_float4(cx, cy, cz, 1.00001f * sqrtf(r2) + 1e-30f);
+        meta->uniform[b] = uniform ? 1u : 0u;
+    }
+}
+
+// phases A and B of the tile of this workgroup; returns this wave's first brick (row block, window)
+template <typename SRC>
+static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict__ PRM, const float* __restrict__ TAB,
+                                                         const SRC& s, const sdfk_rowgeom& g, sdfk_rowmeta* meta,
+                                                         unsigned& rb0, unsigned& c0) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned q0 = blockIdx.x * SDFK_RNBRICK + wave * SDFK_RWBRICKS;      // first brick of this wave
+    rb0 = q0 / g.nchunk;
+    c0 = q0 - rb0 * g.nchunk;
+    unsigned rb = rb0, c = c0;
+    // (hoisting all loads of the wave ahead of the first use was measured slower: registers, not memory-level
+    // parallelism, limit this phase)
+#pragma unroll
+    for (int j = 0; j < SDFK_RWBRICKS; ++j) {
+        if (q0 + j < g.nbricks) {
+            sdfk_rowregs regs;
+            sdfk_rows_load(s, g, (long long)rb * SDFK_RROWS, c, lane, regs);
+            sdfk_rows_bounds(regs, lane, meta, wave * SDFK_RWBRICKS + j);
+        }
+        if (++c == g.nchunk) { c = 0; ++rb; }
+    }
+    __syncthreads();
+    if (threadIdx.x < SDFK_RNBRICK && blockIdx.x * SDFK_RNBRICK + threadIdx.x < g.nbricks) {
+        const float4 bb = meta->bound[threadIdx.x];
+        V3T<float> ctr = {bb.x, bb.y, bb.z};
+        unsigned long long m0 = 0ull, m1 = 0ull;
+#ifndef SDFK_ABLATE_PROBE
+        sdfk_probe_r(ctr, bb.w, PRM, TAB, m0, m1);
+#endif
+        meta->mask0[threadIdx.x] = m0;
+        meta->mask1[threadIdx.x] = m1;
+    }
+    __syncthreads();
+}
+
+template <typename SRC>
+static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict__ PRM, const float* __restrict__ TAB,
+                                                        const SRC& s, const sdfk_rowgeom& g, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) sdfk_rowmeta meta;
+    unsigned rb, c;
+    sdfk_rows_prepare(PRM, TAB, s, g, &meta, rb, c);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned q0 = blockIdx.x * SDFK_RNBRICK + wave * SDFK_RWBRICKS;
+    const int lr = lane / SDFK_RLPR;
+    const int zq = (lane % SDFK_RLPR) * (2 * SDFK_NP);
+#pragma unroll 1
+    for (int j = 0; j < SDFK_RWBRICKS; ++j) {
+        if (q0 + j >= g.nbricks) break;
+        const int b = wave * SDFK_RWBRICKS + j;
+        const unsigned k = c;
+        const long long r0 = (long long)rb * SDFK_RROWS;
+        if (++c == g.nchunk) { c = 0; ++rb; }
+        const unsigned long long m0 = meta.mask0[b], m1 = meta.mask1[b];
+        const unsigned w0 = __builtin_amdgcn_readfirstlane((unsigned)m0), w1 = __builtin_amdgcn_readfirstlane((unsigned)(m0 >> 32));
+        const unsigned w2 = __builtin_amdgcn_readfirstlane((unsigned)m1), w3 = __builtin_amdgcn_readfirstlane((unsigned)(m1 >> 32));
+        const bool uniform = __builtin_amdgcn_readfirstlane(meta.uniform[b]) != 0u;
+        const bool interior = sdfk_interior(g.L, k);
+        const bool live_row = r0 + lr < g.R;
+        const int dr = live_row ? lr : (int)(g.R - 1 - r0);
+        long long f;                                              // flat index of this lane's first point
+        const int z = sdfk_win_z(r0 + dr, g.L, k, zq, &f);        // its index in the row (edge chunks: may lie outside)
+        const int last = (int)g.L - 1;
+        V3P P[SDFK_NP];
+        f2 res[SDFK_NP];
+        SDFK_EACH P[q].z = *reinterpret_cast<const f2*>(&meta.z[b][lr * SDFK_RZ + zq + 2 * q]);
+#ifdef SDFK_ABLATE_EVAL
+        if (true) {
+            SDFK_EACH res[q] = P[q].z + __builtin_bit_cast(float, w0 ^ w1 ^ w2 ^ w3);
+        } else
+#endif
+        if (uniform) {
+            const float2 xy = meta.xy[b][lr];
+            SDFK_EACH { P[q].x = sp<f2>(xy.x); P[q].y = sp<f2>(xy.y); }
+            sdfk_rows_culled<true>(xy.x, xy.y, P, w0, w1, w2, w3, PRM, TAB, res);
+        } else {                                                  // x, y of every point again (L2-resident)
+#pragma unroll
+            for (int q = 0; q < SDFK_NP; q += 2) {
+                float4 X, Y, Z;
+                sdfk_rows_fetch(s, g, r0, dr, z + 2 * q, interior, X, Y, Z);
+                P[q].x = {X.x, X.y}; P[q].y = {Y.x, Y.y};
+                P[q + 1].x = {X.z, X.w}; P[q + 1].y = {Y.z, Y.w};
+            }
+            sdfk_rows_culled<false>(0.0f, 0.0f, P, w0, w1, w2, w3, PRM, TAB, res);
+        }
+        if (live_row) {
+            float* po = out + f;
+            if (interior) {
+#pragma unroll
+                for (int q = 0; q < SDFK_NP; q += 2) {
+                    sdfk_f4u v = {res[q].x, res[q].y, res[q + 1].x, res[q + 1].y};
+                    *reinterpret_cast<sdfk_f4u*>(po + 2 * q) = v;
+                }
+            } else {
+                SDFK_EACH {
+                    if (z + 2 * q >= 0 && z + 2 * q <= last) po[2 * q] = res[q].x;
+                    if (z + 2 * q + 1 >= 0 && z + 2 * q + 1 <= last) po[2 * q + 1] = res[q].y;
+                }
+            }
+        }
+    }
+}
+extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_r(
+    const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
+    sdfk_rowgeom g, float* __restrict__ out) {
+    const SrcArray s = {co, stride};
+    sdfk_rows_kernel(PRM, TAB, s, g, out);
+}
+// the same on a regular grid expanded from three per-axis tables (no coordinate array: 4 B/point); the slab
+// starts at a row boundary and out[0] is its first point
+extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_rg(
+    const float* __restrict__ PRM, const float* __restrict__ TAB, SrcGrid s, sdfk_rowgeom g, float* __restrict__ out) {
+    sdfk_rows_kernel(PRM, TAB, s, g, out);
+}
+// test aid: the skip masks (two 64-bit words per brick: sites 0-31, 32-63; bit 2k = first operand of site k
+// skipped, bit 2k+1 = second) followed by the "uniform rows" flag in a third word
+extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_rmask(
+    const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
+    sdfk_rowgeom g, unsigned long long* __restrict__ masks) {
+    __shared__ __attribute__((aligned(16))) sdfk_rowmeta meta;
+    const SrcArray s = {co, stride};
+    unsigned rb, c;
+    sdfk_rows_prepare(PRM, TAB, s, g, &meta, rb, c);
+    const unsigned q = blockIdx.x * SDFK_RNBRICK + threadIdx.x;
+    if (threadIdx.x < SDFK_RNBRICK && q < g.nbricks) {
+        masks[3ull * q] = meta.mask0[threadIdx.x];
+        masks[3ull * q + 1] = meta.mask1[threadIdx.x];
+        masks[3ull * q + 2] = meta.uniform[threadIdx.x];
+    }
+}
+)SDFKR";
+
 namespace {
 
 struct Gen {
@@ -349,6 +627,7 @@ struct Gen {
     size_t n_instr;
     const std::vector<sdfk_cullsite>* sites;
     std::string s;
+    bool rows = false;   // emitting for the row-block kernel: registers are arrays of SDFK_NP packed pairs
 
     // "root transforms": XFORM instructions that read the untouched input point C0. slot[i] = their
     // index (else -1). On a brick whose points share x and y their first six fmas are one value per
@@ -371,14 +650,22 @@ struct Gen {
     // mode 0: plain; 1: probe (stores the base of root transforms); 2: culled (reads it when ZRUN)
     void instr_x(size_t i, const char* indent, int mode) {
         const int r = root_slot.empty() ? -1 : root_slot[i];
-        if (r < 0 || mode == 0) {
-            instr(i, indent);
+        // (the row-block probe keeps no bases: every lane computes its own in phase C)
+        if (r < 0 || mode == 0 || (rows && mode == 1)) {
+            instr(i, indent, rows && mode == 2);
             return;
         }
         char buf[640];
         const uint32_t w = code[2 * i], poff = code[2 * i + 1];
         const unsigned a = (w >> 8) & 255u;
-        if (mode == 1) {
+        if (rows) {
+            snprintf(buf, sizeof buf,
+                     "%sif constexpr (ZRUN) { const V3T<float> bs = op_xform_base(X, Y, PRM + %u);\n"
+                     "%s  const V3P bp = {sp<f2>(bs.x), sp<f2>(bs.y), sp<f2>(bs.z)};\n"
+                     "%s  SDFK_EACH C_%u[q] = op_xform_z(bp, C_0[q].z, PRM + %u); }\n"
+                     "%selse { SDFK_EACH C_%u[q] = op_xform(C_0[q], PRM + %u, TAB, 0); }\n",
+                     indent, poff, indent, indent, a, poff, indent, a, poff);
+        } else if (mode == 1) {
             snprintf(buf, sizeof buf,
                      "%s{ const V3T<float> bs = op_xform_base(C_0.x, C_0.y, PRM + %u); bases[%d] = bs.x; bases[%d] = bs.y; "
                      "bases[%d] = bs.z;\n%s  C_%u = op_xform_z(bs, C_0.z, PRM + %u); }\n",
@@ -392,31 +679,34 @@ struct Gen {
         s += buf;
     }
 
-    void instr(size_t i, const char* indent) {
+    void instr(size_t i, const char* indent) { instr(i, indent, false); }
+    void instr(size_t i, const char* indent, bool arr) {
         char buf[256];
         const uint32_t w = code[2 * i], poff = code[2 * i + 1];
         const unsigned op = w & 255u, a = (w >> 8) & 255u, b = (w >> 16) & 255u, c = w >> 24;
         if ((int)op >= n_ops) return;
         const sdfk_opinfo& o = ops[op];
+        const char* e = arr ? "SDFK_EACH " : "";
+        const char* x = arr ? "[q]" : "";
         switch (o.kind) {
             case SDFK_KIND_C_C:
-                snprintf(buf, sizeof buf, "%sC_%u = %s(C_%u, PRM + %u, TAB, %u);\n", indent, a, o.func, b, poff, c);
+                snprintf(buf, sizeof buf, "%s%sC_%u%s = %s(C_%u%s, PRM + %u, TAB, %u);\n", indent, e, a, x, o.func, b, x, poff, c);
                 break;
             case SDFK_KIND_V_C:
-                snprintf(buf, sizeof buf, "%sV_%u = %s(C_%u, PRM + %u, TAB);\n", indent, a, o.func, b, poff);
+                snprintf(buf, sizeof buf, "%s%sV_%u%s = %s(C_%u%s, PRM + %u, TAB);\n", indent, e, a, x, o.func, b, x, poff);
                 break;
             case SDFK_KIND_V_V:
-                snprintf(buf, sizeof buf, "%sV_%u = %s(V_%u, PRM + %u);\n", indent, a, o.func, b, poff);
+                snprintf(buf, sizeof buf, "%s%sV_%u%s = %s(V_%u%s, PRM + %u);\n", indent, e, a, x, o.func, b, x, poff);
                 break;
             default:
-                snprintf(buf, sizeof buf, "%sV_%u = %s(V_%u, V_%u, PRM + %u);\n", indent, a, o.func, b, c, poff);
+                snprintf(buf, sizeof buf, "%s%sV_%u%s = %s(V_%u%s, V_%u%s, PRM + %u);\n", indent, e, a, x, o.func, b, x, c, x, poff);
                 break;
         }
         s += buf;
     }
 
-    void declare(const char* ctype, const char* vtype, bool zero_init) {
-        zero_init = false;   // skipped subtrees never have their registers read (set_cull's liveness check)
+    // (no initialisers: skipped subtrees never have their registers read — set_cull's liveness check)
+    void declare(const char* ctype, const char* vtype, bool arr) {
         std::set<unsigned> cregs, vregs;
         for (size_t i = 0; i < n_instr; ++i) {
             const uint32_t w = code[2 * i];
@@ -426,14 +716,14 @@ struct Gen {
             else vregs.insert(a);
         }
         char buf[160];
+        const char* dim = arr ? "[SDFK_NP]" : "";
         for (unsigned c : cregs)
             if (c != 0) {
-                snprintf(buf, sizeof buf, zero_init ? "    %s C_%u = C_0;\n" : "    %s C_%u;\n", ctype, c);
+                snprintf(buf, sizeof buf, "    %s C_%u%s;\n", ctype, c, dim);
                 s += buf;
             }
         for (unsigned v : vregs) {
-            snprintf(buf, sizeof buf, zero_init ? "    %s V_%u = sp<%s>(0.0f);\n" : "    %s V_%u;\n", vtype, v,
-                     vtype);
+            snprintf(buf, sizeof buf, "    %s V_%u%s;\n", vtype, v, dim);
             s += buf;
         }
     }
@@ -474,10 +764,15 @@ struct Gen {
     // Lipschitz constants L_a, L_b (k = L_a + L_b): gap(c) >= w + k*rho  =>  gap(p) >= w for every p
     // of the brick, and then the (smooth) min / max returns the other operand bit-exactly.
     void emit_probe() {
-        s += "\nstatic __device__ __forceinline__ unsigned long long sdfk_probe(V3T<float> C_0, float rho, float* bases, "
-             "const float* __restrict__ PRM, const float* __restrict__ TAB) {\n";
+        if (rows)
+            s += "\nstatic __device__ __forceinline__ void sdfk_probe_r(V3T<float> C_0, float rho, "
+                 "const float* __restrict__ PRM, const float* __restrict__ TAB, unsigned long long& mask, "
+                 "unsigned long long& mask1) {\n";
+        else
+            s += "\nstatic __device__ __forceinline__ unsigned long long sdfk_probe(V3T<float> C_0, float rho, float* bases, "
+                 "const float* __restrict__ PRM, const float* __restrict__ TAB) {\n";
         declare("V3", "float", false);
-        s += "    unsigned long long mask = 0ull;\n";
+        s += rows ? "    mask = 0ull; mask1 = 0ull;\n" : "    unsigned long long mask = 0ull;\n";
         char buf[512], gB[64], gA[64], wx[32];
         for (size_t i = 0; i < n_instr; ++i) {
             for (size_t k = 0; k < sites->size(); ++k) {   // decisions read the operands BEFORE the combiner
@@ -487,30 +782,32 @@ struct Gen {
                 site_ops(t, gB, gA, wx, &neg, sizeof gB);
                 const uint32_t w = code[2 * i];
                 const unsigned b = (w >> 16) & 255u, c = w >> 24;
+                const char* mv = k < 32 ? "mask" : "mask1";
+                const unsigned sh = 2 * (unsigned)(k & 31);
                 snprintf(buf, sizeof buf,
                          "    { const float thr = %s + %.9gf * rho + 1e-6f * (1.0f + fabsf(V_%u) + fabsf(V_%u));\n"
-                         "      if (%d && %s >= thr) mask |= %lluull;\n"
-                         "      else if (%d && %s >= thr) mask |= %lluull; }\n",
-                         wx, (double)t.k * 1.0001, b, c, t.skip_b_ok, gB, 2ull << (2 * k), t.skip_a_ok, gA,
-                         1ull << (2 * k));
+                         "      if (%d && %s >= thr) %s |= %lluull;\n"
+                         "      else if (%d && %s >= thr) %s |= %lluull; }\n",
+                         wx, (double)t.k * 1.0001, b, c, t.skip_b_ok, gB, mv, 2ull << sh, t.skip_a_ok, gA, mv,
+                         1ull << sh);
                 s += buf;
             }
             instr_x(i, "    ", 1);
         }
-        s += "    return mask;\n}\n";
+        s += rows ? "}\n" : "    return mask;\n}\n";
     }
 
     // ---- culled evaluation ----
     // mask bit `bit` (0..63) as a test on one of the two 32-bit scalar halves
-    static std::string bit_test(unsigned bit) {
+    std::string bit_test(unsigned bit) const {
         char b[48];
-        snprintf(b, sizeof b, "(%s & %uu)", bit < 32 ? "mlo" : "mhi", 1u << (bit & 31));
+        if (rows) snprintf(b, sizeof b, "(mw%u & %uu)", bit >> 5, 1u << (bit & 31));
+        else snprintf(b, sizeof b, "(%s & %uu)", bit < 32 ? "mlo" : "mhi", 1u << (bit & 31));
         return b;
     }
 
     void emit_span(size_t lo, size_t hi, int depth) {
-        std::string ind(4 + 4 * depth, ' ');
-        char buf[512];
+        std::string ind(4 + 4 * std::min(depth, 10), ' ');   // (cosmetic; capped so lines fit the line buffers)
         size_t i = lo;
         while (i <= hi) {
             const int k = site_opening_at(i, hi);
@@ -533,20 +830,39 @@ struct Gen {
             char gB[64], gA[64], wx[32];
             bool neg;
             site_ops(t, gB, gA, wx, &neg, sizeof gB);
-            snprintf(buf, sizeof buf, "%sif %s V_%u = %sV_%u;\n%selse if %s V_%u = V_%u;\n%selse {\n", ind.c_str(), ta.c_str(),
-                     a, neg ? "-" : "", c, ind.c_str(), tb.c_str(), a, b, ind.c_str());
-            s += buf;
-            instr(t.comb, (ind + "    ").c_str());
+            {   // (deep chains indent past any fixed buffer: build the lines as strings)
+                char ra[24], rb_[24], rc[24];
+                snprintf(ra, sizeof ra, "V_%u", a);
+                snprintf(rb_, sizeof rb_, "V_%u", b);
+                snprintf(rc, sizeof rc, "V_%u", c);
+                const std::string e = rows ? "{ SDFK_EACH " : "", x = rows ? "[q]" : "", z = rows ? " }" : "";
+                s += ind + "if " + ta + " " + e + ra + x + " = " + (neg ? "-" : "") + rc + x + ";" + z + "\n";
+                s += ind + "else if " + tb + " " + e + ra + x + " = " + rb_ + x + ";" + z + "\n";
+                s += ind + "else {\n";
+            }
+            instr(t.comb, (ind + "    ").c_str(), rows);
             s += ind + "}\n";
             i = t.comb + 1;
         }
+    }
+
+    void emit_rows_culled(int result_reg) {
+        s += "\ntemplate <bool ZRUN> static __device__ __forceinline__ void sdfk_rows_culled(float X, float Y, "
+             "const V3P (&P0)[SDFK_NP], unsigned mw0, unsigned mw1, unsigned mw2, unsigned mw3, "
+             "const float* __restrict__ PRM, const float* __restrict__ TAB, f2 (&R)[SDFK_NP]) {\n"
+             "    typedef f2 T;\n    V3P C_0[SDFK_NP];\n    SDFK_EACH C_0[q] = P0[q];\n";
+        declare("V3P", "f2", true);
+        emit_span(0, n_instr - 1, 0);
+        char buf[96];
+        snprintf(buf, sizeof buf, "    SDFK_EACH R[q] = V_%d[q];\n}\n", result_reg);
+        s += buf;
     }
 
     void emit_culled(int result_reg) {
         s += "\ntemplate <typename T, bool ZRUN> static __device__ __forceinline__ T sdfk_point_culled(V3T<T> C_0, "
              "unsigned mlo, unsigned mhi, const float* bases, const float* __restrict__ PRM, "
              "const float* __restrict__ TAB) {\n";
-        declare("V3T<T>", "T", true);
+        declare("V3T<T>", "T", false);
         emit_span(0, n_instr - 1, 0);
         char buf[64];
         snprintf(buf, sizeof buf, "    return V_%d;\n}\n", result_reg);
@@ -560,7 +876,7 @@ std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32
                                  int result_reg, const std::vector<sdfk_cullsite>& sites) {
     Gen g{ops, n_ops, code, n_instr, &sites, std::string()};
     g.s.reserve(sizeof(kEmbeddedDevice) + sizeof(kEmbeddedAccess) + sizeof(kWrappers) + sizeof(kTileKernel) +
-                400 * n_instr + 1024);
+                sizeof(kRowsKernel) + 800 * n_instr + 1024);
     g.s += kEmbeddedDevice;
     g.s += "\n";
     g.s += kEmbeddedAccess;
@@ -573,12 +889,31 @@ std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32
     g.s += buf;
     g.s += kWrappers;
     if (!sites.empty()) {
+        // the flat tile kernel carries 62 mask bits: the first 31 sites; the row-block kernel takes 64
+        // (the 31 widest, in program order)
+        std::vector<size_t> order(sites.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+            return sites[x].comb - sites[x].a0 > sites[y].comb - sites[y].a0;
+        });
+        order.resize(std::min<size_t>(order.size(), 31));
+        std::sort(order.begin(), order.end());
+        std::vector<sdfk_cullsite> flat;
+        for (size_t i : order) flat.push_back(sites[i]);
+        g.sites = &flat;
         g.find_roots();
         snprintf(buf, sizeof buf, "\n#define SDFK_NROOT %d\n", g.n_root > 0 ? g.n_root : 1);
         g.s += buf;
         g.emit_probe();
         g.emit_culled(result_reg);
         g.s += kTileKernel;
+        g.sites = &sites;
+        g.rows = true;
+        g.s += "\n#ifndef SDFK_NP\n#define SDFK_NP 4\n#endif\n"
+               "#define SDFK_EACH _Pragma(\"unroll\") for (int q = 0; q < SDFK_NP; ++q)\n";
+        g.emit_probe();
+        g.emit_rows_culled(result_reg);
+        g.s += kRowsKernel;
     }
     return g.s;
 }

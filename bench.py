@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--mode", default="auto", choices=["auto", "interpret", "nocull"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-allgather", action="store_true")
+    ap.add_argument("--no-rows", action="store_true", help="do not pass the row-length layout hint (flat 128-point bricks)")
     return ap.parse_args()
 
 
@@ -127,8 +128,10 @@ def main():
     axes64, res = grid_axes(size, (args.grid,) * len(size))
     axes = [a.astype(np.float32) for a in axes64]           # fp32-rounded float64 linspace ("identical grids")
     n_total = int(axes[0].size) * int(axes[1].size) * int(axes[2].size)
-    # contiguous slabs of the flat index (x-slabs); remainder to the last rank
-    per = n_total // world
+    # contiguous slabs of the flat index, whole grid rows each (row = the last axis longer than 1);
+    # remainder to the last rank
+    row_len = int(axes[2].size) if axes[2].size > 1 else int(axes[1].size)
+    per = (n_total // row_len // world) * row_len
     start = rank * per
     count = per if rank < world - 1 else n_total - start
 
@@ -144,7 +147,8 @@ def main():
     culled = mode == _engine.MODE_SPECIALIZED and len(low.cull_sites) > 0
 
     def step():
-        prog.eval_device(co.data_ptr(), count, stride, out.data_ptr(), stream=stream, mode=mode)
+        prog.eval_device(co.data_ptr(), count, stride, out.data_ptr(), stream=stream, mode=mode,
+                         row_len=None if args.no_rows else row_len)
 
     def fence():
         torch.cuda.synchronize()
@@ -238,7 +242,9 @@ def main():
             "config": {"workload": desc, "grid": "%dx%dx%d (request %d per axis), size %s" % (
                 axes[0].size, axes[1].size, axes[2].size, args.grid, tuple(size)),
                        "points": n_total, "points_per_gpu": count, "sharding": "contiguous x-slabs, no collective",
-                       "kernel": ("sdfk_spec_t (hiprtc, topology-specialised, exact brick culling)" if culled else
+                       "kernel": (("sdfk_spec_t (hiprtc, topology-specialised, exact culling on 128-point bricks)" if args.no_rows else
+                                   "sdfk_spec_r (hiprtc, topology-specialised, exact culling on 32x16-point row blocks)")
+                                  if culled else
                                   "sdfk_spec_v4 (hiprtc, topology-specialised)") if mode != _engine.MODE_INTERPRET
                        else "sdfk_interp_kernel", "instructions": int(low.code.shape[0]),
                        "cull_sites": int(len(low.cull_sites)) if culled else 0},

@@ -54,7 +54,7 @@ sdfk_program* sdfk_program_create(const uint32_t* code, size_t n_instr, const fl
 void sdfk_program_destroy(sdfk_program* prog);
 /* Replace the parameter values of a program in place (same topology, new shape parameters). */
 int sdfk_program_set_params(sdfk_program* prog, const float* params, size_t n_params);
-/* Brick culling (optional, before first use of the program): n_sites rows {combiner index, a_start,
+/* Brick culling (optional, before first use of the program): n_sites rows (at most 64) {combiner index, a_start,
  * a_end, b_start, b_end} naming, for min/max-type combiners, the instruction ranges that produce the
  * two operands, and k[i] = L_a + L_b, the sum of the Lipschitz constants of the operand fields with
  * respect to the input point. The specialised kernel then evaluates the tree once per brick of 128
@@ -76,6 +76,14 @@ int sdfk_program_compile_check(sdfk_program* prog, size_t* code_size);
  * Uses 16-byte vector loads when d_co, d_out and row_stride allow (16-B aligned, stride % 4 == 0). */
 int sdfk_eval_device(sdfk_program* prog, const float* d_co, int64_t n, int64_t row_stride, float* d_out,
                      void* stream, int mode);
+/* The same with a LAYOUT HINT: the n points are consecutive rows of row_len points (n % row_len == 0) — for the
+ * (3, N) array of generate_grid (cores/helper_functions.py:86-91, meshgrid "ij" flattened) row_len is the last
+ * grid dimension. Brick culling then works on blocks of 32 points x 16 rows instead of 128 points in a line
+ * (4x smaller bounding spheres, far fewer surviving subtrees), and rows need no 16-byte alignment. The hint
+ * affects speed only: the field is bit-identical to sdfk_eval_device for ANY row_len (bounds, the "one x and
+ * one y per row" test and every skip decision are derived from the coordinates actually read). */
+int sdfk_eval_device_rows(sdfk_program* prog, const float* d_co, int64_t n, int64_t row_stride, int64_t row_len,
+                          float* d_out, void* stream, int mode);
 /* Host-buffer convenience: stages co (dtype 0 = fp32, 1 = fp64; (3, n) with row stride in elements)
  * through device memory in chunks, evaluates and copies the fp32 field back. */
 int sdfk_eval_host(sdfk_program* prog, const void* co, int co_dtype, int64_t n, int64_t row_stride, float* out,
@@ -95,6 +103,12 @@ void sdfk_set_default_mode(int mode);
  * bit 63 = all points of the brick share x and y). */
 int sdfk_debug_brick_masks(sdfk_program* prog, const float* d_co, int64_t n, int64_t row_stride, uint64_t* d_masks,
                            void* stream);
+/* The same for the row-block kernel of sdfk_eval_device_rows: 3 words per brick {skip bits of sites 0-31, of sites
+ * 32-63, rows-uniform flag}; brick q covers rows [brick_rows*(q / nchunk), +brick_rows) and points
+ * [32*(q % nchunk), +32) of each, nchunk = ceil(row_len / 32). With d_masks == NULL only *n_bricks and
+ * *brick_rows are returned. */
+int sdfk_debug_row_masks(sdfk_program* prog, const float* d_co, int64_t n, int64_t row_stride, int64_t row_len,
+                         uint64_t* d_masks, int64_t* n_bricks, int* brick_rows, void* stream);
 
 /* ---- grid builder -----------------------------------------------------------------------------
  * numpy.linspace(lo, hi, n) in float64 (step = (hi-lo)/(n-1); y[i] = i*step + lo; y[n-1] = hi),

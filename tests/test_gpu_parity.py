@@ -103,7 +103,7 @@ def test_empty_and_ragged_inputs(engine):
         tree.create(np.zeros((2, 10)))
 
 
-def _device_eval(engine, prog, co32, n, stride, misalign=0, mode=None):
+def _device_eval(engine, prog, co32, n, stride, misalign=0, mode=None, row_len=None):
     """eval_device on raw HIP buffers (optionally shifted by `misalign` floats to defeat 16-B alignment)."""
     lib = engine.lib()
     d_co = lib.sdfk_malloc((3 * stride + misalign + 4) * 4)
@@ -114,7 +114,7 @@ def _device_eval(engine, prog, co32, n, stride, misalign=0, mode=None):
         engine.check(lib.sdfk_memcpy_h2d(ctypes.c_void_p(d_co + 4 * misalign), host.ctypes.data_as(ctypes.c_void_p),
                                          host.nbytes), "h2d")
         prog.eval_device(d_co + 4 * misalign, n, stride, d_out + 4 * misalign,
-                         mode=engine.MODE_SPECIALIZED if mode is None else mode)
+                         mode=engine.MODE_SPECIALIZED if mode is None else mode, row_len=row_len)
         engine.check(lib.sdfk_sync(None), "sync")
         out = np.empty(n, dtype=np.float32)
         engine.check(lib.sdfk_memcpy_d2h(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_out + 4 * misalign),
@@ -325,6 +325,47 @@ def test_sharded_evaluation_matches_whole_grid(engine):
 CULL_SCENES = ["tree_cfg2_smooth_union10", "tree_cfg5_three_level", "tree_cfg4_union50_2d", "tree_pawn_like",
                "tree_deep_right", "combine_SMOOTH_SUBTRACT2", "combine_SUBTRACT2", "combine_INTERSECT_nary",
                "combine_SMOOTH_INTERSECT2", "combine_modified_result", "alias_symmetry_in_child_not_visible"]
+
+
+ROW_SHAPES = [((9, 37, 1025), 0), ((20, 33, 64), 0), ((7, 50, 40), 1), ((3, 16, 32), 3), ((5, 5, 333), 2)]
+
+
+@pytest.mark.parametrize("name", CULL_SCENES)
+def test_row_block_culling_is_bit_exact(name, engine):
+    """sdfk_eval_device_rows (bricks of 32 points x 16 rows, several packed pairs per lane, per-lane transform
+    bases) returns exactly what the plain specialised kernel returns: odd row lengths (rows only 4-byte
+    aligned), row counts that are no multiple of the brick height, last chunks of 1 / 8 / 13 points,
+    shifted pointers — and a row length that has nothing to do with the data."""
+    low = lower_geometry(scenes.SCENES[name](ns))
+    prog = engine.Program.from_lowered(low)
+    for shape, mis in ROW_SHAPES:
+        if "2d" in name:
+            co, _ = ns.generate_grid((10, 10), (shape[0] * shape[1] - 1, shape[2] - 1))
+        else:
+            co, _ = ns.generate_grid((2.6, 2.6, 2.6), tuple(r - 1 for r in shape))
+        co32 = co.astype(np.float32)
+        n = co32.shape[1]
+        # rows run along z (3-D) or along y (2-D): the first change of the next slower coordinate ends row 0
+        slower = co32[0] if "2d" in name else co32[1]
+        row_len = int(np.flatnonzero(slower != slower[0])[0])
+        assert n % row_len == 0
+        stride = n + 5
+        plain = _device_eval(engine, prog, co32, n, stride, mis, engine.MODE_NOCULL)
+        rows = _device_eval(engine, prog, co32, n, stride, mis, engine.MODE_SPECIALIZED, row_len=row_len)
+        np.testing.assert_array_equal(rows, plain)
+        # grid flavour (coordinates from the per-axis tables): the whole grid and a slab of whole rows
+        axes = [a.astype(np.float32) for a in co.grid_axes]
+        np.testing.assert_array_equal(prog.eval_grid_host(axes), plain)
+        s0, cnt = 3 * row_len, (n // row_len - 5) * row_len
+        np.testing.assert_array_equal(prog.eval_grid_host(axes, s0, cnt), plain[s0:s0 + cnt])
+    # scattered points under a row hint: nothing is uniform, nothing may be skipped wrongly
+    rng = np.random.default_rng(11)
+    pts = rng.uniform(-1.5, 1.5, (3, 48 * 100)).astype(np.float32)
+    pts[:, 1000:1100] = pts[:, 1000:1001]                   # a run of identical points
+    pts[:2, 2000:2048] = pts[:2, 2000:2001]                 # x/y-constant stretch that is not a whole row
+    plain = _device_eval(engine, prog, pts, pts.shape[1], pts.shape[1], 0, engine.MODE_NOCULL)
+    rows = _device_eval(engine, prog, pts, pts.shape[1], pts.shape[1], 0, engine.MODE_SPECIALIZED, row_len=48)
+    np.testing.assert_array_equal(rows, plain)
 
 
 @pytest.mark.parametrize("name", CULL_SCENES)
