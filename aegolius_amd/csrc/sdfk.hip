@@ -902,6 +902,23 @@ extern "C" int sdfk_grid_fill(float* d_co, int64_t row_stride, const float* ax0,
 }
 
 // ---- host-buffer convenience --------------------------------------------------------------------
+// Row length of a host (3, n) array that looks like a flattened meshgrid: the index at which x or y first
+// changes (3-D grids: rows along z) or, failing that, at which x first changes (2-D grids: rows along y).
+// Only a layout hint for the row-block kernel — a wrong guess costs speed, never correctness.
+template <typename T>
+static int64_t detect_row_len(const T* co, int64_t n, int64_t stride) {
+    const int64_t scan = std::min<int64_t>(n, (int64_t)1 << 22);
+    const T *x = co, *y = co + stride;
+    int64_t a = 0, b = 0;
+    for (int64_t i = 1; i < scan && (!a || !b); ++i) {
+        if (!b && x[i] != x[0]) b = i;
+        if (!a && (x[i] != x[0] || y[i] != y[0])) a = i;
+    }
+    if (a >= 32 && n % a == 0) return a;
+    if (b >= 32 && n % b == 0) return b;
+    return 0;
+}
+
 extern "C" int sdfk_eval_host(sdfk_program* p, const void* co, int co_dtype, int64_t n, int64_t row_stride, float* out,
                               int device, int mode) {
     if (!p) return fail(-1, "null program");
@@ -910,7 +927,11 @@ extern "C" int sdfk_eval_host(sdfk_program* p, const void* co, int co_dtype, int
     if (row_stride < n) return fail(-1, "sdfk_eval_host: row stride smaller than the point count");
     if (n == 0) return 0;
     HIPCHK(hipSetDevice(device));
-    const int64_t chunk = std::min<int64_t>(n, (int64_t)1 << 25);  // 32 Mi points = 512 MiB of device staging
+    int64_t chunk = std::min<int64_t>(n, (int64_t)1 << 25);  // 32 Mi points = 512 MiB of device staging
+    const int64_t row_len = p->sites.empty() ? 0
+                            : co_dtype == 0 ? detect_row_len(static_cast<const float*>(co), n, row_stride)
+                                            : detect_row_len(static_cast<const double*>(co), n, row_stride);
+    if (row_len > 0 && chunk > row_len) chunk = chunk / row_len * row_len;   // whole rows per chunk
     const int64_t stride = (chunk + 63) & ~(int64_t)63;
     float *d_co = nullptr, *d_out = nullptr;
     HIPCHK(hipMalloc(&d_co, (size_t)stride * 3 * sizeof(float)));
@@ -935,7 +956,9 @@ extern "C" int sdfk_eval_host(sdfk_program* p, const void* co, int co_dtype, int
             if (hipMemcpy(d_co + r * stride, srcf, (size_t)m * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
                 rc = fail(-6, "sdfk_eval_host: host-to-device copy failed");
         }
-        if (rc == 0) rc = sdfk_eval_device(p, d_co, m, stride, d_out, nullptr, mode);
+        if (rc == 0)
+            rc = (row_len > 0 && m % row_len == 0) ? sdfk_eval_device_rows(p, d_co, m, stride, row_len, d_out, nullptr, mode)
+                                                   : sdfk_eval_device(p, d_co, m, stride, d_out, nullptr, mode);
         if (rc == 0 && hipMemcpy(out + s, d_out, (size_t)m * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
             rc = fail(-6, "sdfk_eval_host: device-to-host copy failed");
     }

@@ -393,9 +393,11 @@ static __device__ __forceinline__ bool sdfk_interior(unsigned L, unsigned k) {  
 }
 static __device__ __forceinline__ float4 sdfk_win_quad(const float* __restrict__ rowp, int z, int last, bool interior) {
     if (interior) {
-        const sdfk_f4u v = *reinterpret_cast<const sdfk_f4u*>(rowp + z);
+        const sdfk_f4u v = __builtin_nontemporal_load(reinterpret_cast<const sdfk_f4u*>(rowp + z));
         return make_float4(v.x, v.y, v.z, v.w);
     }
+    // edge window, branch-free on purpose: per-lane branches around the loads (whole quad / one value / mixed)
+    // serialise the memory round trips and were measured 15 % slower for the whole kernel
     return make_float4(rowp[min(max(z, 0), last)], rowp[min(max(z + 1, 0), last)], rowp[min(max(z + 2, 0), last)],
                        rowp[min(max(z + 3, 0), last)]);
 }
@@ -457,6 +459,13 @@ static __device__ __forceinline__ void sdfk_rows_load(const SRC& s, const sdfk_r
 }
 // phase A, part 2: z and the row heads to LDS, "every row has one x and one y", bounding sphere
 static __device__ __forceinline__ void sdfk_rows_bounds(const sdfk_rowregs& r, int lane, sdfk_rowmeta* meta, int b) {
+#ifdef SDFK_ABLATE_BOUNDS
+    *reinterpret_cast<float4*>(&meta->z[b][(lane >> 3) * SDFK_RZ + 4 * (lane & 7)]) = r.Z[0];
+    if (SDFK_RLOADS > 1) *reinterpret_cast<float4*>(&meta->z[b][(8 + (lane >> 3)) * SDFK_RZ + 4 * (lane & 7)]) = r.Z[SDFK_RLOADS - 1];
+    if ((lane & 7) == 0) { meta->xy[b][lane >> 3] = make_float2(r.X[0].x, r.Y[0].x); meta->xy[b][SDFK_RROWS - 8 + (lane >> 3)] = make_float2(r.X[SDFK_RLOADS - 1].x, r.Y[SDFK_RLOADS - 1].x); }
+    if (lane == 0) { meta->bound[b] = make_float4(0.f, 0.f, 0.f, 1.f); meta->uniform[b] = 1u; }
+    return;
+#endif
     bool uni = true;
 #pragma unroll
     for (int t = 0; t < SDFK_RLOADS; ++t) {
@@ -501,7 +510,11 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
     // parallelism, limit this phase)
 #pragma unroll
     for (int j = 0; j < SDFK_RWBRICKS; ++j) {
+#ifdef SDFK_ABLATE_EDGE
+        if (q0 + j < g.nbricks && sdfk_interior(g.L, c)) {
+#else
         if (q0 + j < g.nbricks) {
+#endif
             sdfk_rowregs regs;
             sdfk_rows_load(s, g, (long long)rb * SDFK_RROWS, c, lane, regs);
             sdfk_rows_bounds(regs, lane, meta, wave * SDFK_RWBRICKS + j);
@@ -544,6 +557,9 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
         const unsigned w2 = __builtin_amdgcn_readfirstlane((unsigned)m1), w3 = __builtin_amdgcn_readfirstlane((unsigned)(m1 >> 32));
         const bool uniform = __builtin_amdgcn_readfirstlane(meta.uniform[b]) != 0u;
         const bool interior = sdfk_interior(g.L, k);
+#ifdef SDFK_ABLATE_EDGE
+        if (!interior) continue;
+#endif
         const bool live_row = r0 + lr < g.R;
         const int dr = live_row ? lr : (int)(g.R - 1 - r0);
         long long f;                                              // flat index of this lane's first point
@@ -577,7 +593,7 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
 #pragma unroll
                 for (int q = 0; q < SDFK_NP; q += 2) {
                     sdfk_f4u v = {res[q].x, res[q].y, res[q + 1].x, res[q + 1].y};
-                    *reinterpret_cast<sdfk_f4u*>(po + 2 * q) = v;
+                    __builtin_nontemporal_store(v, reinterpret_cast<sdfk_f4u*>(po + 2 * q));
                 }
             } else {
                 SDFK_EACH {

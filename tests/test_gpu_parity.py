@@ -449,3 +449,70 @@ def test_brick_masks_are_conservative(engine):
     assert n_skipped > 0.3 * masks.size * 9          # and the probe is not vacuous
     # 7 of every ~8 bricks lie inside one row (x/y-constant runs), the others straddle a row end
     assert 0.8 < ((masks >> np.uint64(63)) & np.uint64(1)).mean() < 0.95
+
+
+def test_row_block_masks_are_conservative(engine):
+    """The same justification for the row-block kernel (sdfk_eval_device_rows): bricks are 32-point windows
+    (aligned in the flat array) of 16 consecutive rows; every skip bit is checked against the float64 oracle at
+    every point of its brick, the probe must cull far more than the 128-point line bricks do, and all bricks of
+    a regular grid must come out as 'uniform rows'."""
+    from aegolius_amd._ir import CombineSDF
+    tree = scenes.cfg2_tree(ns)
+    low = lower_geometry(tree)
+    prog = engine.Program.from_lowered(low)
+    dz = 2.0 / 1024                                          # the spacing of the 1025^3 north-star grid, on a slab
+    co, res = ns.generate_grid((8 * dz, 128 * dz, 2), (8, 128, 1024))
+    co32 = co.astype(np.float32)
+    n, L = co32.shape[1], 1025
+    assert n % L == 0 and res[-1] == L
+    R = n // L
+    lib = engine.lib()
+    nb, brows = ctypes.c_int64(0), ctypes.c_int(0)
+    engine.check(lib.sdfk_debug_row_masks(prog.handle, ctypes.c_void_p(1), n, n, L, None, ctypes.byref(nb),
+                                          ctypes.byref(brows), None), "size query")
+    nb, brows = nb.value, brows.value
+    nchunk = (L + 62) // 32
+    assert nb == nchunk * ((R + brows - 1) // brows)
+    d_co, d_m = lib.sdfk_malloc(3 * n * 4), lib.sdfk_malloc(nb * 24)
+    try:
+        engine.check(lib.sdfk_memcpy_h2d(ctypes.c_void_p(d_co), co32.ctypes.data_as(ctypes.c_void_p), co32.nbytes), "h2d")
+        engine.check(lib.sdfk_debug_row_masks(prog.handle, ctypes.c_void_p(d_co), n, n, L, ctypes.c_void_p(d_m), None,
+                                              None, None), "masks")
+        engine.check(lib.sdfk_sync(None), "sync")
+        words = np.empty((nb, 3), dtype=np.uint64)
+        engine.check(lib.sdfk_memcpy_d2h(words.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_m), words.nbytes), "d2h")
+    finally:
+        lib.sdfk_free(ctypes.c_void_p(d_co))
+        lib.sdfk_free(ctypes.c_void_p(d_m))
+    masks, uniform = words[:, 0], words[:, 2]
+    assert np.all(words[:, 1] == 0) and np.all(uniform == 1)
+    # brick of every point
+    r, z = np.divmod(np.arange(n, dtype=np.int64), L)
+    brick = (r // brows) * nchunk + ((r * L + z) >> 5) - ((r * L) >> 5)
+    assert brick.max() < nb
+    prims, node = [], tree
+    while isinstance(node.modified_object, CombineSDF):
+        a, b = node.modified_object.children
+        prims.append(b)
+        node = a
+    prims.append(node)
+    prims = prims[::-1]
+    co64 = co32.astype(np.float64)
+    d = [sdf_oracle.evaluate(p, co64) for p in prims]
+    w = 0.1
+    acc = d[0].copy()
+    alive = np.ones((10, nb), dtype=bool)                     # primitives a brick still evaluates
+    for k in range(1, 10):
+        skip_b = ((masks >> np.uint64(2 * (k - 1) + 1)) & np.uint64(1)).astype(bool)
+        skip_a = ((masks >> np.uint64(2 * (k - 1))) & np.uint64(1)).astype(bool)
+        alive[k] &= ~skip_b
+        alive[:k] &= ~skip_a
+        gap_b = np.full(nb, np.inf)
+        np.minimum.at(gap_b, brick, d[k] - acc)
+        gap_a = np.full(nb, np.inf)
+        np.minimum.at(gap_a, brick, acc - d[k])
+        assert np.all(gap_b[skip_b] >= w) and np.all(gap_a[skip_a] >= w)
+        assert not np.any(skip_a & skip_b)
+        acc = sdf_oracle.smin_poly(acc, d[k], w, 3)
+    assert alive.sum(axis=0).min() >= 1
+    assert alive.mean() < 0.45, alive.mean()                 # central slab of the scene, where the primitives crowd

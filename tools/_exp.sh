@@ -1,8 +1,9 @@
-run() { echo "== $*"; env "$@" timeout -k 10 200 python bench.py --steps 10 --warmup 2 --cpu-seconds 0 $BENCH_ARGS 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('kernel_ms %.3f' % d['roofline']['kernel_ms'], d.get('grid_path'))"; }
-timeout -k 10 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
+run() { local envs=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do envs+=("$1"); shift; done; [ "$1" = "--" ] && shift
+  echo "== ${envs[*]} $*"; env "${envs[@]}" timeout -k 10 250 python bench.py --steps 10 --warmup 2 --cpu-seconds 0 "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('kernel_ms %.3f frac %.3f grid_ms %.3f' % (d['roofline']['kernel_ms'], d['roofline']['frac'], d['grid_path']['ms']))"; }
 run A=1
-run BENCH_ARGS="--workload cfg5"
-run BENCH_ARGS="--workload cfg4 --grid 16384"
-run BENCH_ARGS="--workload cfg4 --grid 16384 --no-rows"
-run BENCH_ARGS="--workload cfg1"
-run BENCH_ARGS="--workload cfg3"
+run SDFK_TWAVES=1 SDFK_RWBRICKS=8
+run SDFK_TWAVES=1 SDFK_RWBRICKS=4
+run SDFK_TWAVES=2 SDFK_RWBRICKS=4
+run SDFK_TWAVES=2 SDFK_RWBRICKS=2
+run SDFK_TWAVES=8 SDFK_RWBRICKS=2
+run SDFK_TWAVES=4 SDFK_RWBRICKS=3

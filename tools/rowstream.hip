@@ -13,6 +13,34 @@ __global__ __launch_bounds__(256) void flat4(const float* __restrict__ co, long 
         *(float4*)(out + i) = make_float4(x.x + y.x + z.x, x.y + y.y + z.y, x.z + y.z + z.z, x.w + y.w + z.w);
     }
 }
+__global__ __launch_bounds__(256) void flat4nt(const float* __restrict__ co, long long stride, long long n, float* __restrict__ out) {
+    long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    if (i + 3 < n) {
+        f4 x = __builtin_nontemporal_load((const f4*)(co + i)), y = __builtin_nontemporal_load((const f4*)(co + stride + i)),
+           z = __builtin_nontemporal_load((const f4*)(co + 2 * stride + i));
+        __builtin_nontemporal_store(x + y + z, (f4*)(out + i));
+    }
+}
+__global__ __launch_bounds__(256) void flat4nts(const float* __restrict__ co, long long stride, long long n, float* __restrict__ out) {
+    long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    if (i + 3 < n) {
+        f4 x = *((const f4*)(co + i)), y = *((const f4*)(co + stride + i)), z = *((const f4*)(co + 2 * stride + i));
+        __builtin_nontemporal_store(x + y + z, (f4*)(out + i));
+    }
+}
+// 2 quads per thread (more bytes in flight per wave)
+__global__ __launch_bounds__(256) void flat8(const float* __restrict__ co, long long stride, long long n, float* __restrict__ out) {
+    long long i = ((long long)blockIdx.x * 512 + threadIdx.x) * 4;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    if (i + 1024 + 3 < n) {
+        f4 x = *((const f4*)(co + i)), y = *((const f4*)(co + stride + i)), z = *((const f4*)(co + 2 * stride + i));
+        f4 x2 = *((const f4*)(co + i + 1024)), y2 = *((const f4*)(co + stride + i + 1024)), z2 = *((const f4*)(co + 2 * stride + i + 1024));
+        *(f4*)(out + i) = x + y + z;
+        *(f4*)(out + i + 1024) = x2 + y2 + z2;
+    }
+}
 // one wave instruction = LPR lanes x 16 B per row, 64/LPR rows; a wave handles NB consecutive chunks along z
 template <int LPR, int NB>
 __global__ __launch_bounds__(256) void rows(const float* __restrict__ co, long long stride, unsigned L, long long R, unsigned nchunk,
@@ -54,13 +82,19 @@ template <int LPR, int NB> void run_rows(const float* co, long long stride, unsi
     printf("%-28s L=%u: %.3f ms  %.0f GB/s\n", name, L, ms, 16.0 * L * R / ms / 1e6);
 }
 int main(int argc, char** argv) {
-    for (unsigned L : {1028u, 1040u, 1025u}) {
+    for (unsigned L : {1024u}) {
         const long long R = 1025LL * 1025LL, n = R * L, stride = (n + 255) / 256 * 256;
         float *co, *out;
         CHK(hipMalloc(&co, 3 * stride * 4)); CHK(hipMalloc(&out, stride * 4));
         CHK(hipMemset(co, 0, 3 * stride * 4));
         float ms = time_it([&] { hipLaunchKernelGGL(flat4, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, 0, co, stride, n, out); }, 10);
         printf("%-28s L=%u: %.3f ms  %.0f GB/s\n", "flat float4", L, ms, 16.0 * n / ms / 1e6);
+        ms = time_it([&] { hipLaunchKernelGGL(flat4nt, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, 0, co, stride, n, out); }, 10);
+        printf("%-28s L=%u: %.3f ms  %.0f GB/s\n", "flat float4 nontemporal", L, ms, 16.0 * n / ms / 1e6);
+        ms = time_it([&] { hipLaunchKernelGGL(flat4nts, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, 0, co, stride, n, out); }, 10);
+        printf("%-28s L=%u: %.3f ms  %.0f GB/s\n", "flat float4 nt store only", L, ms, 16.0 * n / ms / 1e6);
+        ms = time_it([&] { hipLaunchKernelGGL(flat8, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, 0, co, stride, n, out); }, 10);
+        printf("%-28s L=%u: %.3f ms  %.0f GB/s\n", "flat 2 quads/thread", L, ms, 16.0 * n / ms / 1e6);
         run_rows<8, 1>(co, stride, L, R, out, "8 rows x 32, 1 chunk/wave");
         run_rows<8, 4>(co, stride, L, R, out, "8 rows x 32, 4 chunks/wave");
         run_rows<8, 8>(co, stride, L, R, out, "8 rows x 32, 8 chunks/wave");
