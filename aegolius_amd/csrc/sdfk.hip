@@ -447,6 +447,10 @@ static int rows_np() {
     static int v = [] { const char* e = getenv("SDFK_NP"); int t = e ? atoi(e) : 4; return (t == 2 || t == 4) ? t : 4; }();
     return v;
 }
+static int rows_tiles() {   // tiles per workgroup of the row-block kernel
+    static int v = [] { const char* e = getenv("SDFK_RTILES"); int t = e ? atoi(e) : 1; return (t >= 1 && t <= 64) ? t : 1; }();
+    return v;
+}
 static int rows_wbricks() {
     static int v = [] { const char* e = getenv("SDFK_RWBRICKS"); int t = e ? atoi(e) : 2; return (t >= 1 && t <= 16) ? t : 2; }();
     return v;
@@ -480,7 +484,8 @@ static int rtc_compile(const std::string& src, std::vector<char>* out, std::stri
         *log = "hiprtcCreateProgram failed";
         return -1;
     }
-    char d_tile[48], d_thr[48], d_np[48], d_rwb[48];
+    char d_tile[48], d_thr[48], d_np[48], d_rwb[48], d_rt[48];
+    snprintf(d_rt, sizeof d_rt, "-DSDFK_RTILES=%d", rows_tiles());
     snprintf(d_tile, sizeof d_tile, "-DSDFK_TWAVES=%d", tile_waves());
     snprintf(d_thr, sizeof d_thr, "-DSDFK_WBRICKS=%d", tile_wbricks());
     snprintf(d_np, sizeof d_np, "-DSDFK_NP=%d", rows_np());
@@ -488,7 +493,7 @@ static int rtc_compile(const std::string& src, std::vector<char>* out, std::stri
     // -fno-honor-nans -mno-amdgpu-ieee: v_min/v_max without the canonicalising pre-op (same flags as the
     // hipcc build of the interpreter kernel, so both flavours stay bit-identical)
     std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17",
-                                     "-fno-honor-nans", "-mno-amdgpu-ieee", d_tile, d_thr, d_np, d_rwb};
+                                     "-fno-honor-nans", "-mno-amdgpu-ieee", d_tile, d_thr, d_np, d_rwb, d_rt};
     // experiment hook: extra -D switches for the generated source (space separated), e.g. SDFK_RTC_DEFS="-DSDFK_TWAVES=2"
     std::vector<std::string> extra;
     if (const char* e = getenv("SDFK_RTC_DEFS")) {
@@ -635,7 +640,7 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
             const float* co = arr->co;
             long long stride = arr->stride;
             void* args[] = {&prm, &tab, &co, &stride, &rg, &d_out};
-            const unsigned per_tile = (unsigned)(tile_waves() * rows_wbricks());
+            const unsigned per_tile = (unsigned)(tile_waves() * rows_wbricks() * rows_tiles());
             const unsigned tiles = (rg.nbricks + per_tile - 1) / per_tile;
             HIPCHK(hipModuleLaunchKernel(sk->rows, tiles, 1, 1, tile_threads(), 1, 1, 0, stream, args, nullptr));
             return 0;
@@ -657,7 +662,7 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
             rg.row0 = grid->start / grow;
             rg.yrows = grid->n2 > 1 ? 0 : 1;
             void* args[] = {&prm, &tab, &g, &rg, &d_out};
-            const unsigned per_tile = (unsigned)(tile_waves() * rows_wbricks());
+            const unsigned per_tile = (unsigned)(tile_waves() * rows_wbricks() * rows_tiles());
             const unsigned tiles = (rg.nbricks + per_tile - 1) / per_tile;
             HIPCHK(hipModuleLaunchKernel(sk->rows_grid, tiles, 1, 1, tile_threads(), 1, 1, 0, stream, args, nullptr));
             return 0;

@@ -500,9 +500,9 @@ static __device__ __forceinline__ void sdfk_rows_bounds(const sdfk_rowregs& r, i
 template <typename SRC>
 static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict__ PRM, const float* __restrict__ TAB,
                                                          const SRC& s, const sdfk_rowgeom& g, sdfk_rowmeta* meta,
-                                                         unsigned& rb0, unsigned& c0) {
+                                                         unsigned tile, unsigned& rb0, unsigned& c0) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned q0 = blockIdx.x * SDFK_RNBRICK + wave * SDFK_RWBRICKS;      // first brick of this wave
+    const unsigned q0 = tile * SDFK_RNBRICK + wave * SDFK_RWBRICKS;            // first brick of this wave
     rb0 = q0 / g.nchunk;
     c0 = q0 - rb0 * g.nchunk;
     unsigned rb = rb0, c = c0;
@@ -522,7 +522,7 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
         if (++c == g.nchunk) { c = 0; ++rb; }
     }
     __syncthreads();
-    if (threadIdx.x < SDFK_RNBRICK && blockIdx.x * SDFK_RNBRICK + threadIdx.x < g.nbricks) {
+    if (threadIdx.x < SDFK_RNBRICK && tile * SDFK_RNBRICK + threadIdx.x < g.nbricks) {
         const float4 bb = meta->bound[threadIdx.x];
         V3T<float> ctr = {bb.x, bb.y, bb.z};
         unsigned long long m0 = 0ull, m1 = 0ull;
@@ -539,12 +539,20 @@ template <typename SRC>
 static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict__ PRM, const float* __restrict__ TAB,
                                                         const SRC& s, const sdfk_rowgeom& g, float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) sdfk_rowmeta meta;
-    unsigned rb, c;
-    sdfk_rows_prepare(PRM, TAB, s, g, &meta, rb, c);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned q0 = blockIdx.x * SDFK_RNBRICK + wave * SDFK_RWBRICKS;
     const int lr = lane / SDFK_RLPR;
     const int zq = (lane % SDFK_RLPR) * (2 * SDFK_NP);
+#ifndef SDFK_RTILES
+#define SDFK_RTILES 1
+#endif
+#pragma unroll 1
+  for (unsigned tt = 0; tt < SDFK_RTILES; ++tt) {
+    const unsigned tile = blockIdx.x * SDFK_RTILES + tt;
+    if (tile * SDFK_RNBRICK >= g.nbricks) break;
+    if (tt) __syncthreads();
+    unsigned rb, c;
+    sdfk_rows_prepare(PRM, TAB, s, g, &meta, tile, rb, c);
+    const unsigned q0 = tile * SDFK_RNBRICK + wave * SDFK_RWBRICKS;
 #pragma unroll 1
     for (int j = 0; j < SDFK_RWBRICKS; ++j) {
         if (q0 + j >= g.nbricks) break;
@@ -603,8 +611,14 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
             }
         }
     }
+  }
 }
-extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_r(
+#ifdef SDFK_WPE
+#define SDFK_ROWS_ATTR __attribute__((amdgpu_waves_per_eu(SDFK_WPE, SDFK_WPE)))
+#else
+#define SDFK_ROWS_ATTR
+#endif
+extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) SDFK_ROWS_ATTR void sdfk_spec_r(
     const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
     sdfk_rowgeom g, float* __restrict__ out) {
     const SrcArray s = {co, stride};
@@ -624,7 +638,7 @@ extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_rmask(
     __shared__ __attribute__((aligned(16))) sdfk_rowmeta meta;
     const SrcArray s = {co, stride};
     unsigned rb, c;
-    sdfk_rows_prepare(PRM, TAB, s, g, &meta, rb, c);
+    sdfk_rows_prepare(PRM, TAB, s, g, &meta, blockIdx.x, rb, c);
     const unsigned q = blockIdx.x * SDFK_RNBRICK + threadIdx.x;
     if (threadIdx.x < SDFK_RNBRICK && q < g.nbricks) {
         masks[3ull * q] = meta.mask0[threadIdx.x];

@@ -12,26 +12,30 @@ streams, the process group), the evaluation itself is libsdfk.so.
 import numpy as np
 
 
-def slab_bounds(n_total, world_size, rank):
-    """(start, count) of rank's contiguous slab; the remainder goes to the last rank."""
+def slab_bounds(n_total, world_size, rank, unit=1):
+    """(start, count) of rank's contiguous slab; the remainder goes to the last rank. Slabs are whole
+    multiples of `unit` points (the grid's row length: the row-block culling kernel wants whole rows)."""
     if not (0 <= rank < world_size):
         raise ValueError("rank %d outside world of %d" % (rank, world_size))
-    per = n_total // world_size
+    if unit < 1 or n_total % unit:
+        raise ValueError("%d points are not whole units of %d" % (n_total, unit))
+    per = (n_total // unit // world_size) * unit
     start = rank * per
     count = per if rank < world_size - 1 else n_total - start
     return start, count
 
 
-def gather_slabs(local, n_total, group=None):
+def gather_slabs(local, n_total, group=None, unit=1):
     """All-gather the per-rank slabs (1-D tensors laid out by slab_bounds) into the full field on every rank."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    start, count = slab_bounds(n_total, world, rank)
+    start, count = slab_bounds(n_total, world, rank, unit)
     if local.numel() != count:
         raise ValueError("rank %d holds %d values, its slab has %d" % (rank, local.numel(), count))
-    pad = n_total - (world - 1) * (n_total // world)          # largest slab (the last one)
+    per = (n_total // unit // world) * unit
+    pad = n_total - (world - 1) * per                         # largest slab (the last one)
     send = local
     if count != pad:
         send = torch.zeros(pad, dtype=local.dtype, device=local.device)
@@ -40,10 +44,9 @@ def gather_slabs(local, n_total, group=None):
     dist.all_gather_into_tensor(full, send.contiguous(), group=group)
     if pad * world == n_total:
         return full
-    per = n_total // world
     out = torch.empty(n_total, dtype=local.dtype, device=local.device)
     for r in range(world):
-        s, c = slab_bounds(n_total, world, r)
+        s, c = slab_bounds(n_total, world, r, unit)
         out[s:s + c] = full[r * pad:r * pad + c]
     return out
 
@@ -61,12 +64,14 @@ def evaluate_grid_sharded(geometry, size, resolution, gather=True, group=None, e
     n_total = int(np.prod([a.size for a in axes64]))
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    start, count = slab_bounds(n_total, world, rank)
+    # whole grid rows per slab (rows run along the last axis longer than one point)
+    unit = int(axes64[2].size) if axes64[2].size > 1 else int(axes64[1].size)
+    start, count = slab_bounds(n_total, world, rank, unit)
     if evaluate_slab is None:
         evaluate_slab = _GpuSlabEvaluator(geometry)
     local = evaluate_slab([a.astype(np.float32) for a in axes64], start, count)
     if gather and world > 1:
-        return gather_slabs(local, n_total, group), res
+        return gather_slabs(local, n_total, group, unit), res
     return local, res
 
 

@@ -1,12 +1,12 @@
 """Developer tool: evaluate every scene on the GPU (both kernel flavours) and print the deviation
-from the golden vectors. Not part of the product or the test-suite."""
+from the golden vectors. Test infrastructure (it may use the oracle), not collected by pytest: python tests/report_gpu_parity.py"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # tests/ -> repo root
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import scenes  # noqa: E402

@@ -24,6 +24,17 @@ def test_slab_bounds_partition_the_index_space():
                 assert s0 + c0 == s1
     with pytest.raises(ValueError):
         slab_bounds(10, 2, 2)
+    # whole grid rows per slab
+    for shape in ((9, 7, 11), (1025, 1025, 1025), (33, 1, 129)):
+        n, unit = shape[0] * shape[1] * shape[2], shape[2]
+        for w in (1, 2, 3, 8):
+            spans = [slab_bounds(n, w, r, unit) for r in range(w)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+            assert all(s % unit == 0 and c % unit == 0 for s, c in spans)
+            for (s0, c0), (s1, _) in zip(spans, spans[1:]):
+                assert s0 + c0 == s1
+    with pytest.raises(ValueError):
+        slab_bounds(10, 2, 0, unit=3)
 
 
 def _free_port():
@@ -56,7 +67,7 @@ def _worker(rank, world, port, resolution, q):
         full, res = evaluate_grid_sharded(tree, (3, 3, 3), resolution, gather=True, evaluate_slab=oracle_slab)
         local, _ = evaluate_grid_sharded(tree, (3, 3, 3), resolution, gather=False, evaluate_slab=oracle_slab)
         n = res[0] * res[1] * res[2]
-        s, c = slab_bounds(n, world, rank)
+        s, c = slab_bounds(n, world, rank, res[2])
         ok = full.numel() == n and local.numel() == c and torch.equal(full[s:s + c], local)
         q.put((rank, bool(ok), full.numpy().copy(), tuple(res)))
     finally:

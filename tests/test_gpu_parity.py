@@ -316,8 +316,8 @@ def test_sharded_evaluation_matches_whole_grid(engine):
     whole = tree.create(co)
     axes = [a.astype(np.float32) for a in grid_axes(size, resolution)[0]]
     ev = _GpuSlabEvaluator(tree)
-    for world in (2, 3, 8):
-        parts = [ev(axes, *slab_bounds(whole.size, world, r)) for r in range(world)]
+    for world, u in ((2, 1), (3, 1), (8, 1), (2, res[2]), (3, res[2]), (8, res[2])):   # arbitrary cuts and whole rows
+        parts = [ev(axes, *slab_bounds(whole.size, world, r, unit)) for r in range(world) for unit in (u,)]
         torch.cuda.synchronize()
         np.testing.assert_array_equal(torch.cat(parts).cpu().numpy(), whole)
 

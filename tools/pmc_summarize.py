@@ -13,7 +13,7 @@ def collect(root, kernel):
     for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
             for row in csv.DictReader(f):
-                if kernel not in row.get("Kernel_Name", ""):
+                if row.get("Kernel_Name", "").split("(")[0].strip() != kernel:      # exact name, not a prefix
                     continue
                 name, val = row["Counter_Name"], float(row["Counter_Value"])
                 did = row.get("Dispatch_Id")
