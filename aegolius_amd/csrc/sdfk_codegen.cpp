@@ -849,29 +849,31 @@ struct Gen {
             const sdfk_cullsite& t = (*sites)[k];
             // (inside [a0, a1] this site is out of reach: its combiner lies beyond a1)
             const std::string ta = bit_test(2 * k), tb = bit_test(2 * k + 1);
+            // first operand (unless irrelevant), then — only if the second one matters — the second operand and the
+            // combiner. Everything the second operand computes lives and dies inside that block, so a skipped
+            // operand costs one scalar branch: no merge copies, no placeholder values.
             s += ind + "if (!" + ta + ") {\n";
             emit_span(t.a0, t.a1, depth + 1);
-            s += ind + "}\n";
-            s += ind + "if (!" + tb + ") {\n";
-            emit_span(t.b0, t.b1, depth + 1);
             s += ind + "}\n";
             const uint32_t w = code[2 * t.comb];
             const unsigned a = (w >> 8) & 255u, b = (w >> 16) & 255u, c = w >> 24;
             char gB[64], gA[64], wx[32];
             bool neg;
             site_ops(t, gB, gA, wx, &neg, sizeof gB);
-            {   // (deep chains indent past any fixed buffer: build the lines as strings)
-                char ra[24], rb_[24], rc[24];
-                snprintf(ra, sizeof ra, "V_%u", a);
-                snprintf(rb_, sizeof rb_, "V_%u", b);
-                snprintf(rc, sizeof rc, "V_%u", c);
-                const std::string e = rows ? "{ SDFK_EACH " : "", x = rows ? "[q]" : "", z = rows ? " }" : "";
-                s += ind + "if " + ta + " " + e + ra + x + " = " + (neg ? "-" : "") + rc + x + ";" + z + "\n";
-                s += ind + "else if " + tb + " " + e + ra + x + " = " + rb_ + x + ";" + z + "\n";
-                s += ind + "else {\n";
-            }
-            instr(t.comb, (ind + "    ").c_str(), rows);
+            char ra[24], rb_[24], rc[24];
+            snprintf(ra, sizeof ra, "V_%u", a);
+            snprintf(rb_, sizeof rb_, "V_%u", b);
+            snprintf(rc, sizeof rc, "V_%u", c);
+            const std::string e = rows ? "{ SDFK_EACH " : "", x = rows ? "[q]" : "", z = rows ? " }" : "";
+            const std::string in2 = ind + "    ";
+            s += ind + "if (!" + tb + ") {\n";
+            emit_span(t.b0, t.b1, depth + 1);
+            s += in2 + "if " + ta + " " + e + ra + x + " = " + (neg ? "-" : "") + rc + x + ";" + z + "\n";
+            s += in2 + "else {\n";
+            instr(t.comb, (in2 + "    ").c_str(), rows);
+            s += in2 + "}\n";
             s += ind + "}\n";
+            if (a != b) s += ind + "else " + e + ra + x + " = " + rb_ + x + ";" + z + "\n";
             i = t.comb + 1;
         }
     }
