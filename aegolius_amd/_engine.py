@@ -32,6 +32,13 @@ SIGNATURES = {
     "sdfk_eval_device": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _int]),
     "sdfk_eval_device_rows": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int]),
     "sdfk_debug_row_masks": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _c.POINTER(_i64), _c.POINTER(_int), _vp]),
+    "sdfk_eval_grid_sharded": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _int, _vp, _vp, _int]),
+    "sdfk_eval_device_aux": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _i64, _vp, _vp, _int]),
+    "sdfk_eval_grid_aux": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _int, _i64, _vp, _vp, _int]),
+    "sdfk_field_min": (_int, [_vp, _i64, _c.POINTER(_c.c_float), _vp]),
+    "sdfk_grid_box_average": (_int, [_vp, _i64, _i64, _i64, _int, _int, _int, _int, _vp]),
+    "sdfk_grid_edge_detect": (_int, [_vp, _i64, _i64, _i64, _vp]),
+    "sdfk_grid_signed": (_int, [_vp, _i64, _i64, _i64, _c.c_float, _int, _vp]),
     "sdfk_eval_host": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _int, _int]),
     "sdfk_eval_grid": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _int]),
     "sdfk_eval_grid_host": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _int, _int]),
@@ -188,6 +195,20 @@ class Program:
         out = np.empty(count, dtype=np.float32)
         check(lib().sdfk_eval_grid_host(self._h, _ptr(ax[0]), ax[0].size, _ptr(ax[1]), ax[1].size, _ptr(ax[2]),
                                         ax[2].size, start, count, _ptr(out), device, mode), "sdfk_eval_grid_host")
+        return out
+
+    def eval_grid_sharded(self, axes, n_shards, devices=None, mode=MODE_AUTO):
+        """Whole grid, cut into `n_shards` slabs of whole rows evaluated concurrently on `devices`
+        (default: shard d on device d modulo the device count), field returned as one host array."""
+        require_gpu()
+        ax = [np.ascontiguousarray(a, dtype=np.float32) for a in axes]
+        out = np.empty(ax[0].size * ax[1].size * ax[2].size, dtype=np.float32)
+        dev = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
+        if dev is not None and dev.size != n_shards:
+            raise ValueError("one device per shard")
+        check(lib().sdfk_eval_grid_sharded(self._h, _ptr(ax[0]), ax[0].size, _ptr(ax[1]), ax[1].size, _ptr(ax[2]),
+                                           ax[2].size, n_shards, _ptr(dev) if dev is not None else None, _ptr(out),
+                                           mode), "sdfk_eval_grid_sharded")
         return out
 
     def __del__(self):

@@ -55,8 +55,198 @@ def _run(lowered, co):
 
 
 def evaluate_geometry(node, co):
-    return _run(lower_geometry(node), co)
+    return _evaluate(lambda **kw: lower_geometry(node, **kw), co, node.modified_object)
 
 
 def evaluate_expr(expr, co, params):
-    return _run(lower_expression(expr, params), co)
+    return _evaluate(lambda **kw: lower_expression(expr, params, **kw), co, expr)
+
+
+def _evaluate(lower, co, root=None):
+    from ._lower import NeedsStage
+    try:
+        lowered = lower()
+    except NeedsStage:
+        return _run_staged(lower, co, root)
+    return _run(lowered, co)
+
+
+# ---------------------------------------------------------------------------------------------------
+# staged evaluation: trees with grid-neighbourhood operators (signed, conv_averaging, conv_edge_detection)
+# ---------------------------------------------------------------------------------------------------
+def _grid_shape(n, resolution):
+    """Shape smarter_reshape gives an (n,) field (reference cores/helper_functions.py:96-148)."""
+    from .cores.helper_functions import resolution_conversion
+    res = [resolution_conversion(int(r)) for r in np.atleast_1d(np.asarray(resolution)).ravel()]
+    if len(res) == 1:
+        r = res[0]
+        for shape in ((r,), (r, r), (r, r, r)):
+            if n // int(np.prod(shape)) == 1:
+                return shape
+        raise ValueError("Cannot reshape the pattern with shape (%d,)" % n)
+    if len(res) == 2:
+        div = n // (res[0] * res[1])
+        shape = (res[0], res[1]) if div == 1 else (res[0], res[1], int(div))
+    elif len(res) == 3:
+        div = n // (res[0] * res[1] * res[2])
+        if div != 1:
+            raise ValueError("Cannot reshape the pattern with shape (%d,)" % n)
+        shape = tuple(res)
+    else:
+        raise ValueError("resolution must have 1, 2 or 3 entries")
+    if int(np.prod(shape)) != n:
+        raise ValueError("cannot reshape array of size %d into shape %r" % (n, shape))
+    return shape
+
+
+def _plan_stages(lower):
+    """[(stage program, operator node)], final program: every grid operator gets the field of its inner
+    expression from the stage before it (innermost / first-met operators first)."""
+    from ._lower import NeedsStage
+    fields, stages = {}, []
+    while True:
+        try:
+            return stages, lower(fields=fields), fields
+        except NeedsStage as need:
+            target = need.expr
+        while True:
+            try:
+                prog = lower(fields=fields, stop_at=target)
+                break
+            except NeedsStage as inner:            # an operator nested in (or met before) the target: that one first
+                target = inner.expr
+        stages.append((prog, target))
+        fields[id(target)] = len(fields)
+        if len(fields) > 32:
+            raise NotImplementedError("more than 32 grid-neighbourhood operators in one tree")
+
+
+def _apply_grid_op(lib, node, d_field, n, lower, fields, points4):
+    """Run one operator in place on a device field of n points."""
+    name, args = node.name, node.args
+    shape = _grid_shape(n, args["co_resolution"])
+    dims = tuple(shape) + (1,) * (3 - len(shape))
+    vp = _engine._vp
+    if name == "conv_averaging":
+        ks = args["kernel_size"]
+        if isinstance(ks, (int, np.integer)):
+            ks = (int(ks),) * len(shape)
+        ks = tuple(int(k) for k in np.asarray(ks).ravel())
+        if len(ks) != len(shape):
+            raise ValueError("Dimension of the kernel and the field must match!")
+        ks = ks + (1,) * (3 - len(ks))
+        _engine.check(lib.sdfk_grid_box_average(vp(d_field), dims[0], dims[1], dims[2], ks[0], ks[1], ks[2],
+                                                int(args["iterations"]), None), "sdfk_grid_box_average")
+    elif name == "conv_edge_detection":
+        _engine.check(lib.sdfk_grid_edge_detect(vp(d_field), dims[0], dims[1], dims[2], None), "sdfk_grid_edge_detect")
+    else:                                           # signed, signed_old
+        if len(shape) != 3:
+            raise ValueError("Dimension of the kernel and the field must match!")      # conv_averaging((2, 2, 1)) on 2-D
+        # grid spacings as the operator sees them: coordinate i of the neighbour along axis i minus that of point 0
+        seps = []
+        for axis in range(3):
+            vals = _eval_few(lib, lower(fields=fields, stop_at=node, probe_axis=axis), points4, len(fields))
+            seps.append(abs(float(vals[1 + axis]) - float(vals[0])))
+        _engine.check(lib.sdfk_grid_signed(vp(d_field), dims[0], dims[1], dims[2], float(np.float32(min(seps))),
+                                           0 if name == "signed_old" else 1, None), "sdfk_grid_signed")
+
+
+def _eval_few(lib, lowered, points, n_aux):
+    """A program on a handful of points (fields of earlier stages, if it reads any, are dead code there: zeros)."""
+    m = int(points.shape[1])
+    vp = _engine._vp
+    host = np.zeros((3 + max(n_aux, 1) + 1, 64), dtype=np.float32)
+    host[:3, :m] = points
+    d = lib.sdfk_malloc(host.nbytes)
+    if not d:
+        raise _engine.SdfkError("staged evaluation: out of device memory")
+    try:
+        _engine.check(lib.sdfk_memcpy_h2d(vp(d), _engine._ptr(host), host.nbytes), "h2d")
+        d_aux, d_out = d + 4 * 3 * 64, d + 4 * (3 + max(n_aux, 1)) * 64
+        _engine.check(lib.sdfk_eval_device_aux(program_for(lowered).handle, vp(d), m, 64, vp(d_aux), max(n_aux, 1), 64,
+                                               vp(d_out), None, config.mode), "sdfk_eval_device_aux")
+        _engine.check(lib.sdfk_sync(None), "sdfk_sync")
+        out = np.empty(m, dtype=np.float32)
+        _engine.check(lib.sdfk_memcpy_d2h(_engine._ptr(out), vp(d_out), m * 4), "d2h")
+        return out
+    finally:
+        lib.sdfk_free(vp(d))
+
+
+def _edge_detection_is_outermost(expr):
+    """conv_edge_detection returns the GRID-shaped array (reference cores/modifications.py:1631-1634: no flatten);
+    when nothing but pointwise value operations follows, that is the shape create() hands back."""
+    from ._ir import ModSDF, NodeSDF
+    while True:
+        if isinstance(expr, NodeSDF):
+            expr = expr.obj.modified_object
+        elif isinstance(expr, ModSDF):
+            if expr.name == "conv_edge_detection":
+                return expr
+            expr = expr.inner
+        else:
+            return None
+
+
+def _run_staged(lower, co, root=None):
+    _engine.require_gpu()
+    lib = _engine.lib()
+    _engine.check(lib.sdfk_set_device(config.device), "sdfk_set_device")
+    stages, final, fields = _plan_stages(lower)
+    n = int(co.shape[1])
+    axes = getattr(co, "grid_axes", None) if config.grid_fast_path else None
+    vp = _engine._vp
+    stride = (n + 63) // 64 * 64
+    d_aux = lib.sdfk_malloc(len(stages) * stride * 4)
+    d_out = lib.sdfk_malloc(stride * 4)
+    d_co = None
+    if not d_aux or not d_out:
+        raise _engine.SdfkError("staged evaluation: out of device memory")
+    try:
+        if axes is None:
+            host = np.ascontiguousarray(co, dtype=np.float32)
+            if host.shape[0] != 3:
+                raise ValueError("coordinates must have shape (3, N)")
+            d_co = lib.sdfk_malloc(3 * stride * 4)
+            if not d_co:
+                raise _engine.SdfkError("staged evaluation: out of device memory")
+            for r in range(3):
+                _engine.check(lib.sdfk_memcpy_h2d(vp(d_co + 4 * r * stride), _engine._ptr(host[r]), n * 4), "h2d")
+        ax = None if axes is None else [np.ascontiguousarray(a, dtype=np.float32) for a in axes]
+
+        def run_program(lowered, d_dst, n_aux):
+            prog = program_for(lowered)
+            if ax is not None:
+                _engine.check(lib.sdfk_eval_grid_aux(prog.handle, _engine._ptr(ax[0]), ax[0].size, _engine._ptr(ax[1]),
+                                                     ax[1].size, _engine._ptr(ax[2]), ax[2].size, 0, n, vp(d_aux), n_aux,
+                                                     stride, vp(d_dst), None, config.mode), "sdfk_eval_grid_aux")
+            else:
+                _engine.check(lib.sdfk_eval_device_aux(prog.handle, vp(d_co), n, stride, vp(d_aux), n_aux, stride,
+                                                       vp(d_dst), None, config.mode), "sdfk_eval_device_aux")
+                _engine.check(lib.sdfk_sync(None), "sdfk_sync")
+
+        # the 4 points `signed` reads its grid spacings from: point 0 and its neighbour along each axis
+        points4 = None
+        known = {}
+        for k, (lowered, node) in enumerate(stages):
+            run_program(lowered, d_aux + 4 * k * stride, k)
+            if node.name in ("signed", "signed_old") and points4 is None:
+                shape = _grid_shape(n, node.args["co_resolution"])
+                if len(shape) == 3:
+                    idx = [0, shape[1] * shape[2], shape[2], 1]
+                    points4 = np.stack([np.asarray(co[r])[idx] for r in range(3)]).astype(np.float64)
+            _apply_grid_op(lib, node, d_aux + 4 * k * stride, n, lower, known, points4)
+            known[id(node)] = k
+        run_program(final, d_out, len(stages))
+        out = np.empty(n, dtype=np.float32)
+        _engine.check(lib.sdfk_memcpy_d2h(_engine._ptr(out), vp(d_out), n * 4), "d2h")
+    finally:
+        for d in (d_aux, d_out, d_co):
+            if d:
+                lib.sdfk_free(vp(d))
+    if config.output_dtype is not np.float32:
+        out = out.astype(config.output_dtype)
+    edge = _edge_detection_is_outermost(root) if root is not None else None
+    if edge is not None:
+        out = out.reshape(_grid_shape(n, edge.args["co_resolution"]))
+    return out

@@ -51,6 +51,23 @@ class LoweredProgram:
         return self.n_creg <= _ops.INTERP_NC and self.n_vreg <= _ops.INTERP_NV
 
 
+class NeedsStage(Exception):
+    """Lowering met a grid-neighbourhood operator (signed / conv_*) whose input field has not been computed
+    by an earlier evaluation stage yet (see _eval._run_staged)."""
+
+    def __init__(self, expr):
+        Exception.__init__(self, "grid-neighbourhood operator %r needs a staged evaluation" % (expr.name,))
+        self.expr = expr
+
+
+class StageStop(Exception):
+    """Raised at the operator a stage program stops at: `vreg` holds the value that stage has to produce."""
+
+    def __init__(self, vreg):
+        Exception.__init__(self)
+        self.vreg = vreg
+
+
 class Lowerer:
     def __init__(self):
         self.code = []
@@ -63,6 +80,9 @@ class Lowerer:
         self.lip_c = {0: 1.0}      # Lipschitz bound of each register w.r.t. the root point (_lipschitz.py)
         self.lip_v = {}
         self.cull = []             # (combiner index, a_start, a_end, b_start, b_end, K)
+        self.fields = {}           # id(grid-operator node) -> auxiliary field index (fields of earlier stages)
+        self.stop_at = None        # grid-operator node this (stage) program ends at
+        self.probe_axis = None     # with stop_at: produce coordinate component `probe_axis` there instead
         self._fold_floor = 0       # instructions below this index are never merged into (range boundaries)
         self._affine = {}          # instruction index -> (A (3,3), c (3,)) of an affine coordinate op, float64
 
@@ -301,10 +321,23 @@ def as_expr(fn):
                               "aegolius_amd geometry, or obj.propagate" % (fn,))
 
 
-def lower_geometry(node):
-    """Lower `node.create(co)` to a program."""
-    L = Lowerer()
-    v = L.lower_node(node, 0, OWNED)
+def _staged(L, fields, stop_at, probe_axis):
+    L.fields = dict(fields or {})
+    L.stop_at = stop_at
+    L.probe_axis = probe_axis
+    return L
+
+
+def lower_geometry(node, fields=None, stop_at=None, probe_axis=None):
+    """Lower `node.create(co)` to a program. `fields` / `stop_at` / `probe_axis`: stage programs of a tree with
+    grid-neighbourhood operators (see _eval._run_staged)."""
+    L = _staged(Lowerer(), fields, stop_at, probe_axis)
+    try:
+        v = L.lower_node(node, 0, OWNED)
+    except StageStop as stop:
+        return L.finish(stop.vreg)
+    if stop_at is not None:
+        raise LoweringError("stage operator not reached")
     return L.finish(v)
 
 
@@ -319,9 +352,14 @@ class _ExprNode:
         self._geo_parameters = tuple(params)
 
 
-def lower_expression(expr, params):
+def lower_expression(expr, params, fields=None, stop_at=None, probe_axis=None):
     # a bare closure call gets the caller's array itself (no private copy): OWNED is safe because the
     # register is loaded from memory and the caller's array is never written
-    L = Lowerer()
-    v = L.lower_expr(expr, 0, OWNED, tuple(params))
+    L = _staged(Lowerer(), fields, stop_at, probe_axis)
+    try:
+        v = L.lower_expr(expr, 0, OWNED, tuple(params))
+    except StageStop as stop:
+        return L.finish(stop.vreg)
+    if stop_at is not None:
+        raise LoweringError("stage operator not reached")
     return L.finish(v)

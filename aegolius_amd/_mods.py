@@ -408,9 +408,38 @@ def _unsupported(reason):
     return fn
 
 
-for _n in ("signed", "signed_old", "conv_averaging", "conv_edge_detection"):
-    MOD_LOWER[_n] = _unsupported("grid-neighbourhood operation (needs the whole field); not part of the fused "
-                                 "per-point GPU pass yet")
+# ------------------------------------------------------------------------------------------------
+# grid-neighbourhood operators  C/modifications.py:163-275 (signed_old, signed), :1589-1637 (conv_*)
+# They need the whole field of their inner expression: the evaluation is cut into stages at these nodes
+# (_eval._run_staged). In a program they are either the point where a stage stops or a V_FIELD read of the
+# field an earlier stage produced.
+# ------------------------------------------------------------------------------------------------
+GRID_OPS = ("signed", "signed_old", "conv_averaging", "conv_edge_detection")
+
+
+def _grid_op(L, e, creg, mode, params):
+    from ._lower import NeedsStage, StageStop
+    idx = L.fields.get(id(e))
+    if idx is not None:
+        v = L.new_v()
+        L.emit("V_FIELD", v, creg, idx)
+        return v
+    if L.stop_at is e:
+        if L.probe_axis is not None:            # the coordinates this operator is handed (signed: grid spacings)
+            v = L.new_v()
+            L.emit("P_AXIS", v, creg, params=[0.0, float(L.probe_axis)])
+        else:
+            v = L.lower_expr(e.inner, creg, mode, params)
+        raise StageStop(v)
+    if L.stop_at is not None:
+        # on the way to another operator: if that one lies inside this one, StageStop passes through here;
+        # if not, this operator is met first and must get its own stage first
+        L.lower_expr(e.inner, creg, mode, params)
+    raise NeedsStage(e)
+
+
+for _n in GRID_OPS:
+    MOD_LOWER[_n] = _grid_op
 for _n in ("custom_modification", "custom_post_process"):
     MOD_LOWER[_n] = _unsupported("opaque Python callable cannot be fused into the GPU evaluation")
 

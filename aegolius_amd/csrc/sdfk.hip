@@ -21,6 +21,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -61,7 +62,8 @@ template <int VEC, typename SRC>
 __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_interp_kernel(const uint2* __restrict__ code, int n_instr,
                                                                 const float* __restrict__ prm,
                                                                 const float* __restrict__ tab, SRC src, long long off,
-                                                                long long n, float* __restrict__ out, int result_reg) {
+                                                                long long n, float* __restrict__ out, int result_reg,
+                                                                const float* __restrict__ aux, long long aux_stride) {
     const long long block_base = (long long)blockIdx.x * (SDFK_BLOCK * VEC);
     const unsigned lane_off = threadIdx.x * VEC;
     if (block_base + lane_off >= n) return;
@@ -72,6 +74,11 @@ __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_interp_kernel(const uint2* __
         const uint2 ins = code[pc];  // wave-uniform -> scalar load
         const unsigned op = ins.x & 255u, a = (ins.x >> 8) & 255u, b = (ins.x >> 16) & 255u, c = ins.x >> 24;
         const float* __restrict__ P = prm + ins.y;
+        if (op == SDFK_OP_V_FIELD) {   // auxiliary field c at this lane's points (validated: aux != nullptr)
+            _Pragma("unroll") for (int v = 0; v < VEC; ++v)
+                V[a][v] = sdfk_aux<float>(aux + off + block_base + lane_off + v, aux_stride, (int)c);
+            continue;
+        }
         switch (op) {
 #define SDFK_EXEC_C_C(F) \
     _Pragma("unroll") for (int v = 0; v < VEC; ++v) C[a][v] = F(C[b][v], P, tab, (int)c)
@@ -161,6 +168,7 @@ struct sdfk_program {
     std::vector<float> params, tables;
     int result_reg = 0;
     bool interp_ok = true;  // fits the interpreter's register file
+    int n_aux = 0;          // auxiliary per-point fields read by V_FIELD instructions
     unsigned long long params_version = 1;
     std::string key;
     std::string source;
@@ -263,6 +271,14 @@ static int validate(sdfk_program* p, std::string* why) {
             snprintf(buf, sizeof buf, "instruction %zu (%s): reads a register that was never written", i, info.name);
             *why = buf;
             return 0;
+        }
+        if (op == SDFK_OP_V_FIELD) {
+            if (c >= 32) {
+                snprintf(buf, sizeof buf, "instruction %zu: auxiliary field index %u out of range (32)", i, c);
+                *why = buf;
+                return 0;
+            }
+            p->n_aux = std::max(p->n_aux, (int)c + 1);
         }
         if (op == SDFK_OP_SYMMETRY && c > 2) {
             snprintf(buf, sizeof buf, "instruction %zu: symmetry axis %u out of range", i, c);
@@ -388,6 +404,7 @@ extern "C" int sdfk_program_set_cull(sdfk_program* p, const uint32_t* rows, size
     std::lock_guard<std::mutex> lk(p->mu);
     if (!p->source.empty() || !p->dev.empty())
         return fail(-2, "sdfk_program_set_cull: must be called before the program is first used");
+    if (p->n_aux > 0) n_sites = 0;   // auxiliary fields have no Lipschitz bound and the culling kernels do not carry them
     const size_t n = p->code.size() / 2;
     std::vector<sdfk_cullsite> sites;
     for (size_t i = 0; i < n_sites; ++i) {
@@ -597,9 +614,11 @@ static inline unsigned blocks_for(long long n, int vec) {
 }
 
 static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long long n, float* d_out, void* stream_,
-               int mode, bool vec_ok, long long row_len = 0) {
+               int mode, bool vec_ok, long long row_len = 0, const float* aux = nullptr, long long aux_stride = 0) {
     if (!p) return fail(-1, "null program");
     if (n < 0) return fail(-1, "negative point count");
+    if (p->n_aux > 0 && (!aux || aux_stride < n))
+        return fail(-1, "this program reads auxiliary fields (staged evaluation): use sdfk_eval_device_aux / sdfk_eval_grid_aux");
     if (n == 0) return 0;
     if (mode == SDFK_MODE_AUTO) mode = g_default_mode;
     hipStream_t stream = (hipStream_t)stream_;
@@ -679,13 +698,13 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
             long long stride = arr->stride;
             if (n4) {
                 long long off = 0;
-                void* args[] = {&prm, &tab, &co, &stride, &off, &n4, &d_out};
+                void* args[] = {&prm, &tab, &co, &stride, &off, &n4, &d_out, &aux, &aux_stride};
                 HIPCHK(hipModuleLaunchKernel(sk->v4, blocks_for(n4, 4), 1, 1, SDFK_BLOCK, 1, 1, 0, stream, args,
                                              nullptr));
             }
             if (tail) {
                 long long off = n4;
-                void* args[] = {&prm, &tab, &co, &stride, &off, &tail, &d_out};
+                void* args[] = {&prm, &tab, &co, &stride, &off, &tail, &d_out, &aux, &aux_stride};
                 HIPCHK(hipModuleLaunchKernel(sk->v1, blocks_for(tail, 1), 1, 1, SDFK_BLOCK, 1, 1, 0, stream, args,
                                              nullptr));
             }
@@ -693,13 +712,13 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
             SrcGrid g = *grid;
             if (n4) {
                 long long off = 0;
-                void* args[] = {&prm, &tab, &g, &off, &n4, &d_out};
+                void* args[] = {&prm, &tab, &g, &off, &n4, &d_out, &aux, &aux_stride};
                 HIPCHK(hipModuleLaunchKernel(sk->g4, blocks_for(n4, 4), 1, 1, SDFK_BLOCK, 1, 1, 0, stream, args,
                                              nullptr));
             }
             if (tail) {
                 long long off = n4;
-                void* args[] = {&prm, &tab, &g, &off, &tail, &d_out};
+                void* args[] = {&prm, &tab, &g, &off, &tail, &d_out, &aux, &aux_stride};
                 HIPCHK(hipModuleLaunchKernel(sk->g1, blocks_for(tail, 1), 1, 1, SDFK_BLOCK, 1, 1, 0, stream, args,
                                              nullptr));
             }
@@ -712,17 +731,17 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
     if (arr) {
         if (n4)
             hipLaunchKernelGGL((sdfk_interp_kernel<4, SrcArray>), dim3(blocks_for(n4, 4)), dim3(SDFK_BLOCK), 0, stream,
-                               d->d_code, n_instr, prm, tab, *arr, zero, n4, d_out, p->result_reg);
+                               d->d_code, n_instr, prm, tab, *arr, zero, n4, d_out, p->result_reg, aux, aux_stride);
         if (tail)
             hipLaunchKernelGGL((sdfk_interp_kernel<1, SrcArray>), dim3(blocks_for(tail, 1)), dim3(SDFK_BLOCK), 0,
-                               stream, d->d_code, n_instr, prm, tab, *arr, n4, tail, d_out, p->result_reg);
+                               stream, d->d_code, n_instr, prm, tab, *arr, n4, tail, d_out, p->result_reg, aux, aux_stride);
     } else {
         if (n4)
             hipLaunchKernelGGL((sdfk_interp_kernel<4, SrcGrid>), dim3(blocks_for(n4, 4)), dim3(SDFK_BLOCK), 0, stream,
-                               d->d_code, n_instr, prm, tab, *grid, zero, n4, d_out, p->result_reg);
+                               d->d_code, n_instr, prm, tab, *grid, zero, n4, d_out, p->result_reg, aux, aux_stride);
         if (tail)
             hipLaunchKernelGGL((sdfk_interp_kernel<1, SrcGrid>), dim3(blocks_for(tail, 1)), dim3(SDFK_BLOCK), 0,
-                               stream, d->d_code, n_instr, prm, tab, *grid, n4, tail, d_out, p->result_reg);
+                               stream, d->d_code, n_instr, prm, tab, *grid, n4, tail, d_out, p->result_reg, aux, aux_stride);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -748,6 +767,16 @@ extern "C" int sdfk_eval_device_rows(sdfk_program* p, const float* d_co, int64_t
     SrcArray a = {d_co, (long long)row_stride};
     bool vec_ok = aligned16(d_co) && aligned16(d_out) && (row_stride % 4 == 0);
     return run(p, &a, nullptr, n, d_out, stream, mode, vec_ok, row_len);
+}
+
+extern "C" int sdfk_eval_device_aux(sdfk_program* p, const float* d_co, int64_t n, int64_t row_stride, const float* d_aux,
+                                    int n_aux, int64_t aux_stride, float* d_out, void* stream, int mode) {
+    if (!p || !d_co || !d_out) return fail(-1, "sdfk_eval_device_aux: null pointer");
+    if (row_stride < n) return fail(-1, "sdfk_eval_device_aux: row stride smaller than the point count");
+    if (n_aux < p->n_aux) return fail(-1, "sdfk_eval_device_aux: the program reads more auxiliary fields than were passed");
+    SrcArray a = {d_co, (long long)row_stride};
+    bool vec_ok = aligned16(d_co) && aligned16(d_out) && (row_stride % 4 == 0);
+    return run(p, &a, nullptr, n, d_out, stream, mode, vec_ok, 0, d_aux, aux_stride);
 }
 
 extern "C" int sdfk_debug_row_masks(sdfk_program* p, const float* d_co, int64_t n, int64_t row_stride, int64_t row_len,
@@ -860,6 +889,22 @@ extern "C" int sdfk_eval_grid(sdfk_program* p, const float* ax0, int64_t n0, con
     return 0;
 }
 
+extern "C" int sdfk_eval_grid_aux(sdfk_program* p, const float* ax0, int64_t n0, const float* ax1, int64_t n1,
+                                  const float* ax2, int64_t n2, int64_t start, int64_t count, const float* d_aux, int n_aux,
+                                  int64_t aux_stride, float* d_out, void* stream, int mode) {
+    if (!p || !d_out) return fail(-1, "sdfk_eval_grid_aux: null pointer");
+    if (start < 0 || count < 0 || start + count > n0 * n1 * n2) return fail(-1, "sdfk_eval_grid_aux: range outside the grid");
+    if (n_aux < p->n_aux) return fail(-1, "sdfk_eval_grid_aux: the program reads more auxiliary fields than were passed");
+    AxisTables t;
+    SrcGrid g;
+    int rc = upload_axes(ax0, n0, ax1, n1, ax2, n2, (hipStream_t)stream, &t, &g, start);
+    if (rc) return rc;
+    rc = run(p, nullptr, &g, count, d_out, stream, mode, aligned16(d_out), 0, d_aux, aux_stride);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));  // the axis tables are freed on return
+    return 0;
+}
+
 // Host-buffer convenience for grids: evaluate flat indices [start, start+count) of the grid in device chunks
 // and copy the field back; no coordinate array ever exists (host or device).
 extern "C" int sdfk_eval_grid_host(sdfk_program* p, const float* ax0, int64_t n0, const float* ax1, int64_t n1,
@@ -887,6 +932,40 @@ extern "C" int sdfk_eval_grid_host(sdfk_program* p, const float* ax0, int64_t n0
     }
     (void)hipFree(d_out);
     return rc;
+}
+
+// One process, several devices: device d evaluates the d-th slab of whole grid rows and copies it into its part of
+// the host field; the slabs run concurrently (one host thread per device). The per-device state of a program and
+// the kernel cache are keyed by device, so this is sdfk_eval_grid_host once per slab.
+extern "C" int sdfk_eval_grid_sharded(sdfk_program* p, const float* ax0, int64_t n0, const float* ax1, int64_t n1,
+                                      const float* ax2, int64_t n2, int n_shards, const int* devices, float* out,
+                                      int mode) {
+    if (!p || !out) return fail(-1, "sdfk_eval_grid_sharded: null argument");
+    if (n_shards < 1 || n_shards > 64) return fail(-1, "sdfk_eval_grid_sharded: 1..64 shards");
+    if (!ax0 || !ax1 || !ax2 || n0 < 1 || n1 < 1 || n2 < 1) return fail(-1, "grid axes missing or empty");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return fail(-8, "sdfk_eval_grid_sharded: no HIP device");
+    const int64_t total = n0 * n1 * n2, unit = n2 > 1 ? n2 : n1;
+    const int64_t per = (total / unit / n_shards) * unit;
+    std::vector<int> rc((size_t)n_shards, 0);
+    std::vector<std::string> msg((size_t)n_shards);
+    std::vector<std::thread> workers;
+    for (int d = 0; d < n_shards; ++d) {
+        const int dev = devices ? devices[d] : d % n_dev;
+        if (dev < 0 || dev >= n_dev) return fail(-1, "sdfk_eval_grid_sharded: device index out of range");
+    }
+    for (int d = 0; d < n_shards; ++d) {
+        const int dev = devices ? devices[d] : d % n_dev;
+        const int64_t start = d * per, count = d < n_shards - 1 ? per : total - start;
+        workers.emplace_back([=, &rc, &msg] {
+            rc[(size_t)d] = count > 0 ? sdfk_eval_grid_host(p, ax0, n0, ax1, n1, ax2, n2, start, count, out + start, dev, mode) : 0;
+            if (rc[(size_t)d]) msg[(size_t)d] = sdfk_last_error();     // thread-local: carry it to the caller's thread
+        });
+    }
+    for (std::thread& t : workers) t.join();
+    for (int d = 0; d < n_shards; ++d)
+        if (rc[(size_t)d]) return fail(rc[(size_t)d], "shard " + std::to_string(d) + ": " + msg[(size_t)d]);
+    return 0;
 }
 
 extern "C" int sdfk_grid_fill(float* d_co, int64_t row_stride, const float* ax0, int64_t n0, const float* ax1,
@@ -1033,3 +1112,5 @@ extern "C" int sdfk_stream_probe(const float* d_co, int64_t n, int64_t row_strid
     HIPCHK(hipGetLastError());
     return 0;
 }
+
+#include "sdfk_gridops.inc"

@@ -13,45 +13,47 @@ static const char kWrappers[] = R"SDFKW(
 template <int VEC, typename SRC>
 static __device__ __forceinline__ void sdfk_body(const float* __restrict__ PRM, const float* __restrict__ TAB,
                                                  const SRC& src, long long off, long long n,
-                                                 float* __restrict__ out) {
+                                                 float* __restrict__ out, const float* __restrict__ aux,
+                                                 long long aux_stride) {
     const long long block_base = (long long)blockIdx.x * (SDFK_BLOCK * VEC);
     const unsigned lane_off = threadIdx.x * VEC;
     if (block_base + lane_off >= n) return;
     V3 p[VEC];
     sdfk_load<VEC>(src, off + block_base, lane_off, p);
+    const float* ax = aux + (off + block_base + lane_off);   // only dereferenced by V_FIELD instructions
     float v[VEC];
     if constexpr (VEC == 4) {
         // two points per lane value: packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32)
-        const f2 ra = sdfk_point<f2>(sd_join(p[0], p[1]), PRM, TAB);
-        const f2 rb = sdfk_point<f2>(sd_join(p[2], p[3]), PRM, TAB);
+        const f2 ra = sdfk_point<f2>(sd_join(p[0], p[1]), PRM, TAB, ax, aux_stride);
+        const f2 rb = sdfk_point<f2>(sd_join(p[2], p[3]), PRM, TAB, ax + 2, aux_stride);
         v[0] = ra.x; v[1] = ra.y; v[2] = rb.x; v[3] = rb.y;
     } else {
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) v[k] = sdfk_point<float>(p[k], PRM, TAB);
+        for (int k = 0; k < VEC; ++k) v[k] = sdfk_point<float>(p[k], PRM, TAB, ax + k, aux_stride);
     }
     sdfk_store<VEC>(out, off + block_base + lane_off, v);
 }
 extern "C" __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_spec_v4(
     const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
-    long long off, long long n, float* __restrict__ out) {
+    long long off, long long n, float* __restrict__ out, const float* __restrict__ aux, long long aux_stride) {
     SrcArray s = {co, stride};
-    sdfk_body<4>(PRM, TAB, s, off, n, out);
+    sdfk_body<4>(PRM, TAB, s, off, n, out, aux, aux_stride);
 }
 extern "C" __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_spec_v1(
     const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
-    long long off, long long n, float* __restrict__ out) {
+    long long off, long long n, float* __restrict__ out, const float* __restrict__ aux, long long aux_stride) {
     SrcArray s = {co, stride};
-    sdfk_body<1>(PRM, TAB, s, off, n, out);
+    sdfk_body<1>(PRM, TAB, s, off, n, out, aux, aux_stride);
 }
 extern "C" __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_spec_g4(
     const float* __restrict__ PRM, const float* __restrict__ TAB, SrcGrid g, long long off, long long n,
-    float* __restrict__ out) {
-    sdfk_body<4>(PRM, TAB, g, off, n, out);
+    float* __restrict__ out, const float* __restrict__ aux, long long aux_stride) {
+    sdfk_body<4>(PRM, TAB, g, off, n, out, aux, aux_stride);
 }
 extern "C" __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_spec_g1(
     const float* __restrict__ PRM, const float* __restrict__ TAB, SrcGrid g, long long off, long long n,
-    float* __restrict__ out) {
-    sdfk_body<1>(PRM, TAB, g, off, n, out);
+    float* __restrict__ out, const float* __restrict__ aux, long long aux_stride) {
+    sdfk_body<1>(PRM, TAB, g, off, n, out, aux, aux_stride);
 }
 )SDFKW";
 
@@ -716,6 +718,11 @@ struct Gen {
         const unsigned op = w & 255u, a = (w >> 8) & 255u, b = (w >> 16) & 255u, c = w >> 24;
         if ((int)op >= n_ops) return;
         const sdfk_opinfo& o = ops[op];
+        if (!strcmp(o.name, "V_FIELD")) {   // only ever reached for the plain kernels (programs with fields have no sites)
+            snprintf(buf, sizeof buf, "%sV_%u = sdfk_aux<T>(AUX, AUXS, %u);\n", indent, a, c);
+            s += buf;
+            return;
+        }
         const char* e = arr ? "SDFK_EACH " : "";
         const char* x = arr ? "[q]" : "";
         switch (o.kind) {
@@ -913,7 +920,8 @@ std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32
     g.s += "\n";
     g.s += kEmbeddedAccess;
     g.s += "\ntemplate <typename T> static __device__ __forceinline__ T sdfk_point(V3T<T> C_0, "
-           "const float* __restrict__ PRM, const float* __restrict__ TAB) {\n";
+           "const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ AUX, "
+           "long long AUXS) {\n";
     g.declare("V3T<T>", "T", false);
     for (size_t i = 0; i < n_instr; ++i) g.instr(i, "    ");
     char buf[64];

@@ -684,6 +684,18 @@ template <typename T> SDFK_DEV T cmb_extrude(T a, T b, const float* __restrict__
     return sd_min0(sd_max(a, b)) + sd_len2(sd_max0(a), sd_max0(b));
 }
 
+// V_FIELD: the value of an auxiliary per-point field (the output of an earlier evaluation stage that went through a
+// grid-neighbourhood operator). The kernels read it themselves (they know the point index): sdfk_aux below; this
+// placeholder only keeps the opcode table uniform.
+template <typename T> SDFK_DEV T prim_field(V3T<T>, const float* __restrict__, const float* __restrict__) { return sp<T>(0.0f); }
+// AUX points at this lane's first point in auxiliary row 0, rows are AUXS elements apart
+template <typename T> SDFK_DEV T sdfk_aux(const float* __restrict__ AUX, long long AUXS, int k);
+template <> SDFK_DEV float sdfk_aux<float>(const float* __restrict__ AUX, long long AUXS, int k) { return AUX[k * AUXS]; }
+template <> SDFK_DEV f2 sdfk_aux<f2>(const float* __restrict__ AUX, long long AUXS, int k) {
+    f2 r = {AUX[k * AUXS], AUX[k * AUXS + 1]};
+    return r;
+}
+
 // =============================================================================================
 // pair adapters: operators written for one point per lane, applied to each half of an f2 lane
 // =============================================================================================

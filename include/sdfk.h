@@ -97,6 +97,12 @@ int sdfk_eval_grid(sdfk_program* prog, const float* ax0, int64_t n0, const float
  * trip without a coordinate array on either side. */
 int sdfk_eval_grid_host(sdfk_program* prog, const float* ax0, int64_t n0, const float* ax1, int64_t n1,
                         const float* ax2, int64_t n2, int64_t start, int64_t count, float* out, int device, int mode);
+/* Single-process multi-GPU: the grid is cut into n_shards contiguous slabs of whole rows (the remainder goes to
+ * the last); shard d runs on devices[d] (devices == NULL: d modulo the device count), all shards concurrently,
+ * each copying its slab into `out` (HOST, n0*n1*n2 floats). Slabs are independent (the path is pointwise): no
+ * collective. The multi-process route (one rank per GPU, torch.distributed) is aegolius_amd/distributed.py. */
+int sdfk_eval_grid_sharded(sdfk_program* prog, const float* ax0, int64_t n0, const float* ax1, int64_t n1,
+                           const float* ax2, int64_t n2, int n_shards, const int* devices, float* out, int mode);
 void sdfk_set_default_mode(int mode);
 /* Test / diagnostics aid for brick culling: writes one 64-bit skip mask per brick of 128 consecutive
  * points (ceil(n / 2048) * 16 entries; bit 2k = first operand of site k skipped, bit 2k+1 = second operand,
@@ -109,6 +115,32 @@ int sdfk_debug_brick_masks(sdfk_program* prog, const float* d_co, int64_t n, int
  * *brick_rows are returned. */
 int sdfk_debug_row_masks(sdfk_program* prog, const float* d_co, int64_t n, int64_t row_stride, int64_t row_len,
                          uint64_t* d_masks, int64_t* n_bricks, int* brick_rows, void* stream);
+
+/* ---- staged evaluation: grid-neighbourhood modifications ------------------------------------------
+ * signed / conv_averaging / conv_edge_detection (cores/modifications.py:220-275, 1589-1637) reshape the field to
+ * the grid and look at neighbours, so a tree that contains them is evaluated in stages: the sub-tree below the
+ * operator with an ordinary program, the operator on the resident field (below), and the rest of the tree with a
+ * program whose V_FIELD instructions read that field as auxiliary input c: d_aux + c*aux_stride + point index.
+ * Programs with V_FIELD instructions must be run through the _aux entry points (the others refuse them). */
+int sdfk_eval_device_aux(sdfk_program* prog, const float* d_co, int64_t n, int64_t row_stride, const float* d_aux,
+                         int n_aux, int64_t aux_stride, float* d_out, void* stream, int mode);
+int sdfk_eval_grid_aux(sdfk_program* prog, const float* ax0, int64_t n0, const float* ax1, int64_t n1, const float* ax2,
+                       int64_t n2, int64_t start, int64_t count, const float* d_aux, int n_aux, int64_t aux_stride,
+                       float* d_out, void* stream, int mode);
+/* Operators on a DEVICE field of n0*n1*n2 fp32 laid out like the (N,) output (flat index (i*n1 + j)*n2 + k; 2-D
+ * fields: n2 = 1), in place, synchronous:
+ *   box average  = post_processing.conv_averaging (cores/post_processing.py:561-600): scipy.ndimage.convolve with
+ *                  ones(k0,k1,k2)/(k0*k1*k2), mode "reflect", `iterations` times;
+ *   edge detect  = post_processing.conv_edge_detection (:603-623): [[-1,-1,-1],[-1,8,-1],[-1,-1,-1]] on axes 0, 1;
+ *   signed       = ModifyObject.signed (cores/modifications.py:220-275): unchanged if the field has a negative value,
+ *                  else boundary = field < sep_min (the smallest grid spacing), scan-line parity along axes 0 and 1,
+ *                  2x2x1 average, inner crop + edge pad (crop = 0: signed_old, :163-218, without it),
+ *                  field *= (1 - 2*(average > 0.5)). */
+int sdfk_field_min(const float* d_field, int64_t n, float* out_min, void* stream);
+int sdfk_grid_box_average(float* d_field, int64_t n0, int64_t n1, int64_t n2, int k0, int k1, int k2, int iterations,
+                          void* stream);
+int sdfk_grid_edge_detect(float* d_field, int64_t n0, int64_t n1, int64_t n2, void* stream);
+int sdfk_grid_signed(float* d_field, int64_t n0, int64_t n1, int64_t n2, float sep_min, int crop, void* stream);
 
 /* ---- grid builder -----------------------------------------------------------------------------
  * numpy.linspace(lo, hi, n) in float64 (step = (hi-lo)/(n-1); y[i] = i*step + lo; y[n-1] = hi),

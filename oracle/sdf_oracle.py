@@ -823,6 +823,100 @@ MODS["gaussian_boundary"] = _post(lambda u, a: a["amplitude"] * np.exp(-4 * (u /
 MODS["gaussian_falloff"] = _post(lambda u, a: a["amplitude"] * np.exp(-4 * (np.maximum(u, 0) / a["width"]) ** 2))
 
 
+# grid-neighbourhood operators  C/modifications.py:163-275, 1589-1637; C/post_processing.py:561-623;
+# reshapes: C/helper_functions.py:96-199 (smarter_reshape, vector_smarter_reshape)
+def _resolution_conversion(r):                    # C/helper_functions.py:10-20
+    return int(r) if int(r) % 2 == 1 else int(r) + 1
+
+
+def _smarter_reshape(pattern, resolution):        # C/helper_functions.py:96-148
+    n = pattern.shape[0]
+    res = [_resolution_conversion(r) for r in np.atleast_1d(np.asarray(resolution)).ravel()]
+    if len(res) == 1:
+        r = res[0]
+        if n // r == 1:
+            return pattern
+        if n // r ** 2 == 1:
+            return pattern.reshape(r, r)
+        if n // r ** 3 == 1:
+            return pattern.reshape(r, r, r)
+        raise ValueError("Cannot reshape the pattern with shape %r" % (pattern.shape,))
+    if len(res) == 2:
+        div = n // (res[0] * res[1])
+        return pattern.reshape(res[0], res[1]) if div == 1 else pattern.reshape(res[0], res[1], int(div))
+    div = n // (res[0] * res[1] * res[2])
+    if div != 1:
+        raise ValueError("Cannot reshape the pattern with shape %r" % (pattern.shape,))
+    return pattern.reshape(res[0], res[1], res[2])
+
+
+def _conv_averaging(u, kernel_size, iterations):  # C/post_processing.py:561-600
+    from scipy.ndimage import convolve
+    if iterations == 0:
+        return u
+    if isinstance(kernel_size, (int, np.integer)):
+        kernel_size = (int(kernel_size),) * u.ndim
+    kernel_size = tuple(int(k) for k in np.asarray(kernel_size).ravel())
+    if len(kernel_size) != u.ndim:
+        raise ValueError("Dimension of the kernel and the field must match!")
+    filt = np.ones(kernel_size) / float(np.prod(kernel_size))
+    new = convolve(u, filt)
+    for _ in range(iterations - 1):
+        new = convolve(new, filt)
+    return new
+
+
+@_m("conv_averaging")        # C/modifications.py:1607-1612
+def _(e, co, params):
+    u = _smarter_reshape(_inner(e, co, params), e.args["co_resolution"])
+    return _conv_averaging(u, e.args["kernel_size"], e.args["iterations"]).flatten()
+
+
+@_m("conv_edge_detection")   # C/modifications.py:1631-1634 (the grid-shaped result is returned as is)
+def _(e, co, params):
+    from scipy.ndimage import convolve
+    u = _smarter_reshape(_inner(e, co, params), e.args["co_resolution"])
+    f = np.asarray([[-1, -1, -1], [-1, 8, -1], [-1, -1, -1]], dtype=np.float64)
+    f = f if u.ndim == 2 else f[:, :, None]
+    _note(convolve(np.abs(u), np.abs(f)).ravel())   # sum |w||u|: what an input rounding error is multiplied by
+    return convolve(u, f)
+
+
+def _signed(e, co, params, crop):                 # C/modifications.py:163-218 (old), 220-275
+    sp = _inner(e, co, params)
+    if np.amin(sp) < 0:
+        return sp
+    res = e.args["co_resolution"]
+    s = _smarter_reshape(sp, res)
+    c = np.stack([_smarter_reshape(co[i], res) for i in range(co.shape[0])])
+    seps = tuple(np.abs(c[i, 1 * (i == 0), 1 * (i == 1), 1 * (i == 2)] - c[i, 0, 0, 0]) for i in range(c.shape[0]))
+    boundary = s < np.min(seps)
+    interior = None
+    for axis in (0, 1):
+        b = np.moveaxis(boundary, axis, 0)
+        chu, chuu = np.zeros(b.shape), np.zeros(b.shape)
+        chu[1:] = b[1:] * ~b[:-1]
+        chuu[:-1] = b[:-1] * ~b[1:]
+        mark = np.cumsum(chu, axis=0)
+        if crop:
+            fmark = np.flip(np.cumsum(chuu, axis=0), axis=0)   # :250-254 the cumulative sum, flipped (not a reverse sum)
+        else:
+            # signed_old :185-203: fmark[i] accumulates the falling edges met walking back from the far end, then is
+            # flipped: the number of falling edges at or after the point
+            fmark = np.flip(np.cumsum(np.flip(chuu, axis=0), axis=0), axis=0)
+        part = np.moveaxis(np.clip(mark % 2 + fmark % 2, 0, 1), 0, axis)
+        interior = part if interior is None else interior * part
+    interior = _conv_averaging(interior, (2, 2, 1), 1)
+    if crop:
+        interior = np.pad(interior[1:-1, 1:-1, 1:-1], pad_width=1, mode="edge")
+    sign = 1 - 2 * (interior > 0.5)
+    return sp * sign.flatten()
+
+
+MODS["signed"] = lambda e, co, params: _signed(e, co, params, True)
+MODS["signed_old"] = lambda e, co, params: _signed(e, co, params, False)
+
+
 @_m("polygon")               # C/geom_2d.py:537-550
 def _(e, co, params):
     d = _inner(e, co, params)

@@ -43,6 +43,22 @@ def main():
         meta["scenes"][name] = {"rotation_matrix": np.asarray(obj.rotation_matrix).tolist(),
                                 "center": np.asarray(obj.center, dtype=float).tolist(), "scale": float(obj.scale),
                                 "nan": int(np.isnan(field).sum())}
+    # grid-neighbourhood modifications: whole generate_grid clouds (fp32-rounded coordinates), own inputs
+    meta["grid_scenes"] = {}
+    for key in scenes.GRIDS:
+        co_g, res_g = scenes.grid_inputs(ref, key)
+        out["gridinputs/" + key] = co_g.astype(np.float32)
+    for name, (build, key) in scenes.GRID_SCENES.items():
+        co_g, res_g = scenes.grid_inputs(ref, key)
+        try:
+            with contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):
+                obj = build(ref, res_g)
+                field = np.asarray(obj.create(co_g.copy()), dtype=np.float64)
+        except Exception as exc:  # noqa: BLE001
+            failures.append((name, repr(exc)))
+            continue
+        out["gridscene/" + name] = field
+        meta["grid_scenes"][name] = {"grid": key, "shape": list(field.shape)}
     # grid builder
     grids = {"g3_even": ((2, 2, 2), (8, 8, 8)), "g3_mixed": ((2.0, 3.0, 1.0), (5, 8, 7)), "g3_scalar_res": ((4, 4, 4), 6),
              "g2": ((10, 6), (8, 5)), "g2_scalar_res": ((3, 3), 4), "g1": ((5,), (6,))}

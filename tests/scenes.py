@@ -613,3 +613,145 @@ def random_tree(ns, seed, depth=3):
 
 for _seed in range(48):
     scene("random_tree_%02d" % _seed, True)(lambda ns, s=_seed: random_tree(ns, 1000 + s))
+
+
+# -------------------------------------------------------------------------------------------------
+# grid-neighbourhood modifications (signed, conv_averaging, conv_edge_detection): these reshape the field to the
+# grid, so they are evaluated on whole generate_grid clouds, not on the shared point cloud.
+#   GRID_SCENES[name] = (builder(ns, co_resolution), grid key);  GRIDS[key] = (size, resolution as the user passes it)
+# -------------------------------------------------------------------------------------------------
+GRIDS = {"g3": ((2.0, 2.0, 2.0), (14, 12, 10)), "g2": ((3.0, 3.0), (30, 24))}
+GRID_SCENES = {}
+
+
+def grid_scene(name, grid, discontinuous=False):
+    def deco(fn):
+        assert name not in GRID_SCENES and name not in SCENES, name
+        GRID_SCENES[name] = (fn, grid)
+        if discontinuous:
+            DISCONTINUOUS.add(name)
+        return fn
+    return deco
+
+
+def grid_inputs(ns, key):
+    """(co, co_resolution): generate_grid of the namespace under test, coordinates rounded to fp32 values."""
+    size, resolution = GRIDS[key]
+    co, _ = ns.generate_grid(size, resolution)
+    return np.asarray(co).astype(np.float32).astype(np.float64), resolution
+
+
+@grid_scene("grid_conv_sphere_3x3x3", "g3")
+def _(ns, res):
+    s = ns.Sphere(0.6)
+    s.conv_averaging((3, 3, 3), 1, res)
+    return s
+
+
+@grid_scene("grid_conv_even_kernel_iterated_then_rounding", "g3")
+def _(ns, res):
+    b = ns.Box(0.9, 0.7, 0.5)
+    b.rotate(0.6, (1, 1, 0))
+    b.conv_averaging((2, 4, 1), 3, res)
+    b.rounding(0.03)
+    b.move((0.1, -0.05, 0.0))
+    return b
+
+
+@grid_scene("grid_conv_integer_kernel", "g3")
+def _(ns, res):
+    t = ns.Torus(0.5, 0.15)
+    t.conv_averaging(3, 2, res)
+    return t
+
+
+@grid_scene("grid_conv_point_cloud_2d", "g2")
+def _(ns, res):
+    phi = np.linspace(0, 2 * np.pi, 26)
+    pts = np.asarray([np.cos(phi), np.sin(phi), 0 * phi])
+    pc = ns.PointCloud2D(pts)
+    pc.conv_averaging((5, 5), 4, res)
+    return pc
+
+
+@grid_scene("grid_conv_under_a_twist", "g3")
+def _(ns, res):
+    b = ns.Box(0.8, 0.4, 0.9)
+    b.conv_averaging((3, 3, 1), 1, res)
+    b.twist(0.8)                              # declared later: warps the coordinates the averaged closure is given
+    b.set_scale(1.2)
+    return b
+
+
+@grid_scene("grid_edge_detection_3d", "g3")
+def _(ns, res):
+    s = ns.Sphere(0.55)
+    s.move((0.1, 0.0, -0.1))
+    s.conv_edge_detection(res)
+    return s
+
+
+@grid_scene("grid_edge_detection_2d", "g2")
+def _(ns, res):
+    c = ns.Circle(0.8)
+    c.conv_edge_detection(res)
+    return c
+
+
+@grid_scene("grid_signed_sphere_shell", "g3", True)
+def _(ns, res):
+    s = ns.Sphere(0.62)
+    s.boundary()
+    s.signed(res)
+    return s
+
+
+@grid_scene("grid_signed_box_transformed_node", "g3", True)
+def _(ns, res):
+    b = ns.Box(0.9, 0.8, 0.7)
+    b.boundary()
+    b.signed(res)
+    b.move((0.07, -0.04, 0.05))
+    b.set_scale(1.1)
+    return b
+
+
+@grid_scene("grid_signed_old_rotated_torus", "g3", True)
+def _(ns, res):
+    t = ns.Torus(0.55, 0.22)
+    t.boundary()
+    t.signed_old(res)
+    t.rotate(0.5, (1, 0, 0))
+    return t
+
+
+@grid_scene("grid_signed_already_signed_is_untouched", "g3")
+def _(ns, res):
+    s = ns.Sphere(0.5)
+    s.signed(res)
+    return s
+
+
+@grid_scene("grid_signed_then_conv_then_onion", "g3", True)
+def _(ns, res):
+    c = ns.Cylinder(0.5, 0.9)
+    c.boundary()
+    c.signed(res)
+    c.conv_averaging((3, 3, 3), 1, res)
+    c.onion(0.02)
+    return c
+
+
+@grid_scene("grid_union_of_signed_and_plain", "g3", True)
+def _(ns, res):
+    a = ns.Box(0.7, 0.7, 0.7)
+    a.boundary()
+    a.signed(res)
+    a.rounding(0.02)
+    b = ns.Sphere(0.35)
+    b.move((0.45, 0.3, 0.2))
+    c = ns.Torus(0.6, 0.1)
+    c.conv_averaging((3, 3, 1), 2, res)
+    u = ns.CombineGeometry("UNION").combine(a, b, c)
+    u.rotate(0.0, (0, 0, 1))
+    return u

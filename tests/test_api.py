@@ -164,10 +164,12 @@ def test_callable_recognition():
     g = ns.GenericGeometry(lambda co, r: co[0] - r, 1.0)
     with pytest.raises(NotImplementedError):
         lower_geometry(g)
+    # grid-neighbourhood operators cannot live in ONE per-point program: lowering asks for a staged evaluation
+    from aegolius_amd._lower import NeedsStage
     for mod in ("signed", "conv_edge_detection"):
         b = ns.Box(1, 1, 1)
         getattr(b, mod)((8, 8, 8))
-        with pytest.raises(NotImplementedError):
+        with pytest.raises(NeedsStage):
             lower_geometry(b)
     seg = ns.SegmentedLine3D(np.zeros((3, 4)))      # reference wires the open variant with the wrong arity
     with pytest.raises(TypeError):
@@ -203,3 +205,35 @@ def test_generate_grid_tag_is_only_trusted_while_the_array_cannot_change():
         np.testing.assert_array_equal(plain, np.asarray(co))
     finally:
         aegolius_amd.config.grid_fast_path = True
+
+
+def test_stage_plan_of_trees_with_grid_operators():
+    """signed / conv_* cut the evaluation into stages: one program per operator (stopping at its inner field) and
+    a final program that reads the operator outputs as auxiliary fields (V_FIELD). Innermost operators first."""
+    from aegolius_amd import _ops
+    from aegolius_amd._eval import _grid_shape, _plan_stages
+    res = (12, 10, 8)
+    s = ns.Sphere(0.5)
+    s.boundary()
+    s.conv_averaging((3, 3, 1), 2, res)
+    s.rounding(0.01)
+    s.move((0.1, 0, 0))
+    b = ns.Box(0.4, 0.4, 0.4)
+    b.boundary()
+    b.signed(res)
+    b.conv_averaging(3, 1, res)                      # nested: signed first, then the average of its result
+    u = ns.CombineGeometry("UNION2").combine(s, b)
+    stages, final, fields = _plan_stages(lambda **kw: lower_geometry(u, **kw))
+    names = lambda low: [_ops.OPS[w & 255].name for w in low.code[:, 0]]      # noqa: E731
+    assert [node.name for _, node in stages] == ["conv_averaging", "signed", "conv_averaging"]
+    assert names(stages[0][0]) == ["XLATE", "P_SPHERE", "VABS"]
+    assert names(stages[1][0])[-2:] == ["P_BOX", "VABS"]
+    assert names(stages[2][0])[-1] == "V_FIELD" and stages[2][0].code[-1, 0] >> 24 == 1
+    assert names(final) == ["XLATE", "V_FIELD", "VSUBC", "V_FIELD", "VMIN"]
+    assert [int(w >> 24) for w in final.code[:, 0] if _ops.OPS[w & 255].name == "V_FIELD"] == [0, 2]
+    assert len(final.cull_sites) == 0                 # no Lipschitz bound through a field: nothing is culled
+    # smarter_reshape shapes
+    assert _grid_shape(13 * 11 * 9, res) == (13, 11, 9) and _grid_shape(9 * 5, (8, 5)) == (9, 5)
+    assert _grid_shape(9 ** 3, 8) == (9, 9, 9) and _grid_shape(9 * 5 * 4, (8, 5)) == (9, 5, 4)
+    with pytest.raises(ValueError):
+        _grid_shape(100, (8, 8, 8))

@@ -82,6 +82,34 @@ def test_scene_matches_reference_golden(name, engine, golden, golden_inputs):
     np.testing.assert_array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("name", sorted(scenes.GRID_SCENES))
+def test_grid_neighbourhood_scene_matches_reference_golden(name, engine, golden):
+    """signed / conv_averaging / conv_edge_detection (staged evaluation: per-point programs + grid operators on the
+    resident field + V_FIELD reads), both kernel flavours, tagged grid and plain array input."""
+    data, meta = golden
+    build, key = scenes.GRID_SCENES[name]
+    co, res = scenes.grid_inputs(ns, key)
+    tagged, _ = ns.generate_grid(*scenes.GRIDS[key])
+    ref = data["gridscene/" + name]
+    # edge detection subtracts neighbouring samples of an fp32 field: its error is judged against sum |w||u|
+    # (reported by the oracle), like the intermediate magnitudes of the random trees
+    magnitude = None
+    if "edge_detection" in name:
+        with np.errstate(all="ignore"):
+            again, magnitude = sdf_oracle.evaluate_with_magnitude(build(ns, res), co)
+        np.testing.assert_allclose(again, ref, rtol=1e-12, atol=1e-12)
+    outs = []
+    for mode in (engine.MODE_SPECIALIZED, engine.MODE_INTERPRET):
+        aegolius_amd.config.mode = mode
+        for arr in (co.copy(), tagged):
+            out = build(ns, res).create(arr)
+            assert list(out.shape) == meta["grid_scenes"][name]["shape"]
+            check(name, out.ravel(), ref.ravel(), magnitude)
+            outs.append(out)
+    for o in outs[1:]:
+        np.testing.assert_array_equal(o, outs[0])
+
+
 def test_float32_and_float64_coordinates_agree(engine, golden_inputs):
     tree = scenes.cfg2_tree(ns)
     a = tree.create(golden_inputs)
@@ -320,6 +348,21 @@ def test_sharded_evaluation_matches_whole_grid(engine):
         parts = [ev(axes, *slab_bounds(whole.size, world, r, unit)) for r in range(world) for unit in (u,)]
         torch.cuda.synchronize()
         np.testing.assert_array_equal(torch.cat(parts).cpu().numpy(), whole)
+
+
+def test_single_process_sharded_grid(engine):
+    """sdfk_eval_grid_sharded: slabs of whole rows on a device list (here all on device 0), concurrent host
+    threads; equals the unsharded field; bad device indices are refused."""
+    from aegolius_amd.cores.helper_functions import grid_axes
+    tree = scenes.cfg5_tree(ns)
+    prog = engine.Program.from_lowered(lower_geometry(tree))
+    axes = [a.astype(np.float32) for a in grid_axes((3, 3, 3), (20, 30, 70))[0]]
+    whole = prog.eval_grid_host(axes)
+    for shards in (1, 3, 8):
+        np.testing.assert_array_equal(prog.eval_grid_sharded(axes, shards, devices=[0] * shards), whole)
+    np.testing.assert_array_equal(prog.eval_grid_sharded(axes, 2), whole)
+    with pytest.raises(engine.SdfkError):
+        prog.eval_grid_sharded(axes, 2, devices=[0, 99])
 
 
 CULL_SCENES = ["tree_cfg2_smooth_union10", "tree_cfg5_three_level", "tree_cfg4_union50_2d", "tree_pawn_like",

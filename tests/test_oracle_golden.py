@@ -20,6 +20,7 @@ def rel_err(out, ref):
 def test_golden_covers_every_scene(golden):
     data, meta = golden
     assert set(meta["scenes"]) == set(scenes.SCENES)
+    assert set(meta["grid_scenes"]) == set(scenes.GRID_SCENES)
     assert data["inputs"].dtype == np.float32 and data["inputs"].shape == (3, meta["n_points"])
     # inputs are reproducible from the seed (no hidden state in the fixture)
     np.testing.assert_array_equal(data["inputs"], scenes.input_points().astype(np.float32))
@@ -36,6 +37,22 @@ def test_oracle_matches_reference(name, golden, golden_inputs):
     assert out.shape == ref.shape and out.dtype == np.float64
     assert np.array_equal(np.isnan(out), np.isnan(ref))
     assert rel_err(out, ref).max() <= 1e-12
+
+
+@pytest.mark.parametrize("name", sorted(scenes.GRID_SCENES))
+def test_oracle_matches_reference_on_grid_scenes(name, golden):
+    """signed / conv_averaging / conv_edge_detection: evaluated on whole generate_grid clouds (own inputs)."""
+    data, meta = golden
+    build, key = scenes.GRID_SCENES[name]
+    co, res = scenes.grid_inputs(ns, key)
+    np.testing.assert_array_equal(co.astype(np.float32), data["gridinputs/" + key])
+    ref = data["gridscene/" + name]
+    with np.errstate(all="ignore"):
+        out = sdf_oracle.evaluate(build(ns, res), co.copy())
+    assert list(out.shape) == meta["grid_scenes"][name]["shape"] and out.dtype == np.float64
+    assert rel_err(out, ref).max() <= 1e-12
+    if "signed" in name and "already" not in name:
+        assert (ref < 0).sum() > 30                  # the sign really is recovered
 
 
 @pytest.mark.parametrize("name", ALL)
