@@ -36,9 +36,9 @@ SIGNATURES = {
     "sdfk_eval_device_aux": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _i64, _vp, _vp, _int]),
     "sdfk_eval_grid_aux": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _int, _i64, _vp, _vp, _int]),
     "sdfk_field_min": (_int, [_vp, _i64, _c.POINTER(_c.c_float), _vp]),
-    "sdfk_grid_box_average": (_int, [_vp, _i64, _i64, _i64, _int, _int, _int, _int, _vp]),
-    "sdfk_grid_edge_detect": (_int, [_vp, _i64, _i64, _i64, _vp]),
-    "sdfk_grid_signed": (_int, [_vp, _i64, _i64, _i64, _c.c_float, _int, _vp]),
+    "sdfk_grid_box_average": (_int, [_vp, _i64, _i64, _i64, _int, _int, _int, _int, _vp, _vp]),
+    "sdfk_grid_edge_detect": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "sdfk_grid_signed": (_int, [_vp, _i64, _i64, _i64, _c.c_float, _int, _vp, _vp]),
     "sdfk_eval_host": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _int, _int]),
     "sdfk_eval_grid": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _int]),
     "sdfk_eval_grid_host": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _int, _int]),

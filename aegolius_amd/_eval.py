@@ -121,7 +121,7 @@ def _plan_stages(lower):
             raise NotImplementedError("more than 32 grid-neighbourhood operators in one tree")
 
 
-def _apply_grid_op(lib, node, d_field, n, lower, fields, points4):
+def _apply_grid_op(lib, node, d_field, n, lower, fields, points4, d_scratch):
     """Run one operator in place on a device field of n points."""
     name, args = node.name, node.args
     shape = _grid_shape(n, args["co_resolution"])
@@ -136,9 +136,10 @@ def _apply_grid_op(lib, node, d_field, n, lower, fields, points4):
             raise ValueError("Dimension of the kernel and the field must match!")
         ks = ks + (1,) * (3 - len(ks))
         _engine.check(lib.sdfk_grid_box_average(vp(d_field), dims[0], dims[1], dims[2], ks[0], ks[1], ks[2],
-                                                int(args["iterations"]), None), "sdfk_grid_box_average")
+                                                int(args["iterations"]), vp(d_scratch), None), "sdfk_grid_box_average")
     elif name == "conv_edge_detection":
-        _engine.check(lib.sdfk_grid_edge_detect(vp(d_field), dims[0], dims[1], dims[2], None), "sdfk_grid_edge_detect")
+        _engine.check(lib.sdfk_grid_edge_detect(vp(d_field), dims[0], dims[1], dims[2], vp(d_scratch), None),
+                      "sdfk_grid_edge_detect")
     else:                                           # signed, signed_old
         if len(shape) != 3:
             raise ValueError("Dimension of the kernel and the field must match!")      # conv_averaging((2, 2, 1)) on 2-D
@@ -148,7 +149,7 @@ def _apply_grid_op(lib, node, d_field, n, lower, fields, points4):
             vals = _eval_few(lib, lower(fields=fields, stop_at=node, probe_axis=axis), points4, len(fields))
             seps.append(abs(float(vals[1 + axis]) - float(vals[0])))
         _engine.check(lib.sdfk_grid_signed(vp(d_field), dims[0], dims[1], dims[2], float(np.float32(min(seps))),
-                                           0 if name == "signed_old" else 1, None), "sdfk_grid_signed")
+                                           0 if name == "signed_old" else 1, vp(d_scratch), None), "sdfk_grid_signed")
 
 
 def _eval_few(lib, lowered, points, n_aux):
@@ -235,7 +236,7 @@ def _run_staged(lower, co, root=None):
                 if len(shape) == 3:
                     idx = [0, shape[1] * shape[2], shape[2], 1]
                     points4 = np.stack([np.asarray(co[r])[idx] for r in range(3)]).astype(np.float64)
-            _apply_grid_op(lib, node, d_aux + 4 * k * stride, n, lower, known, points4)
+            _apply_grid_op(lib, node, d_aux + 4 * k * stride, n, lower, known, points4, d_out)   # d_out doubles as scratch
             known[id(node)] = k
         run_program(final, d_out, len(stages))
         out = np.empty(n, dtype=np.float32)

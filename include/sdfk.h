@@ -137,10 +137,12 @@ int sdfk_eval_grid_aux(sdfk_program* prog, const float* ax0, int64_t n0, const f
  *                  2x2x1 average, inner crop + edge pad (crop = 0: signed_old, :163-218, without it),
  *                  field *= (1 - 2*(average > 0.5)). */
 int sdfk_field_min(const float* d_field, int64_t n, float* out_min, void* stream);
+/* d_scratch: n0*n1*n2*4 bytes of device memory for the operator's work arrays (NULL: allocated and freed inside). */
 int sdfk_grid_box_average(float* d_field, int64_t n0, int64_t n1, int64_t n2, int k0, int k1, int k2, int iterations,
-                          void* stream);
-int sdfk_grid_edge_detect(float* d_field, int64_t n0, int64_t n1, int64_t n2, void* stream);
-int sdfk_grid_signed(float* d_field, int64_t n0, int64_t n1, int64_t n2, float sep_min, int crop, void* stream);
+                          void* d_scratch, void* stream);
+int sdfk_grid_edge_detect(float* d_field, int64_t n0, int64_t n1, int64_t n2, void* d_scratch, void* stream);
+int sdfk_grid_signed(float* d_field, int64_t n0, int64_t n1, int64_t n2, float sep_min, int crop, void* d_scratch,
+                     void* stream);
 
 /* ---- grid builder -----------------------------------------------------------------------------
  * numpy.linspace(lo, hi, n) in float64 (step = (hi-lo)/(n-1); y[i] = i*step + lo; y[n-1] = hi),

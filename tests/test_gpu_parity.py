@@ -110,6 +110,51 @@ def test_grid_neighbourhood_scene_matches_reference_golden(name, engine, golden)
         np.testing.assert_array_equal(o, outs[0])
 
 
+def test_grid_operators_at_scale(engine):
+    """129^3 (cfg 1 size): `signed` of |sphere| followed by an averaging agrees with the oracle (sign flips only
+    for the few points whose boundary test sits within rounding of the threshold);
+    box averaging keeps a constant field constant (also with a kernel wider than the LDS chunk, several iterations,
+    and on a flat 2-D field), and matches scipy-free arithmetic on a linear ramp away from the border."""
+    co, res = ns.generate_grid((2, 2, 2), (128, 128, 128))
+    def build():
+        s = ns.Sphere(0.6)
+        s.boundary()
+        s.signed((128, 128, 128))
+        s.conv_averaging((3, 3, 3), 1, (128, 128, 128))
+        return s
+    got = build().create(co)
+    co64 = np.asarray(co).astype(np.float32).astype(np.float64)
+    ref = sdf_oracle.evaluate(build(), co64)
+    assert (ref < 0).sum() > 0.05 * ref.size
+    err, bad = violations(got, ref)
+    assert bad.sum() <= 0.0005 * ref.size, (int(bad.sum()), float(np.nanmax(err)))
+    # constant field / linear ramp through the operator alone
+    lib = engine.lib()
+    n0, n1, n2 = 33, 41, 130
+    ramp = (np.arange(n0)[:, None, None] * 0.5 + np.arange(n1)[None, :, None] * 0.25 + np.arange(n2)[None, None, :] * 2.0)
+    for field, shape, kern, iters in ((np.full((n0, n1, n2), 1.25), (n0, n1, n2), (9, 9, 9), 2),
+                                      (ramp, (n0, n1, n2), (3, 5, 7), 1), (ramp, (n0, n1, n2), (2, 4, 6), 1),
+                                      (np.full((n0 * n1, n2), -0.75), (n0 * n1, n2, 1), (5, 5, 1), 3)):
+        host = np.ascontiguousarray(field, dtype=np.float32).ravel()
+        d = lib.sdfk_malloc(host.nbytes)
+        try:
+            engine.check(lib.sdfk_memcpy_h2d(ctypes.c_void_p(d), host.ctypes.data_as(ctypes.c_void_p), host.nbytes), "h2d")
+            engine.check(lib.sdfk_grid_box_average(ctypes.c_void_p(d), shape[0], shape[1], shape[2], kern[0], kern[1], kern[2],
+                                                   iters, None, None), "box")
+            out = np.empty_like(host)
+            engine.check(lib.sdfk_memcpy_d2h(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d), host.nbytes), "d2h")
+        finally:
+            lib.sdfk_free(ctypes.c_void_p(d))
+        out = out.reshape(field.shape)
+        if field is ramp:
+            # a box average of a linear function is the function at the box centre: offsets -((k-1)//2) .. k//2
+            shift = sum(w * (k // 2 - (k - 1) // 2) / 2.0 for w, k in zip((0.5, 0.25, 2.0), kern))
+            inner = (slice(5, -5),) * 3
+            np.testing.assert_allclose(out[inner], (ramp + shift)[inner], rtol=1e-6)
+        else:
+            np.testing.assert_array_equal(out, field.astype(np.float32))
+
+
 def test_float32_and_float64_coordinates_agree(engine, golden_inputs):
     tree = scenes.cfg2_tree(ns)
     a = tree.create(golden_inputs)
