@@ -100,9 +100,11 @@ def _grid_shape(n, resolution):
 
 
 def _plan_stages(lower):
-    """[(stage program, operator node)], final program: every grid operator gets the field of its inner
-    expression from the stage before it (innermost / first-met operators first)."""
+    """[(stage program or None, operator node)], final program: every staged operator gets its input from the
+    stage before it (innermost / first-met operators first). Operators that are handed coordinates only
+    (custom_modification, opaque callables) have no stage program of their own."""
     from ._lower import NeedsStage
+    from ._mods import FIELD_STAGE_OPS
     fields, stages = {}, []
     while True:
         try:
@@ -111,14 +113,18 @@ def _plan_stages(lower):
             target = need.expr
         while True:
             try:
-                prog = lower(fields=fields, stop_at=target)
+                if target.name in FIELD_STAGE_OPS:
+                    prog = lower(fields=fields, stop_at=target)
+                else:
+                    lower(fields=fields, stop_at=target, probe_axis=0)     # reachable with what is known so far?
+                    prog = None
                 break
             except NeedsStage as inner:            # an operator nested in (or met before) the target: that one first
                 target = inner.expr
         stages.append((prog, target))
         fields[id(target)] = len(fields)
         if len(fields) > 32:
-            raise NotImplementedError("more than 32 grid-neighbourhood operators in one tree")
+            raise NotImplementedError("more than 32 staged operators in one tree")
 
 
 def _apply_grid_op(lib, node, d_field, n, lower, fields, points4, d_scratch):
@@ -189,6 +195,42 @@ def _edge_detection_is_outermost(expr):
             return None
 
 
+def _run_host_op(lib, node, lowered, k, n, stride, d_aux, d_out, run_program, lower, known):
+    """custom_post_process / custom_modification / an opaque SDF callable: user code on the host between two GPU
+    stages. The field (or the coordinates the closure is handed) comes back over PCIe, the result goes up as
+    auxiliary field k. Functional completeness, not a fast path."""
+    vp = _engine._vp
+    row = d_aux + 4 * k * stride
+    buf = np.empty(n, dtype=np.float32)
+
+    def fetch(d_src):
+        _engine.check(lib.sdfk_memcpy_d2h(_engine._ptr(buf), vp(d_src), n * 4), "d2h")
+        return buf.astype(np.float64)
+
+    if node.name == "custom_post_process":
+        run_program(lowered, row, k)
+        result = node.args["function"](fetch(row), *node.args["parameters"])
+    else:
+        co_here = np.empty((3, n), dtype=np.float64)
+        for axis in range(3):
+            run_program(lower(fields=known, stop_at=node, probe_axis=axis), d_out, k)
+            co_here[axis] = fetch(d_out)
+        params = getattr(node, "stage_params", ())
+        if node.name == "custom_modification":
+            inner = node.inner
+
+            def geo_object(co_, *p):               # the closure the reference hands to the user's modification
+                return evaluate_expr(inner, np.asarray(co_), p).astype(np.float64)
+            result = node.args["modification"](geo_object, co_here, params, node.args["modification_parameters"])
+        else:
+            result = node.fn(co_here, *params)
+    result = np.asarray(result, dtype=np.float32)
+    if result.shape != (n,):
+        raise ValueError("%s returned an array of shape %r, expected (%d,)" % (node.name, result.shape, n))
+    result = np.ascontiguousarray(result)
+    _engine.check(lib.sdfk_memcpy_h2d(vp(row), _engine._ptr(result), n * 4), "h2d")
+
+
 def _run_staged(lower, co, root=None):
     _engine.require_gpu()
     lib = _engine.lib()
@@ -229,7 +271,12 @@ def _run_staged(lower, co, root=None):
         # the 4 points `signed` reads its grid spacings from: point 0 and its neighbour along each axis
         points4 = None
         known = {}
+        from ._mods import HOST_OPS
         for k, (lowered, node) in enumerate(stages):
+            if node.name in HOST_OPS:
+                _run_host_op(lib, node, lowered, k, n, stride, d_aux, d_out, run_program, lower, known)
+                known[id(node)] = k
+                continue
             run_program(lowered, d_aux + 4 * k * stride, k)
             if node.name in ("signed", "signed_old") and points4 is None:
                 shape = _grid_shape(n, node.args["co_resolution"])

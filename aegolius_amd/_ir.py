@@ -72,9 +72,13 @@ class NodeSDF(SDFExpr):
 
 
 class UnsupportedSDF(SDFExpr):
-    """An opaque Python callable. Evaluating it would need a host evaluation of user code inside the
-    fused GPU pass; not supported (raises at create(), never silently routed to a CPU path)."""
+    """An opaque Python callable `fn(co, *params)`. It cannot be fused into a GPU program: the staged evaluation
+    (_eval._run_staged) brings the coordinates it is handed back to the host, calls it there and feeds its result
+    to the rest of the tree as an auxiliary field. `why` is the message raised where that is not possible."""
+    name = "python_callable"
+    inner = None
 
     def __init__(self, fn, why):
         self.fn = fn
         self.why = why
+        self.args = {}

@@ -243,7 +243,8 @@ class Lowerer:
         if isinstance(expr, NodeSDF):
             return self.lower_node(expr.obj, creg, OWNED if mode == OWNED else FROZEN)
         if isinstance(expr, UnsupportedSDF):
-            raise NotImplementedError(expr.why)
+            from ._mods import _staged_op
+            return _staged_op(self, expr, creg, mode, params)
         raise NotImplementedError(
             "aegolius_amd cannot fuse the opaque Python callable %r into the GPU evaluation; build the field "
             "from aegolius_amd primitives / geometry objects (obj.propagate, obj.sign(direct=True), ...)" % (expr,))
@@ -316,9 +317,19 @@ def as_expr(fn):
     owner = getattr(fn, "__self__", None)
     if owner is not None and _is_geometry(owner) and getattr(fn, "__name__", "") in ("propagate", "create"):
         return NodeSDF(owner)
-    return UnsupportedSDF(fn, "aegolius_amd cannot fuse the opaque Python callable %r into the GPU evaluation; "
+    key = id(fn)                                   # one node per callable: stage fields are keyed by node identity
+    known = _OPAQUE.get(key)
+    if known is not None and known.fn is fn:
+        return known
+    if len(_OPAQUE) > 4096:
+        _OPAQUE.clear()
+    _OPAQUE[key] = node = UnsupportedSDF(fn, "aegolius_amd cannot fuse the opaque Python callable %r into the GPU evaluation; "
                               "pass an aegolius_amd sdf_* function, a modification closure returned by an "
                               "aegolius_amd geometry, or obj.propagate" % (fn,))
+    return node
+
+
+_OPAQUE = {}
 
 
 def _staged(L, fields, stop_at, probe_axis):

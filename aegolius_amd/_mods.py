@@ -415,9 +415,14 @@ def _unsupported(reason):
 # field an earlier stage produced.
 # ------------------------------------------------------------------------------------------------
 GRID_OPS = ("signed", "signed_old", "conv_averaging", "conv_edge_detection")
+# opaque user code (C/modifications.py:1330-1359 custom_modification, :1639-1663 custom_post_process, and plain
+# Python callables used as SDF functions): same staging, but the operator runs on the HOST between two GPU stages
+HOST_OPS = ("custom_modification", "custom_post_process", "python_callable")
+# operators whose stage program produces the inner field (the others are handed coordinates only)
+FIELD_STAGE_OPS = GRID_OPS + ("custom_post_process",)
 
 
-def _grid_op(L, e, creg, mode, params):
+def _staged_op(L, e, creg, mode, params):
     from ._lower import NeedsStage, StageStop
     idx = L.fields.get(id(e))
     if idx is not None:
@@ -430,19 +435,17 @@ def _grid_op(L, e, creg, mode, params):
             L.emit("P_AXIS", v, creg, params=[0.0, float(L.probe_axis)])
         else:
             v = L.lower_expr(e.inner, creg, mode, params)
+        e.stage_params = tuple(params)          # the geometry parameters this closure is called with
         raise StageStop(v)
-    if L.stop_at is not None:
+    if L.stop_at is not None and e.name in FIELD_STAGE_OPS:
         # on the way to another operator: if that one lies inside this one, StageStop passes through here;
         # if not, this operator is met first and must get its own stage first
         L.lower_expr(e.inner, creg, mode, params)
     raise NeedsStage(e)
 
 
-for _n in GRID_OPS:
-    MOD_LOWER[_n] = _grid_op
-for _n in ("custom_modification", "custom_post_process"):
-    MOD_LOWER[_n] = _unsupported("opaque Python callable cannot be fused into the GPU evaluation")
-
+for _n in GRID_OPS + ("custom_modification", "custom_post_process"):
+    MOD_LOWER[_n] = _staged_op
 del _n
 
 

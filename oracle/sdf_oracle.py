@@ -20,7 +20,7 @@ Semantics mirrored on purpose:
 """
 import numpy as np
 
-from aegolius_amd._ir import CombineSDF, ModSDF, NodeSDF, PrimSDF
+from aegolius_amd._ir import CombineSDF, ModSDF, NodeSDF, PrimSDF, UnsupportedSDF
 
 norm = np.linalg.norm
 
@@ -83,6 +83,8 @@ def eval_expr(expr, co, params):
         return _combine(expr, co)
     if isinstance(expr, NodeSDF):
         return eval_node(expr.obj, co)
+    if isinstance(expr, UnsupportedSDF):            # an opaque user callable used as SDF function: just call it
+        return expr.fn(co, *params)
     raise TypeError("oracle: cannot evaluate %r" % (expr,))
 
 
@@ -821,6 +823,16 @@ def _slowstart(u, a):
 MODS["slowstart"] = _post(_slowstart)
 MODS["gaussian_boundary"] = _post(lambda u, a: a["amplitude"] * np.exp(-4 * (u / a["width"]) ** 2))
 MODS["gaussian_falloff"] = _post(lambda u, a: a["amplitude"] * np.exp(-4 * (np.maximum(u, 0) / a["width"]) ** 2))
+
+
+@_m("custom_modification")   # C/modifications.py:1353-1356
+def _(e, co, params):
+    return e.args["modification"](lambda co_, *p: eval_expr(e.inner, co_, p), co, params, e.args["modification_parameters"])
+
+
+@_m("custom_post_process")   # C/modifications.py:1658-1660
+def _(e, co, params):
+    return e.args["function"](_inner(e, co, params), *e.args["parameters"])
 
 
 # grid-neighbourhood operators  C/modifications.py:163-275, 1589-1637; C/post_processing.py:561-623;

@@ -616,6 +616,66 @@ for _seed in range(48):
 
 
 # -------------------------------------------------------------------------------------------------
+# opaque user code: custom_post_process, custom_modification, plain Python callables as SDF functions
+# (evaluated on the host between two GPU stages)
+# -------------------------------------------------------------------------------------------------
+def _user_tanh(u, amplitude, width):
+    return amplitude * np.tanh(u / width)
+
+
+def _user_zoom(geo_object, co, params, mod_params):
+    k, drift = mod_params
+    return geo_object(co * k, *params) / k + drift * co[2]
+
+
+def _user_blob(co, radius, bump):
+    return np.linalg.norm(co, axis=0) - radius + bump * np.sin(4.0 * co[0]) * np.cos(3.0 * co[1])
+
+
+def _user_ripple(co, amplitude):
+    return amplitude * np.sin(5.0 * co[0] + 2.0 * co[2])
+
+
+@scene("host_custom_post_process")
+def _(ns):
+    b = ns.Box(0.9, 0.7, 0.5)
+    b.rotate(0.4, (0, 1, 1))
+    b.custom_post_process(_user_tanh, (0.5, 0.3), post_process_name="tanh")
+    b.rounding(0.01)
+    return b
+
+
+@scene("host_custom_modification")
+def _(ns):
+    t = ns.Torus(0.5, 0.15)
+    t.twist(0.4)
+    t.custom_modification(_user_zoom, (1.3, 0.02), modification_name="zoom")
+    t.onion(0.01)
+    t.move((0.1, 0.0, -0.2))
+    return t
+
+
+@scene("host_python_callable_leaf")
+def _(ns):
+    g = ns.GenericGeometry(_user_blob, 0.6, 0.05)
+    g.elongation((0.2, 0.0, 0.1))
+    g.rotate(0.7, (1, 0, 0))
+    g.set_scale(1.2)
+    return g
+
+
+@scene("host_python_callable_as_displacement_in_union")
+def _(ns):
+    s = ns.Sphere(0.55)
+    s.displacement(_user_ripple, (0.03,))
+    c = ns.Cylinder(0.25, 1.2)
+    c.custom_post_process(_user_tanh, (1.0, 2.0))
+    u = ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(s, c, parameters=0.1)
+    u.move((0.05, 0.05, 0.0))
+    return u
+
+
+# -------------------------------------------------------------------------------------------------
 # grid-neighbourhood modifications (signed, conv_averaging, conv_edge_detection): these reshape the field to the
 # grid, so they are evaluated on whole generate_grid clouds, not on the shared point cloud.
 #   GRID_SCENES[name] = (builder(ns, co_resolution), grid key);  GRIDS[key] = (size, resolution as the user passes it)

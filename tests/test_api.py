@@ -161,11 +161,14 @@ def test_callable_recognition():
     assert isinstance(as_expr(s.propagate), NodeSDF) and as_expr(s.propagate).obj is s
     assert isinstance(as_expr(s.create), NodeSDF)
     assert as_expr(ns.sdf_sphere) is ns.sdf_sphere
-    g = ns.GenericGeometry(lambda co, r: co[0] - r, 1.0)
-    with pytest.raises(NotImplementedError):
-        lower_geometry(g)
-    # grid-neighbourhood operators cannot live in ONE per-point program: lowering asks for a staged evaluation
+    # opaque callables and grid-neighbourhood operators cannot live in ONE per-point program: lowering asks for a
+    # staged evaluation (_eval._run_staged)
     from aegolius_amd._lower import NeedsStage
+    fn = lambda co, r: co[0] - r      # noqa: E731
+    g = ns.GenericGeometry(fn, 1.0)
+    with pytest.raises(NeedsStage):
+        lower_geometry(g)
+    assert as_expr(fn) is as_expr(fn)                 # one node per callable (stage fields are keyed by node)
     for mod in ("signed", "conv_edge_detection"):
         b = ns.Box(1, 1, 1)
         getattr(b, mod)((8, 8, 8))
