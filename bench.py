@@ -106,11 +106,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SDFK_BENCH_REHEARSE=1: every rank on device 0 with gloo (reductions on the CPU) — to walk the N > 1 control
+    # flow on a one-GPU box; RCCL refuses several ranks on one device. Never set by the driver.
+    rehearse = world > 1 and os.environ.get("SDFK_BENCH_REHEARSE") == "1"
+    torch.cuda.set_device(0 if rehearse else local_rank)
+    dev = torch.device("cuda", 0 if rehearse else local_rank)
+    red_dev = torch.device("cpu") if rehearse else dev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import __graft_entry__
     if rank == 0:
@@ -169,7 +176,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_ms(ev1) / args.steps            # HIP events on the launch stream
 
-    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms_max = float(t[0]), float(t[1])
@@ -205,8 +212,26 @@ def main():
                      "note": "sdfk_eval_grid: coordinates expanded in-kernel from three axis tables; includes the "
                              "per-call table upload and stream sync"}
 
+    # end to end through host memory (PCIe inclusive): create()-style call on a plain (3, M) float32 host array of
+    # whole x-planes of the same grid, bounded size — a separate line, never `value`
+    host_path = None
+    if rank == 0 and world == 1:
+        planes = max(1, min(int(axes[0].size), int(2.5e7 // (axes[1].size * axes[2].size))))
+        m = planes * int(axes[1].size) * int(axes[2].size)
+        hco = np.empty((3, m), dtype=np.float32)
+        hco[0] = np.repeat(axes[0][:planes], axes[1].size * axes[2].size)
+        hco[1] = np.tile(np.repeat(axes[1], axes[2].size), planes)
+        hco[2] = np.tile(axes[2], planes * axes[1].size)
+        prog.eval_host(hco, device=local_rank, mode=mode)          # warm-up (allocations)
+        h0 = time.perf_counter()
+        prog.eval_host(hco, device=local_rank, mode=mode)
+        hms = (time.perf_counter() - h0) * 1e3
+        host_path = {"ms": hms, "points": m, "mpoints_per_s": m / hms / 1e3, "bytes_over_pcie_per_point": 16,
+                     "note": "sdfk_eval_host: pageable host (3, M) float32 in, (M,) float32 out, synchronous staging"}
+        del hco
+
     allgather = None
-    if world > 1 and not args.no_allgather:
+    if world > 1 and not args.no_allgather and not rehearse:
         pad = (n_total - (world - 1) * per)                   # largest slab
         send = out[:pad].contiguous()
         full = torch.empty((world * pad,), dtype=torch.float32, device=dev)
@@ -225,13 +250,14 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = n_total * args.steps / elapsed / 1e6
         achieved = BYTES_PER_POINT * count / (kernel_ms_max * 1e-3) / 1e9
-        traffic = None
+        traffic = valu_busy = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
                 if rec.get("points_per_launch") == count and rec.get("workload") == args.workload:
                     traffic = rec.get("hbm_bytes_per_launch")
+                    valu_busy = rec.get("valu_active_frac")
             except Exception:  # noqa: BLE001
                 traffic = None
         line = {
@@ -251,8 +277,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel_ms": kernel_ms_max, "bytes_per_point": BYTES_PER_POINT,
-                         "stream_probe_gbps": probe_gbps},
+                         "stream_probe_gbps": probe_gbps, "valu_active_frac": valu_busy},
         }
+        if host_path:
+            line["host_path"] = host_path
         if grid_path:
             line["grid_path"] = grid_path
         if allgather:
