@@ -44,7 +44,7 @@ V_C = {name: (lambda p: 1.0) for name in (
     "P_AXIS", "P_SPHERE", "P_CYLINDER", "P_BOX", "P_TORUS", "P_CHAINLINK", "P_PLANE", "P_UPLANE", "P_SEGMENT3",
     "P_CONE", "P_INFCONE", "P_SOLIDANGLE", "P_TRIANGLE3", "P_QUAD3", "P_SEGLINE3", "P_NEAREST3", "P_CIRCLE", "P_BOX2",
     "P_SEGMENT2", "P_RBOX2", "P_TRIANGLE2", "P_ARC2", "P_ARC3D", "P_SECTOR", "P_INFSECTOR", "P_NGON", "P_SEGLINE2",
-    "P_NEAREST2", "P_ZSLAB")}
+    "P_NEAREST2", "P_ZSLAB", "P_NEARTREE")}
 V_C["P_NEUCIRCLE"] = _neucircle
 # value -> value : factor
 V_V = {

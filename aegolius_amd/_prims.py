@@ -208,12 +208,66 @@ def emit_segline2(L, v, c, points, extra=(), closed_loop=False):
     L.emit("P_SEGLINE2", v, c, params=[len(rows), off])
 
 
+TREE_THRESHOLD = 256     # tables up to this many points are scanned (P_NEAREST*), larger ones go through a box tree
+TREE_LEAF = 32           # points per leaf box, leaf boxes per top box
+
+
+def build_point_tree(points32):
+    """(M, 3) float32 points -> flat float32 table for P_NEARTREE and the number of top boxes.
+    k-d median splits along the longest axis down to leaves of <= TREE_LEAF points; consecutive leaves (spatially
+    coherent in k-d order) are grouped TREE_LEAF at a time under one top box. Boxes are the exact float32 bounds
+    of their points."""
+    pts = np.ascontiguousarray(points32, dtype=np.float32)
+    order = np.arange(pts.shape[0])
+    leaves, stack = [], [order]
+    while stack:
+        idx = stack.pop()
+        if idx.size <= TREE_LEAF:
+            leaves.append(idx)
+            continue
+        sub = pts[idx]
+        axis = int(np.argmax(sub.max(axis=0) - sub.min(axis=0)))
+        half = idx.size // 2
+        part = np.argpartition(sub[:, axis], half)
+        stack.append(idx[part[half:]])
+        stack.append(idx[part[:half]])             # popped first: left-to-right order
+    n_leaf = len(leaves)
+    n_top = (n_leaf + TREE_LEAF - 1) // TREE_LEAF
+    leaf_base = 8 * n_top
+    point_base = leaf_base + 8 * n_leaf
+    table = np.zeros(point_base + 3 * pts.shape[0], dtype=np.float32)
+    cursor = point_base
+    for l, idx in enumerate(leaves):
+        sub = pts[idx]
+        row = table[leaf_base + 8 * l: leaf_base + 8 * l + 8]
+        row[0:3], row[3:6], row[6], row[7] = sub.min(axis=0), sub.max(axis=0), cursor, idx.size
+        table[cursor:cursor + 3 * idx.size] = sub.ravel()
+        cursor += 3 * idx.size
+    for t in range(n_top):
+        first, last = t * TREE_LEAF, min(n_leaf, (t + 1) * TREE_LEAF)
+        boxes = table[leaf_base + 8 * first: leaf_base + 8 * last].reshape(-1, 8)
+        row = table[8 * t: 8 * t + 8]
+        row[0:3], row[3:6], row[6], row[7] = boxes[:, 0:3].min(axis=0), boxes[:, 3:6].max(axis=0), leaf_base + 8 * first, last - first
+    if table.size >= (1 << 24):
+        raise ValueError("nearest-point table too large (indices are carried as fp32)")
+    return table, n_top
+
+
 def emit_nearest(L, v, c, samples, dim):
     s = np.asarray(samples, dtype=np.float64)
     if s.ndim != 2 or s.shape[0] != dim:
         raise ValueError("nearest-point table must have shape (%d, M); got %r" % (dim, s.shape))
     if s.shape[1] < 1:
         raise ValueError("nearest-point table is empty")
+    if s.shape[1] > TREE_THRESHOLD:
+        with np.errstate(over="ignore"):
+            p32 = np.zeros((s.shape[1], 3), dtype=np.float32)
+            p32[:, :dim] = s.T.astype(np.float32)
+        if np.all(np.isfinite(p32)):
+            table, n_top = build_point_tree(p32)
+            off = L.add_table(table)
+            L.emit("P_NEARTREE", v, c, params=[n_top, off, dim])
+            return
     off = L.add_table(s.T)
     L.emit("P_NEAREST3" if dim == 3 else "P_NEAREST2", v, c, params=[s.shape[1], off])
 

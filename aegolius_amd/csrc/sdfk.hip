@@ -211,6 +211,27 @@ static int table_rows_ok(const sdfk_program* p, int op, const float* P, std::str
         case SDFK_OP_P_NEAREST2: row = 2; break;
         case SDFK_OP_P_SHAPESIGN: row = 6; break;
         case SDFK_OP_CURVEINST: row = (P[2] != 0.0f) ? 12 : 3; break;
+        case SDFK_OP_P_NEARTREE: {
+            // every index the kernel will follow stays inside the table; leaves are non-empty
+            if (cnt < 1) return bad("point tree without top boxes");
+            if (P[2] != 2.0f && P[2] != 3.0f) return bad("point tree dimension must be 2 or 3");
+            if (off + 8 * cnt > nt) return bad("point tree: top boxes out of range");
+            const float* t = p->tables.data() + off;
+            const long long room = nt - off;
+            for (long long i = 0; i < cnt; ++i) {
+                const float fl = t[8 * i + 6], fn = t[8 * i + 7];
+                const long long first = (long long)fl, nl = (long long)fn;
+                if (!(fl >= 0.0f) || !(fn >= 1.0f) || (float)first != fl || (float)nl != fn || first + 8 * nl > room)
+                    return bad("point tree: leaf boxes out of range");
+                for (long long l = 0; l < nl; ++l) {
+                    const float pf = t[first + 8 * l + 6], pn = t[first + 8 * l + 7];
+                    const long long pfirst = (long long)pf, pcount = (long long)pn;
+                    if (!(pf >= 0.0f) || !(pn >= 1.0f) || (float)pfirst != pf || (float)pcount != pn || pfirst + 3 * pcount > room)
+                        return bad("point tree: points out of range");
+                }
+            }
+            return 1;
+        }
         case SDFK_OP_P_POLYSIGN: {
             long long pos = off;
             for (long long j = 0; j < cnt; ++j) {
@@ -232,7 +253,7 @@ static int table_rows_ok(const sdfk_program* p, int op, const float* P, std::str
 
 static bool is_table_op(int op) {
     return op == SDFK_OP_P_SEGLINE3 || op == SDFK_OP_P_NEAREST3 || op == SDFK_OP_P_SEGLINE2 ||
-           op == SDFK_OP_P_NEAREST2 || op == SDFK_OP_CURVEINST || op == SDFK_OP_P_POLYSIGN ||
+           op == SDFK_OP_P_NEAREST2 || op == SDFK_OP_CURVEINST || op == SDFK_OP_P_POLYSIGN || op == SDFK_OP_P_NEARTREE ||
            op == SDFK_OP_P_SHAPESIGN;
 }
 

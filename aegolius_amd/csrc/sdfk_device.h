@@ -461,6 +461,62 @@ SDFK_DEV float prim_nearest3(V3 p, const float* __restrict__ P, const float* __r
     return sd_sqrt(best);
 }
 
+// The same distance for large tables: points sorted into leaves of <= 32 (k-d median splits, built on
+// the host: _prims.build_point_tree), leaves grouped into <= 32 per top box. Table at T + P[1]:
+//   top boxes  P[0] x 8 floats : lo(3), hi(3), index of the first leaf box, leaf boxes
+//   leaf boxes          8 floats : lo(3), hi(3), index of the first point, points      (indices relative to the table)
+//   points              3 floats (2-D tables carry z = 0 and the query's z is ignored)
+// A box is skipped only if a slightly deflated lower bound of its distance exceeds the best squared distance found
+// so far, and every visited point goes through the arithmetic of prim_nearest3/2: the result is bit-identical to the
+// brute-force scan (the min does not depend on the order).
+SDFK_DEV float sd_boxdist2(V3 p, const float* __restrict__ b) {
+    const float dx = sd_max0(sd_max(b[0] - p.x, p.x - b[3])), dy = sd_max0(sd_max(b[1] - p.y, p.y - b[4]));
+    const float dz = sd_max0(sd_max(b[2] - p.z, p.z - b[5]));
+    return 0.99999f * sd_fma(dx, dx, sd_fma(dy, dy, dz * dz));
+}
+SDFK_DEV float sd_scan_leaf(V3 p, const float* __restrict__ tab, const float* __restrict__ leaf, float best) {
+    const float* __restrict__ pt = tab + (int)leaf[6];
+    const int n = (int)leaf[7];
+    for (int i = 0; i < n; ++i) {
+        float dx = p.x - pt[3 * i], dy = p.y - pt[3 * i + 1], dz = p.z - pt[3 * i + 2];
+        best = sd_min(best, sd_fma(dx, dx, sd_fma(dy, dy, dz * dz)));
+    }
+    return best;
+}
+SDFK_DEV float prim_neartree(V3 p, const float* __restrict__ P, const float* __restrict__ T) {
+    const int n_top = (int)P[0];
+    const float* __restrict__ tab = T + (int)P[1];
+    if (P[2] == 2.0f) p.z = 0.0f;
+    // a first bound: the nearest top box, its nearest leaf
+    int bt = 0;
+    float bd = 3.0e38f;
+    for (int t = 0; t < n_top; ++t) {
+        const float d = sd_boxdist2(p, tab + 8 * t);
+        if (d < bd) { bd = d; bt = t; }
+    }
+    const float* __restrict__ leaves0 = tab + (int)tab[8 * bt + 6];
+    int bl = 0;
+    bd = 3.0e38f;
+    for (int l = 0; l < (int)tab[8 * bt + 7]; ++l) {
+        const float d = sd_boxdist2(p, leaves0 + 8 * l);
+        if (d < bd) { bd = d; bl = l; }
+    }
+    float best = sd_scan_leaf(p, tab, leaves0 + 8 * bl, 3.0e38f);
+    // pruned sweep over everything else
+    for (int t = 0; t < n_top; ++t) {
+        const float* __restrict__ tb = tab + 8 * t;
+        if (sd_boxdist2(p, tb) > best) continue;
+        const float* __restrict__ leaves = tab + (int)tb[6];
+        const int nl = (int)tb[7];
+        for (int l = 0; l < nl; ++l) {
+            const float* __restrict__ lf = leaves + 8 * l;
+            if ((t == bt && l == bl) || sd_boxdist2(p, lf) > best) continue;
+            best = sd_scan_leaf(p, tab, lf, best);
+        }
+    }
+    return sd_sqrt(best);
+}
+
 // ---- 2-D primitives (z ignored) -------------------------------------------------------------
 // sdf_circle C/sdf_2D.py:12-14
 template <typename T> SDFK_DEV T prim_circle(V3T<T> p, const float* __restrict__ P, const float* __restrict__) {
@@ -725,7 +781,7 @@ SDFK_PAIR_V_C(prim_solidangle) SDFK_PAIR_V_C(prim_triangle3) SDFK_PAIR_V_C(prim_
 SDFK_PAIR_V_C(prim_nearest3) SDFK_PAIR_V_C(prim_neucircle) SDFK_PAIR_V_C(prim_segment2) SDFK_PAIR_V_C(prim_rbox2)
 SDFK_PAIR_V_C(prim_triangle2) SDFK_PAIR_V_C(prim_arc2) SDFK_PAIR_V_C(prim_sector) SDFK_PAIR_V_C(prim_infsector)
 SDFK_PAIR_V_C(prim_ngon) SDFK_PAIR_V_C(prim_segline2) SDFK_PAIR_V_C(prim_nearest2) SDFK_PAIR_V_C(prim_polysign)
-SDFK_PAIR_V_C(prim_shapesign)
+SDFK_PAIR_V_C(prim_shapesign) SDFK_PAIR_V_C(prim_neartree)
 SDFK_PAIR_V_V(val_sigmoid) SDFK_PAIR_V_V(val_capexp) SDFK_PAIR_V_V(val_hardbin) SDFK_PAIR_V_V(val_gauss)
 SDFK_PAIR_V_VV(cmb_boltz) SDFK_PAIR_V_VV(cmb_boltzsub)
 

@@ -604,3 +604,28 @@ def test_row_block_masks_are_conservative(engine):
         acc = sdf_oracle.smin_poly(acc, d[k], w, 3)
     assert alive.sum(axis=0).min() >= 1
     assert alive.mean() < 0.45, alive.mean()                 # central slab of the scene, where the primitives crowd
+
+
+def test_point_tree_equals_brute_force_scan(engine, golden_inputs):
+    """Nearest-point distance through the box tree (P_NEARTREE, tables > 256 points) is bit-identical to the scan
+    over all points (P_NEAREST2/3): clustered, uniform and curve-like clouds, queries inside, near and far away;
+    and it agrees with the float64 oracle."""
+    from aegolius_amd import _prims
+    rng = np.random.default_rng(12)
+    helix = np.stack([np.cos(np.linspace(0, 40, 20000)), np.sin(np.linspace(0, 40, 20000)), np.linspace(-1, 1, 20000)])
+    clouds = [rng.normal(0, 0.5, (3, 16384)), rng.uniform(-1, 1, (3, 3000)), helix,
+              np.concatenate([rng.normal((1, 1, 0), 0.05, (700, 3)), rng.normal((-1, 0, 0.5), 0.2, (900, 3))]).T]
+    co = np.concatenate([golden_inputs, golden_inputs * 8.0, rng.normal(0, 0.5, (3, 3000))], axis=1)
+    co = co.astype(np.float32).astype(np.float64)
+    for pts in clouds:
+        for cls, sub in ((ns.geom_3d.PointCloud3D, pts), (ns.PointCloud2D, pts[:2])):
+            tree = cls(sub).create(co)
+            old = _prims.TREE_THRESHOLD
+            try:
+                _prims.TREE_THRESHOLD = 1 << 30
+                scan = cls(sub).create(co)
+            finally:
+                _prims.TREE_THRESHOLD = old
+            np.testing.assert_array_equal(tree, scan)
+    ref = sdf_oracle.evaluate(ns.geom_3d.PointCloud3D(clouds[0]), co)
+    check("point_cloud_tree", ns.geom_3d.PointCloud3D(clouds[0]).create(co), ref)

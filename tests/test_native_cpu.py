@@ -128,3 +128,39 @@ def test_cull_sites_are_validated(built):
     a.twist(1.0)
     u = ns.CombineGeometry("UNION2").combine(a, ns.Sphere(0.3))
     assert len(lower_geometry(u).cull_sites) == 0
+
+
+def test_point_tree_layout_and_validation(built):
+    """P_NEARTREE: every point sits in exactly one leaf, boxes are the exact bounds, indices stay inside the table;
+    the library refuses a tree whose indices leave it."""
+    from aegolius_amd import _prims
+    rng = np.random.default_rng(4)
+    pts = rng.normal(0, 1, (5000, 3)).astype(np.float32)
+    table, n_top = _prims.build_point_tree(pts)
+    seen = []
+    for t in range(n_top):
+        lo, hi, first, nl = table[8 * t:8 * t + 3], table[8 * t + 3:8 * t + 6], int(table[8 * t + 6]), int(table[8 * t + 7])
+        assert 1 <= nl <= _prims.TREE_LEAF
+        for l in range(nl):
+            row = table[first + 8 * l: first + 8 * l + 8]
+            pf, pn = int(row[6]), int(row[7])
+            assert 1 <= pn <= _prims.TREE_LEAF
+            p = table[pf:pf + 3 * pn].reshape(-1, 3)
+            np.testing.assert_array_equal(p.min(axis=0), row[0:3])
+            np.testing.assert_array_equal(p.max(axis=0), row[3:6])
+            assert np.all(row[0:3] >= lo) and np.all(row[3:6] <= hi)
+            seen.append(p)
+    seen = np.concatenate(seen)
+    assert seen.shape == pts.shape
+    np.testing.assert_array_equal(np.sort(seen.view("f4,f4,f4").ravel()), np.sort(pts.view("f4,f4,f4").ravel()))
+    # through the public classes: large clouds lower to the tree, small ones to the scan
+    names = lambda obj: [_ops.OPS[w & 255].name for w in lower_geometry(obj).code[:, 0]]      # noqa: E731
+    assert "P_NEARTREE" in names(ns.geom_3d.PointCloud3D(pts.T.astype(np.float64)))
+    assert "P_NEAREST3" in names(ns.geom_3d.PointCloud3D(pts[:100].T.astype(np.float64)))
+    assert "P_NEARTREE" in names(ns.PointCloud2D(pts[:, :2].T.astype(np.float64)))
+    low = lower_geometry(ns.geom_3d.PointCloud3D(pts.T.astype(np.float64)))
+    assert built.Program(low.code, low.params, low.tables, low.result_reg).handle
+    bad = low.tables.copy()
+    bad[int(low.params[1]) + 6] = 1e7                       # first leaf index of top box 0 far outside
+    with pytest.raises(built.SdfkError):
+        built.Program(low.code, low.params, bad, low.result_reg)
