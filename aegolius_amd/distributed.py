@@ -81,9 +81,14 @@ class _GpuSlabEvaluator:
     def __init__(self, geometry):
         from . import _engine
         from ._eval import program_for
-        from ._lower import lower_geometry
+        from ._lower import NeedsStage, lower_geometry
         self._engine = _engine
-        self._prog = program_for(lower_geometry(geometry))
+        try:
+            self._prog = program_for(lower_geometry(geometry))
+        except NeedsStage as need:
+            raise NotImplementedError(
+                "the tree contains %r, which needs the whole field on one device (staged evaluation, no slab halos "
+                "yet): evaluate it with geometry.create(co) on a single GPU" % (need.expr.name,)) from None
 
     def __call__(self, axes, start, count):
         import torch

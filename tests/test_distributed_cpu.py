@@ -98,3 +98,16 @@ def test_sharded_evaluation_equals_single_rank(world, resolution):
     for rank, ok, full, r in got:
         assert ok and r == res
         np.testing.assert_array_equal(full, want)
+
+
+def test_sharded_evaluator_refuses_staged_trees():
+    """signed / conv_* / opaque callables need the whole field on one device: the slab evaluator says so instead of
+    leaking a lowering exception."""
+    sys.path.insert(0, ROOT)
+    import aegolius_amd.cores as ns
+    from aegolius_amd.distributed import _GpuSlabEvaluator
+    s = ns.Sphere(0.5)
+    s.boundary()
+    s.signed((8, 8, 8))
+    with pytest.raises(NotImplementedError, match="single GPU"):
+        _GpuSlabEvaluator(s)
