@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--mode", default="auto", choices=["auto", "interpret", "nocull"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-allgather", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host_path extra (it launches the "
+                    "same kernel on a small array, which skews per-kernel averages under rocprofv3)")
     ap.add_argument("--no-rows", action="store_true", help="do not pass the row-length layout hint (flat 128-point bricks)")
     return ap.parse_args()
 
@@ -215,7 +217,7 @@ def main():
     # end to end through host memory (PCIe inclusive): create()-style call on a plain (3, M) float32 host array of
     # whole x-planes of the same grid, bounded size — a separate line, never `value`
     host_path = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_host_path:
         planes = max(1, min(int(axes[0].size), int(2.5e7 // (axes[1].size * axes[2].size))))
         m = planes * int(axes[1].size) * int(axes[2].size)
         hco = np.empty((3, m), dtype=np.float32)
