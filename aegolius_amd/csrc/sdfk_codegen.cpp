@@ -483,13 +483,23 @@ static __device__ __forceinline__ void sdfk_rows_bounds(const sdfk_rowregs& r, i
     const float cy = 0.5f * (sdfk_lane(r.Y[0].x, 0) + sdfk_lane(r.Y[SDFK_RLOADS - 1].w, 63));
     const float cz = 0.5f * (sdfk_lane(r.Z[0].x, 0) + sdfk_lane(r.Z[SDFK_RLOADS - 1].w, 63));
     float d2 = 0.0f;
+    if (uniform) {                                   // one x, y per row segment: |p - c|^2 = dxy^2 + max |z - cz|^2
 #pragma unroll
-    for (int t = 0; t < SDFK_RLOADS; ++t) {
-        const f2 xa = {r.X[t].x, r.X[t].y}, xb = {r.X[t].z, r.X[t].w}, ya = {r.Y[t].x, r.Y[t].y}, yb = {r.Y[t].z, r.Y[t].w};
-        const f2 za = {r.Z[t].x, r.Z[t].y}, zb = {r.Z[t].z, r.Z[t].w};
-        const f2 ax = xa - cx, ay = ya - cy, az = za - cz, bx = xb - cx, by = yb - cy, bz = zb - cz;
-        const f2 da = sd_fma(ax, ax, sd_fma(ay, ay, az * az)), db = sd_fma(bx, bx, sd_fma(by, by, bz * bz));
-        d2 = sd_rawmax(d2, sd_rawmax(sd_rawmax(da.x, da.y), sd_rawmax(db.x, db.y)));
+        for (int t = 0; t < SDFK_RLOADS; ++t) {
+            const float dx = r.X[t].x - cx, dy = r.Y[t].x - cy;
+            const float zm = sd_rawmax(sd_rawmax(sd_abs(r.Z[t].x - cz), sd_abs(r.Z[t].y - cz)),
+                                       sd_rawmax(sd_abs(r.Z[t].z - cz), sd_abs(r.Z[t].w - cz)));
+            d2 = sd_rawmax(d2, sd_fma(zm, zm, sd_fma(dx, dx, dy * dy)));
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < SDFK_RLOADS; ++t) {
+            const f2 xa = {r.X[t].x, r.X[t].y}, xb = {r.X[t].z, r.X[t].w}, ya = {r.Y[t].x, r.Y[t].y}, yb = {r.Y[t].z, r.Y[t].w};
+            const f2 za = {r.Z[t].x, r.Z[t].y}, zb = {r.Z[t].z, r.Z[t].w};
+            const f2 ax = xa - cx, ay = ya - cy, az = za - cz, bx = xb - cx, by = yb - cy, bz = zb - cz;
+            const f2 da = sd_fma(ax, ax, sd_fma(ay, ay, az * az)), db = sd_fma(bx, bx, sd_fma(by, by, bz * bz));
+            d2 = sd_rawmax(d2, sd_rawmax(sd_rawmax(da.x, da.y), sd_rawmax(db.x, db.y)));
+        }
     }
     const float r2 = sdfk_wave_max(d2);
     if (lane == 0) {
