@@ -181,10 +181,33 @@ template <typename T> SDFK_DEV V3T<T> op_zeroz(V3T<T> p, const float* __restrict
     V3T<T> q = {p.x, p.y, sp<T>(0.0f)};
     return q;
 }
+// sin and cos of one angle. |x| <= 8192: Cody-Waite reduction by pi/2 in three parts (exact under fma for these k)
+// and the classic minimax polynomials on [-pi/4, pi/4] (Cephes sinf / cosf coefficients, < 1.5 ulp), inlined: 26
+// VALU instructions against ~60 for the call into ocml's sincosf with its Payne-Hanek tail, which still serves
+// larger arguments and NaN. (The fast intrinsic __sincosf is NOT accurate enough: 1e-6 parity needs ~1 ulp.)
+SDFK_DEV void sd_sincos(float x, float* s, float* c) {
+    if (!(sd_abs(x) <= 8192.0f)) {
+        sincosf(x, s, c);
+        return;
+    }
+    const float k = __builtin_rintf(x * 0.636619772367581343f);
+    float r = sd_fma(k, -1.5703125f, x);
+    r = sd_fma(k, -4.837512969970703125e-4f, r);
+    r = sd_fma(k, -7.54978995489188216e-8f, r);
+    const float z = r * r;
+    const float ps = sd_fma(r * z, sd_fma(z, sd_fma(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+    const float pc = sd_fma(z * z, sd_fma(z, sd_fma(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+                            sd_fma(z, -0.5f, 1.0f));
+    const int q = (int)k;
+    const float ss = (q & 1) ? pc : ps, cc = (q & 1) ? ps : pc;
+    *s = (q & 2) ? -ss : ss;
+    *c = ((q + 1) & 2) ? -cc : cc;
+}
+
 // twist C/modifications.py:517-522 ; P = pitch
 SDFK_DEV V3 op_twist(V3 p, const float* __restrict__ P, const float* __restrict__, int) {
     float s, c;
-    sincosf(P[0] * p.z, &s, &c);
+    sd_sincos(P[0] * p.z, &s, &c);
     V3 q = {sd_fma(c, p.x, -s * p.y), sd_fma(s, p.x, c * p.y), p.z};
     return q;
 }
@@ -243,7 +266,7 @@ SDFK_DEV V3 op_rotsym(V3 p, const float* __restrict__ P, const float* __restrict
     phi = sd_mod(phi, P[0], P[2]) - P[1];
     float r = sd_len2(p.x, p.y);
     float s, c;
-    sincosf(phi, &s, &c);
+    sd_sincos(phi, &s, &c);
     V3 q = {sd_fma(r, c, -P[3]), r * s, p.z};
     return q;
 }
@@ -324,7 +347,7 @@ template <typename T> SDFK_DEV T prim_chainlink(V3T<T> p, const float* __restric
 // sdf_braid C/sdf_3D.py:64-75 ; P = (length/2, R, r, pitch)
 SDFK_DEV float prim_braid(V3 p, const float* __restrict__ P, const float* __restrict__) {
     float s, c;
-    sincosf(P[3] * p.z, &s, &c);
+    sd_sincos(P[3] * p.z, &s, &c);
     // co[:2] = rot[0]*x + rot[1]*y with rot = [[c, s], [-s, c]]  ->  x' = c x - s y ; y' = s x + c y
     float x = sd_fma(c, p.x, -s * p.y);
     float y = sd_fma(s, p.x, c * p.y);
@@ -344,7 +367,7 @@ SDFK_DEV float prim_arc3d(V3 p, const float* __restrict__ P, const float* __rest
     y = sd_abs(y);
     float psi = sd_clip(atan2f(y, x), 0.0f, P[4]);
     float s, c;
-    sincosf(psi, &s, &c);
+    sd_sincos(psi, &s, &c);
     return sd_len3(x - P[0] * c, y - P[0] * s, p.z) - P[1];
 }
 // sdf_plane C/sdf_3D.py:99-102 ; P = (n̂(3), offset)
@@ -386,7 +409,7 @@ SDFK_DEV float sd_sector_tail(float x, float y, const float* __restrict__ P) {
     float phi = atan2f(y, x);
     float psi = sd_clip(phi, 0.0f, P[3]);
     float s, c;
-    sincosf(psi, &s, &c);
+    sd_sincos(psi, &s, &c);
     float length = sd_len2(x - P[0] * c, y - P[0] * s);
     float t = sd_clip(sd_dot2(x, y, P[4], P[5]), 0.0f, P[0]);
     float m = sd_len2(sd_fma(-P[4], t, x), sd_fma(-P[5], t, y));
@@ -575,7 +598,7 @@ SDFK_DEV float prim_arc2(V3 p, const float* __restrict__ P, const float* __restr
     y = sd_abs(y);
     float psi = sd_clip(atan2f(y, x), 0.0f, P[3]);
     float s, c;
-    sincosf(psi, &s, &c);
+    sd_sincos(psi, &s, &c);
     return sd_len2(x - P[0] * c, y - P[0] * s);
 }
 // sdf_sector C/sdf_2D.py:105-129 ; P as sd_sector_tail
@@ -601,7 +624,7 @@ SDFK_DEV float prim_ngon(V3 p, const float* __restrict__ P, const float* __restr
     phi = sd_mod(phi, P[1], P[2]);
     float r = sd_len2(p.x, p.y);
     float s, c;
-    sincosf(phi, &s, &c);
+    sd_sincos(phi, &s, &c);
     float qx = c * r - P[0], qy = s * r;
     float h = sd_clip(sd_dot2(qx, qy, P[3], P[4]), 0.0f, P[7]);
     float len = sd_len2(sd_fma(-P[3], h, qx), sd_fma(-P[4], h, qy));

@@ -629,3 +629,20 @@ def test_point_tree_equals_brute_force_scan(engine, golden_inputs):
             np.testing.assert_array_equal(tree, scan)
     ref = sdf_oracle.evaluate(ns.geom_3d.PointCloud3D(clouds[0]), co)
     check("point_cloud_tree", ns.geom_3d.PointCloud3D(clouds[0]).create(co), ref)
+
+
+def test_inlined_sincos_accuracy(engine):
+    """The kernels' own sincos (Cody-Waite + minimax polynomials, |x| <= 8192, ocml beyond) through a twist of the
+    point (1, 0, z): sdf_x gives cos(pitch*z), sdf_y gives sin(pitch*z). Within 2.5e-7 absolute (about 2 ulp at 1)
+    of float64 over small, moderate and huge angles, quadrant boundaries included."""
+    angles = np.concatenate([np.linspace(-7.0, 7.0, 20001), np.linspace(-8300.0, 8300.0, 20001),
+                             np.arange(-64, 65) * (np.pi / 4), np.linspace(-3.0e5, 3.0e5, 2001)])
+    co = np.zeros((3, angles.size))
+    co[0] = 1.0
+    co[2] = angles.astype(np.float32)                 # pitch 1: the angle is the fp32 z itself
+    exact = co[2].astype(np.float64)
+    for fn, truth in ((ns.sdf_x, np.cos(exact)), (ns.sdf_y, np.sin(exact))):
+        g = ns.GenericGeometry(fn, 0.0)
+        g.twist(1.0)
+        got = g.create(co).astype(np.float64)
+        assert np.abs(got - truth).max() <= 2.5e-7, np.abs(got - truth).max()
