@@ -646,3 +646,29 @@ def test_inlined_sincos_accuracy(engine):
         g.twist(1.0)
         got = g.create(co).astype(np.float64)
         assert np.abs(got - truth).max() <= 2.5e-7, np.abs(got - truth).max()
+
+
+def test_inlined_atan2_accuracy(engine):
+    """The kernels' own atan2 through bend(R = 1, angle = 2 pi): sdf_x of the bent point is atan2(x, 1 - y).
+    All octants, axes, tiny and huge magnitudes, signed zeros; within 1.5 ulp of numpy's float64 arctan2."""
+    rng = np.random.default_rng(8)
+    theta = np.concatenate([np.linspace(-3.1, 3.1, 40001), np.arange(-12, 13) * (np.pi / 8) * 0.999999])
+    rad = np.concatenate([10.0 ** rng.uniform(-6, 4, 40001), np.ones(25)])
+    x = (rad * np.sin(theta)).astype(np.float32)
+    u = (rad * np.cos(theta)).astype(np.float32)          # u = 1 - y
+    extra_x = np.array([0.0, 0.0, 1.0, -1.0, 0.0, -0.0, 3e-30, -3e-30], dtype=np.float32)
+    extra_u = np.array([1.0, -1.0, 0.0, 0.0, 0.0, 2.0, 1e-30, 1e30], dtype=np.float32)
+    x, u = np.concatenate([x, extra_x]), np.concatenate([u, extra_u])
+    co = np.zeros((3, x.size))
+    co[0] = x
+    co[1] = (np.float32(1.0) - u).astype(np.float32)
+    g = ns.GenericGeometry(ns.sdf_x, 0.0)
+    g.bend(1.0, 2 * np.pi)
+    got = g.create(co).astype(np.float64)
+    # what the kernel is asked: atan2(x, -(y - 1)) with y as stored (fp32)
+    uu = -(co[1].astype(np.float32) - np.float32(1.0)).astype(np.float64)
+    want = np.arctan2(co[0], uu)
+    keep = np.abs(want) < 3.14                                    # (at |phi| = pi the bend switches to its rigid tail)
+    err = np.abs(got - want)[keep]
+    ulp = np.spacing(np.maximum(np.abs(want[keep]), 1e-30).astype(np.float32)).astype(np.float64)
+    assert (err / ulp).max() <= 1.5, (err / ulp).max()
