@@ -164,3 +164,22 @@ def test_point_tree_layout_and_validation(built):
     bad[int(low.params[1]) + 6] = 1e7                       # first leaf index of top box 0 far outside
     with pytest.raises(built.SdfkError):
         built.Program(low.code, low.params, bad, low.result_reg)
+
+
+def test_header_is_valid_c_and_links(built, tmp_path):
+    """include/sdfk.h compiles as C99 with -Wall -Werror and a plain-C program drives the library through it
+    (create / source / hiprtc compile check / error reporting / linspace) — no Python, no C++ in the consumer."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    exe = tmp_path / "cabi_smoke"
+    libdir = os.path.join(ROOT, "aegolius_amd")
+    cmd = [gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cabi", "cabi_smoke.c"), "-o", str(exe), "-L", libdir, "-lsdfk",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    run = subprocess.run([str(exe), str(_ops.BY_NAME["P_SPHERE"].code)], capture_output=True, text=True, env=env, timeout=300)
+    assert run.returncode == 0 and "cabi ok" in run.stdout, (run.returncode, run.stdout, run.stderr)
