@@ -653,6 +653,16 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
     long long n4 = vec_ok ? (n / 4) * 4 : 0;
     long long tail = n - n4;
 
+    // Very large trees: hiprtc needs ~0.3 s per primitive for the specialised kernels (minutes beyond a few hundred
+    // primitives); in AUTO mode they run on the interpreter kernel, which needs no compilation
+    // (SDFK_SPECIALIZE_LIMIT instructions, default 600 ~ 200 primitives; MODE_SPECIALIZED always specialises).
+    static const long long spec_limit = [] {
+        const char* e = getenv("SDFK_SPECIALIZE_LIMIT");
+        const long long v = e ? atoll(e) : 600;
+        return v > 0 ? v : 600;
+    }();
+    if (mode == SDFK_MODE_AUTO && (long long)(p->code.size() / 2) > spec_limit && p->interp_ok) mode = SDFK_MODE_INTERPRET;
+
     std::shared_ptr<SpecKernel> sk;
     if (mode != SDFK_MODE_INTERPRET) {
         sk = get_spec(p, device);

@@ -26,7 +26,8 @@ extern "C" {
 #define SDFK_ABI_VERSION 1
 
 /* evaluation modes for sdfk_eval_device / sdfk_set_default_mode */
-#define SDFK_MODE_AUTO 0        /* topology-specialised kernel (hiprtc), built on first use and cached */
+#define SDFK_MODE_AUTO 0        /* topology-specialised kernel (hiprtc), built on first use and cached; programs beyond
+                                   SDFK_SPECIALIZE_LIMIT (env, default 600) instructions run on the interpreter kernel */
 #define SDFK_MODE_INTERPRET 1   /* generic register-machine interpreter kernel */
 #define SDFK_MODE_SPECIALIZED 2 /* as AUTO but fail instead of falling back if hiprtc fails */
 #define SDFK_MODE_NOCULL 3      /* specialised kernel with brick culling switched off (A/B runs, tests) */

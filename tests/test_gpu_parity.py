@@ -672,3 +672,21 @@ def test_inlined_atan2_accuracy(engine):
     err = np.abs(got - want)[keep]
     ulp = np.spacing(np.maximum(np.abs(want[keep]), 1e-30).astype(np.float32)).astype(np.float64)
     assert (err / ulp).max() <= 1.5, (err / ulp).max()
+
+
+def test_very_large_trees_run_without_a_compile(engine, golden_inputs):
+    """A union of 300 spheres (899 instructions) is beyond SDFK_SPECIALIZE_LIMIT: the default mode evaluates it on
+    the interpreter kernel at once (no multi-minute hiprtc build) and matches the oracle."""
+    import time
+    rng = np.random.default_rng(0)
+    objs = []
+    for _ in range(300):
+        s = ns.Sphere(float(rng.uniform(0.03, 0.1)))
+        s.move(tuple(rng.uniform(-1.5, 1.5, 3)))
+        objs.append(s)
+    u = ns.CombineGeometry("UNION").combine(*objs)
+    assert lower_geometry(u).code.shape[0] > 600
+    t0 = time.perf_counter()
+    got = u.create(golden_inputs)
+    assert time.perf_counter() - t0 < 20.0
+    check("union_of_300_spheres", got, sdf_oracle.evaluate(u, golden_inputs))
