@@ -4,7 +4,9 @@ This is the only place the Python layer touches native code. There is no CPU fal
 shared library is missing or no MI355X is visible, evaluation raises.
 """
 import ctypes
+import importlib.util
 import os
+import sys
 import threading
 
 import numpy as np
@@ -51,6 +53,7 @@ SIGNATURES = {
     "sdfk_free": (_int, [_vp]),
     "sdfk_memcpy_h2d": (_int, [_vp, _vp, _sz]),
     "sdfk_memcpy_d2h": (_int, [_vp, _vp, _sz]),
+    "sdfk_memcpy_d2d": (_int, [_vp, _vp, _sz]),
     "sdfk_sync": (_int, [_vp]),
     "sdfk_event_create": (_vp, []),
     "sdfk_event_destroy": (_int, [_vp]),
@@ -68,6 +71,29 @@ _lib = None
 _lock = threading.Lock()
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's).
+    Two HIP runtimes in one process fight over the device: whichever initialises second sees no GPU. If torch is
+    installed but not imported yet, load ITS runtime (and hiprtc) first, so that libsdfk.so — and a later
+    `import torch` — resolve to the same copy. No torch: the system ROCm is used."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libamdhip64.so", "libhiprtc.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def lib():
     """Load libsdfk.so once. Raises (never falls back) when the extension has not been built."""
     global _lib
@@ -79,6 +105,7 @@ def lib():
                         "aegolius_amd: %s is missing - build it with "
                         "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc, gfx950). "
                         "There is no CPU path." % LIB_PATH)
+                _share_torch_hip_runtime()
                 handle = ctypes.CDLL(LIB_PATH)
                 for name, (res, args) in SIGNATURES.items():
                     fn = getattr(handle, name)

@@ -127,10 +127,11 @@ def _plan_stages(lower):
             raise NotImplementedError("more than 32 staged operators in one tree")
 
 
-def _apply_grid_op(lib, node, d_field, n, lower, fields, points4, d_scratch):
-    """Run one operator in place on a device field of n points."""
+def _apply_grid_op(lib, node, d_field, n, lower, fields, points4, d_scratch, shape=None):
+    """Run one operator in place on a device field of n points (`shape`: the field is a slab of planes of the grid
+    the operator's co_resolution describes)."""
     name, args = node.name, node.args
-    shape = _grid_shape(n, args["co_resolution"])
+    shape = _grid_shape(n, args["co_resolution"]) if shape is None else shape
     dims = tuple(shape) + (1,) * (3 - len(shape))
     vp = _engine._vp
     if name == "conv_averaging":
@@ -298,3 +299,71 @@ def _run_staged(lower, co, root=None):
     if edge is not None:
         out = out.reshape(_grid_shape(n, edge.args["co_resolution"]))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# staged evaluation of ONE SLAB of a grid (multi-GPU: aegolius_amd.distributed)
+# ---------------------------------------------------------------------------------------------------
+def _halo_planes(stages, grid_shape, n_total):
+    """Planes of halo a slab needs so that its interior is exact after every operator of `stages`: the reach
+    of each box / edge kernel along the first axis, times its iterations, summed over the chain."""
+    halo = 0
+    for _low, node in stages:
+        if node.name not in ("conv_averaging", "conv_edge_detection"):
+            raise NotImplementedError(
+                "%r cannot run on a slab of the grid (it scans whole grid lines or runs user code on the whole "
+                "field): evaluate the tree with geometry.create(co) on a single GPU" % (node.name,))
+        shape = _grid_shape(n_total, node.args["co_resolution"])
+        if tuple(shape) != tuple(grid_shape):
+            raise ValueError("co_resolution %r of %s does not describe the evaluated grid %r"
+                             % (node.args["co_resolution"], node.name, tuple(grid_shape)))
+        if node.name == "conv_edge_detection":
+            halo += 1
+        else:
+            ks = node.args["kernel_size"]
+            k0 = int(ks) if isinstance(ks, (int, np.integer)) else int(np.asarray(ks).ravel()[0])
+            halo += (k0 // 2) * int(node.args["iterations"])
+    return halo
+
+
+def evaluate_slab_staged(lower, axes, plane0, planes, out_ptr):
+    """Planes [plane0, plane0 + planes) of the grid spanned by `axes` (three per-axis tables) for a tree with
+    conv_averaging / conv_edge_detection nodes, written to the device buffer `out_ptr` (planes * n1 * n2 fp32).
+    The slab is evaluated together with a halo of neighbouring planes (recomputed locally: the per-point stages are
+    cheap, nothing is exchanged); at the true ends of the grid the operators' reflect boundary applies, at the cut
+    ends the contaminated halo planes are dropped. Bit-identical to the same planes of a whole-grid evaluation."""
+    _engine.require_gpu()
+    lib = _engine.lib()
+    vp = _engine._vp
+    ax = [np.ascontiguousarray(a, dtype=np.float32) for a in axes]
+    n0, n1, n2 = (int(a.size) for a in ax)
+    flat2d = n2 == 1
+    grid_shape = (n0, n1) if flat2d else (n0, n1, n2)
+    plane = n1 * n2
+    stages, final, _fields = _plan_stages(lower)
+    halo = _halo_planes(stages, grid_shape, n0 * plane)
+    e0, e1 = max(0, plane0 - halo), min(n0, plane0 + planes + halo)
+    n = (e1 - e0) * plane
+    ext_shape = (e1 - e0, n1) if flat2d else (e1 - e0, n1, n2)
+    stride = (n + 63) // 64 * 64
+    d_aux = lib.sdfk_malloc(max(1, len(stages)) * stride * 4)
+    d_tmp = lib.sdfk_malloc(stride * 4)
+    if not d_aux or not d_tmp:
+        raise _engine.SdfkError("staged slab evaluation: out of device memory")
+    try:
+        def run_program(lowered, d_dst, n_aux):
+            _engine.check(lib.sdfk_eval_grid_aux(program_for(lowered).handle, _engine._ptr(ax[0]), n0, _engine._ptr(ax[1]), n1,
+                                                 _engine._ptr(ax[2]), n2, e0 * plane, n, vp(d_aux), n_aux, stride, vp(d_dst),
+                                                 None, config.mode), "sdfk_eval_grid_aux")
+        known = {}
+        for k, (lowered, node) in enumerate(stages):
+            row = d_aux + 4 * k * stride
+            run_program(lowered, row, k)
+            _apply_grid_op(lib, node, row, n, lower, known, None, d_tmp, shape=ext_shape)
+            known[id(node)] = k
+        run_program(final, d_tmp, len(stages))
+        # hipMemcpy device-to-device through the plumbing entry point (any direction works for device pointers)
+        _engine.check(lib.sdfk_memcpy_d2d(vp(out_ptr), vp(d_tmp + 4 * (plane0 - e0) * plane), planes * plane * 4), "d2d")
+    finally:
+        lib.sdfk_free(vp(d_aux))
+        lib.sdfk_free(vp(d_tmp))

@@ -1108,6 +1108,10 @@ extern "C" int sdfk_memcpy_d2h(void* dst, const void* d_src, size_t bytes) {
     HIPCHK(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
     return 0;
 }
+extern "C" int sdfk_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes) {
+    HIPCHK(hipMemcpy(d_dst, d_src, bytes, hipMemcpyDeviceToDevice));
+    return 0;
+}
 extern "C" int sdfk_sync(void* stream) {
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     return 0;

@@ -64,11 +64,14 @@ def evaluate_grid_sharded(geometry, size, resolution, gather=True, group=None, e
     n_total = int(np.prod([a.size for a in axes64]))
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    # whole grid rows per slab (rows run along the last axis longer than one point)
-    unit = int(axes64[2].size) if axes64[2].size > 1 else int(axes64[1].size)
-    start, count = slab_bounds(n_total, world, rank, unit)
     if evaluate_slab is None:
         evaluate_slab = _GpuSlabEvaluator(geometry)
+    # whole grid rows per slab (rows run along the last axis longer than one point); trees with grid-neighbourhood
+    # operators are cut between planes of the first axis (their slabs carry a halo of planes)
+    unit = int(axes64[2].size) if axes64[2].size > 1 else int(axes64[1].size)
+    if getattr(evaluate_slab, "staged", False):
+        unit = int(axes64[1].size) * int(axes64[2].size)
+    start, count = slab_bounds(n_total, world, rank, unit)
     local = evaluate_slab([a.astype(np.float32) for a in axes64], start, count)
     if gather and world > 1:
         return gather_slabs(local, n_total, group, unit), res
@@ -83,17 +86,36 @@ class _GpuSlabEvaluator:
         from ._eval import program_for
         from ._lower import NeedsStage, lower_geometry
         self._engine = _engine
+        self.staged = False
         try:
             self._prog = program_for(lower_geometry(geometry))
-        except NeedsStage as need:
-            raise NotImplementedError(
-                "the tree contains %r, which needs the whole field on one device (staged evaluation, no slab halos "
-                "yet): evaluate it with geometry.create(co) on a single GPU" % (need.expr.name,)) from None
+        except NeedsStage:
+            # conv_averaging / conv_edge_detection: slabs of whole planes with a recomputed halo (_eval);
+            # signed / opaque user code need the whole field: refused here with the reason
+            from ._eval import _halo_planes, _plan_stages
+            self._lower = lambda **kw: lower_geometry(geometry, **kw)
+            stages, _final, _ = _plan_stages(self._lower)
+            for _low, node in stages:
+                if node.name not in ("conv_averaging", "conv_edge_detection"):
+                    raise NotImplementedError(
+                        "the tree contains %r, which needs the whole field on one device: evaluate it with "
+                        "geometry.create(co) on a single GPU" % (node.name,)) from None
+            self._halo = _halo_planes
+            self.staged = True
 
     def __call__(self, axes, start, count):
         import torch
         self._engine.require_gpu()
         out = torch.empty(count, dtype=torch.float32, device="cuda")
+        if self.staged:
+            from ._eval import evaluate_slab_staged
+            plane = int(axes[1].size) * int(axes[2].size)
+            if start % plane or count % plane:
+                raise ValueError("slabs of a tree with grid-neighbourhood operators must be whole planes of the first axis")
+            torch.cuda.synchronize()
+            if count:
+                evaluate_slab_staged(self._lower, axes, start // plane, count // plane, out.data_ptr())
+            return out
         stream = torch.cuda.current_stream().cuda_stream
         self._prog.eval_grid(axes, start, count, out.data_ptr(), stream=stream)
         return out

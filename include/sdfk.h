@@ -159,6 +159,7 @@ void* sdfk_malloc(size_t bytes);
 int sdfk_free(void* d_ptr);
 int sdfk_memcpy_h2d(void* d_dst, const void* src, size_t bytes);
 int sdfk_memcpy_d2h(void* dst, const void* d_src, size_t bytes);
+int sdfk_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes);
 int sdfk_sync(void* stream);
 void* sdfk_event_create(void);
 int sdfk_event_destroy(void* ev);

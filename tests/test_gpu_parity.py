@@ -11,6 +11,7 @@ coordinates it is computed from: for those scenes (only) the denominator is
 max(1, |ref|, largest intermediate magnitude at that point) as reported by the float64 oracle.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -690,3 +691,60 @@ def test_very_large_trees_run_without_a_compile(engine, golden_inputs):
     got = u.create(golden_inputs)
     assert time.perf_counter() - t0 < 20.0
     check("union_of_300_spheres", got, sdf_oracle.evaluate(u, golden_inputs))
+
+
+def test_sharded_evaluation_of_trees_with_conv_operators(engine):
+    """Slabs of whole planes with a recomputed halo (evaluate_slab_staged): conv_averaging (iterated, even and odd
+    kernels, nested under other modifications) and conv_edge_detection give, slab by slab, exactly the whole-grid
+    field — 3-D and 2-D grids, 'ranks' emulated on one device; signed / user code are refused with the reason."""
+    import torch
+    from aegolius_amd.distributed import _GpuSlabEvaluator, slab_bounds
+    from aegolius_amd.cores.helper_functions import grid_axes
+
+    def tree3(res):
+        a = ns.Box(0.9, 0.7, 0.5)
+        a.rotate(0.6, (1, 1, 0))
+        a.conv_averaging((4, 3, 2), 2, res)
+        a.rounding(0.02)
+        b = ns.Torus(0.5, 0.15)
+        b.conv_edge_detection(res)
+        b.conv_averaging(3, 1, res)
+        return ns.CombineGeometry("UNION2").combine(a, b)
+
+    def tree2(res):
+        c = ns.Circle(0.8)
+        c.conv_averaging((5, 3), 3, res)
+        c.onion(0.05)
+        return c
+    for build, size, resolution in ((tree3, (2, 2, 2), (26, 12, 10)), (tree2, (3, 3), (40, 24))):
+        co, res = ns.generate_grid(size, resolution)
+        whole = np.asarray(build(resolution).create(co)).ravel()
+        axes = [a.astype(np.float32) for a in grid_axes(size, resolution)[0]]
+        plane = axes[1].size * axes[2].size
+        ev = _GpuSlabEvaluator(build(resolution))
+        assert ev.staged
+        for world in (2, 3, 5):
+            parts = [ev(axes, *slab_bounds(whole.size, world, r, plane)) for r in range(world)]
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(torch.cat(parts).cpu().numpy(), whole)
+    s = ns.Sphere(0.5)
+    s.boundary()
+    s.signed((8, 8, 8))
+    with pytest.raises(NotImplementedError, match="single GPU"):
+        _GpuSlabEvaluator(s)
+
+
+def test_library_and_torch_share_one_hip_runtime(engine):
+    """A fresh interpreter that touches libsdfk.so BEFORE importing torch must still leave torch a working GPU
+    (PyTorch-ROCm bundles its own libamdhip64: the engine loads that copy instead of a second runtime)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from aegolius_amd import _engine\n"
+            "_engine.require_gpu()\n"
+            "import torch\n"
+            "assert torch.cuda.is_available()\n"
+            "print(float(torch.ones(8, device='cuda').sum()))\n" % root)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and res.stdout.strip().endswith("8.0"), (res.stdout, res.stderr[-2000:])
