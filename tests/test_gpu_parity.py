@@ -748,3 +748,34 @@ def test_library_and_torch_share_one_hip_runtime(engine):
             "print(float(torch.ones(8, device='cuda').sum()))\n" % root)
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and res.stdout.strip().endswith("8.0"), (res.stdout, res.stderr[-2000:])
+
+
+def test_largest_baseline_grid_2049_cubed_on_one_gpu(engine):
+    """BASELINE configs[4] at full size on ONE device: 2049^3 = 8.6e9 points (flat indices beyond 2^32, 103 GB of
+    coordinates + 34 GB of field resident in HBM), 20-primitive three-level tree through the row-block kernel;
+    40,000 sampled points against the oracle, plus the first and last points."""
+    import torch
+    from aegolius_amd.cores.helper_functions import grid_axes
+    free, _total = torch.cuda.mem_get_info()
+    n1d = 2049
+    n = n1d ** 3
+    if free < 16 * n + (8 << 30):
+        pytest.skip("needs 146 GB of free HBM")
+    tree = scenes.cfg5_tree(ns)
+    prog = engine.Program.from_lowered(lower_geometry(tree))
+    axes = [a.astype(np.float32) for a in grid_axes((3, 3, 3), (2048,) * 3)[0]]
+    co = torch.empty((3, n), dtype=torch.float32, device="cuda")
+    out = torch.empty((n,), dtype=torch.float32, device="cuda")
+    engine.grid_fill(co.data_ptr(), n, axes, 0, n)
+    prog.eval_device(co.data_ptr(), n, n, out.data_ptr(), mode=engine.MODE_SPECIALIZED, row_len=n1d)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(2049)
+    idx = np.unique(np.concatenate([rng.integers(0, n, 40000), [0, n - 1, n1d - 1, n1d, 2 ** 32 - 1, 2 ** 32, 2 ** 33 + 7]]))
+    got = out[torch.from_numpy(idx).cuda()].cpu().numpy()
+    ix, rem = np.divmod(idx, n1d * n1d)
+    iy, iz = np.divmod(rem, n1d)
+    pts = np.stack([axes[0][ix], axes[1][iy], axes[2][iz]]).astype(np.float64)
+    np.testing.assert_array_equal(co[:, torch.from_numpy(idx).cuda()].cpu().numpy(), pts.astype(np.float32))
+    del co
+    with np.errstate(all="ignore"):
+        check("tree_cfg5_three_level", got, sdf_oracle.evaluate(tree, pts))
