@@ -6,6 +6,7 @@ from .modifications import ModifyObject
 from .geom import GenericGeometry
 
 from .helper_functions import resolution_conversion, generate_grid, smarter_reshape
+from .helper_functions import vector_smarter_reshape, nd_vector_smarter_reshape
 
 from .sdf_2D import *  # noqa: F401,F403
 from .sdf_3D import *  # noqa: F401,F403

@@ -131,3 +131,7 @@ class PointCloud2D(GenericGeometry):
         GenericGeometry.__init__(self, P.get("sdf_point_cloud_2d"), self._points)
 
     points = property(lambda self: self._points)
+
+
+class GenericGeometry2D(GenericGeometry):
+    """Reference cores/geom_2d.py:22-36: the same constructor and create / propagate as GenericGeometry."""

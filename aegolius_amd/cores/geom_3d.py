@@ -131,3 +131,7 @@ class PointCloud3D(GenericGeometry):
         GenericGeometry.__init__(self, P.get("sdf_point_cloud_3d"), self._points)
 
     points = property(lambda self: self._points)
+
+
+class GenericGeometry3D(GenericGeometry):
+    """Reference cores/geom_3d.py:22-36: the same constructor and create / propagate as GenericGeometry."""

@@ -93,3 +93,29 @@ def smarter_reshape(pattern, resolution):
         if n_ele // (r[0] * r[1] * r[2]) == 1:
             return pattern.reshape(*r)
         raise bad
+
+
+def vector_smarter_reshape(pattern, resolution):
+    """(3, N) vector field -> array of shape (3, *grid shape) (reference :151-166)."""
+    return np.asarray([smarter_reshape(pattern[i], resolution) for i in range(3)])
+
+
+def nd_vector_smarter_reshape(pattern, resolution):
+    """(ND, N) vector field -> array of shape (ND, *grid shape) (reference :169-188)."""
+    first = smarter_reshape(pattern[0], resolution)
+    out = np.zeros((pattern.shape[0],) + first.shape)
+    out[0] = first
+    for i in range(1, pattern.shape[0]):
+        out[i] = smarter_reshape(pattern[i], resolution)
+    return out
+
+
+def binning(pattern, bins, equal_width=True):
+    """Discretise a field into `bins` levels between its minimum and maximum (reference :191-215)."""
+    lo, span = np.amin(pattern), np.amax(pattern) - np.amin(pattern)
+    v = (pattern - lo) / span
+    if equal_width:
+        u = (v * bins).astype(int) / (bins - 1)
+    else:
+        u = np.round(v * (bins - 1), 0) / (bins - 1)
+    return u * span + lo

@@ -104,3 +104,24 @@ class EuclideanTransform:
             self.rotate_rotvec(inputs[0], np.asarray(inputs[1]))
         elif len(inputs) > 2:
             raise SyntaxError("Wrong number of inputs!")
+
+    # ---- evaluation through the transform (reference cores/transformations.py:232-264) -----------------
+    @staticmethod
+    def apply_ec_transforms(function_, co_, params_, rm, tm, sm):
+        """`sm * function_(co', *params_)` with `co' = (rm^T co_) / sm - rm^T tm`, evaluated on the GPU.
+        `function_`: anything this package accepts as an SDF function (sdf_* functions, modification / combine
+        closures, `other.propagate`, or a plain Python callable — the latter with its code on the host)."""
+        from .._eval import evaluate_geometry
+        from .._lower import as_expr
+
+        class _Transformed:                      # the node protocol the lowering walks
+            rotation_matrix = np.asarray(rm, dtype=float)
+            center = np.asarray(tm, dtype=float)
+            scale = sm
+            modified_object = as_expr(function_)
+            _geo_parameters = tuple(params_)
+        return evaluate_geometry(_Transformed, co_)
+
+    def apply(self, function_, co_, params_):
+        """Apply this object's transformations to an SDF function: field of shape (N,)."""
+        return self.apply_ec_transforms(function_, co_, params_, self.rotation_matrix, self.center, self.scale)

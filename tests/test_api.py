@@ -240,3 +240,18 @@ def test_stage_plan_of_trees_with_grid_operators():
     assert _grid_shape(9 ** 3, 8) == (9, 9, 9) and _grid_shape(9 * 5 * 4, (8, 5)) == (9, 5, 4)
     with pytest.raises(ValueError):
         _grid_shape(100, (8, 8, 8))
+
+
+def test_host_side_helpers_match_the_reference_semantics():
+    """vector reshapes and binning (reference cores/helper_functions.py:151-215): pure host functions."""
+    from aegolius_amd.cores import helper_functions as h
+    v = np.arange(3 * 27, dtype=float).reshape(3, 27)
+    assert h.vector_smarter_reshape(v, 2).shape == (3, 3, 3, 3)
+    assert h.nd_vector_smarter_reshape(v[:2], 2).shape == (2, 3, 3, 3)
+    np.testing.assert_array_equal(h.vector_smarter_reshape(v, 2)[1], v[1].reshape(3, 3, 3))
+    x = np.linspace(0, 1, 7)
+    np.testing.assert_allclose(h.binning(x, 3), [0, 0, 0.5, 0.5, 1, 1, 1.5])
+    np.testing.assert_allclose(h.binning(x, 3, False), [0, 0, 0.5, 0.5, 0.5, 1, 1])
+    assert hasattr(ns.EuclideanTransform, "apply") and hasattr(ns.EuclideanTransform, "apply_ec_transforms")
+    assert issubclass(ns.geom_3d.GenericGeometry3D, ns.GenericGeometry)
+    assert issubclass(ns.geom_2d.GenericGeometry2D, ns.GenericGeometry)

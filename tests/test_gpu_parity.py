@@ -779,3 +779,28 @@ def test_largest_baseline_grid_2049_cubed_on_one_gpu(engine):
     del co
     with np.errstate(all="ignore"):
         check("tree_cfg5_three_level", got, sdf_oracle.evaluate(tree, pts))
+
+
+def test_apply_and_generic_geometry_variants(engine, golden_inputs):
+    """EuclideanTransform.apply / apply_ec_transforms (reference cores/transformations.py:232-264) and the
+    GenericGeometry2D / 3D classes evaluate like the object protocol they are part of."""
+    b = ns.Box(0.4, 0.3, 0.2)
+    b.rotate(0.7, (1, 2, 3))
+    b.move((0.1, -0.2, 0.3))
+    b.set_scale(1.3)
+    want = b.create(golden_inputs)
+    carrier = ns.Sphere(9.0)                            # only its transform matters
+    carrier.rotate(0.7, (1, 2, 3))
+    carrier.move((0.1, -0.2, 0.3))
+    carrier.set_scale(1.3)
+    np.testing.assert_array_equal(carrier.apply(ns.sdf_box, golden_inputs, ((0.4, 0.3, 0.2),)), want)
+    got = ns.EuclideanTransform.apply_ec_transforms(ns.sdf_box, golden_inputs, ((0.4, 0.3, 0.2),), b.rotation_matrix,
+                                                    b.center, b.scale)
+    np.testing.assert_array_equal(got, want)
+    g3 = ns.geom_3d.GenericGeometry3D(ns.sdf_box, (0.4, 0.3, 0.2))
+    g3.rotate(0.7, (1, 2, 3))
+    g3.move((0.1, -0.2, 0.3))
+    g3.set_scale(1.3)
+    np.testing.assert_array_equal(g3.create(golden_inputs), want)
+    g2 = ns.geom_2d.GenericGeometry2D(ns.sdf_circle, 0.5)
+    np.testing.assert_array_equal(g2.propagate(golden_inputs, "ignored"), ns.Circle(0.5).create(golden_inputs))
