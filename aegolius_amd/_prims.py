@@ -380,7 +380,10 @@ def _(L, v, c, args):
     beta = np.pi * (0.5 - 1 / n)
     alpha = 2 * np.pi / n
     s, co = np.sin(beta), np.cos(beta)
-    L.emit("P_NGON", v, c, params=[radius, alpha, 1 / alpha, -co, s, s, co, 2 * radius * np.sin(alpha / 2)])
+    # integer n up to 16: fold by successive rotations instead of atan2 / mod / sincos (prim_ngon)
+    whole = float(n) == int(n) and 3 <= int(n) <= 16
+    L.emit("P_NGON", v, c, params=[radius, alpha, 1 / alpha, -co, s, s, co, 2 * radius * np.sin(alpha / 2),
+                                   np.cos(alpha), np.sin(alpha), int(n) // 2 if whole else 0])
 
 
 @_prim("sdf_segmented_line_2d")     # :191-198

@@ -642,13 +642,30 @@ SDFK_DEV float prim_infsector(V3 p, const float* __restrict__ P, const float* __
 }
 // sdf_ngon C/sdf_2D.py:153-177 ; P = (radius, alpha, 1/alpha, t0 = -cos β, t1 = sin β, n0 = sin β, n1 = cos β, l)
 SDFK_DEV float prim_ngon(V3 p, const float* __restrict__ P, const float* __restrict__) {
-    float phi = sd_atan2(p.y, p.x);
-    phi = (phi < 0.0f) ? SDFK_TWO_PI + phi : phi;
-    phi = sd_mod(phi, P[1], P[2]);
-    float r = sd_len2(p.x, p.y);
-    float s, c;
-    sd_sincos(phi, &s, &c);
-    float qx = c * r - P[0], qy = s * r;
+    float qx, qy;
+    if (P[10] > 0.0f) {
+        // integer n <= 16: the field is mirror-symmetric in y, so fold |y| into the first sector by at most n/2
+        // rotations of -alpha (P[8], P[9] = cos, sin alpha) — no atan2, no sincos, same folded point up to rounding
+        float x = p.x, y = sd_abs(p.y);
+        const int nf = (int)P[10];
+        for (int j = 0; j < nf; ++j) {
+            const float yr = sd_fma(P[8], y, -P[9] * x), xr = sd_fma(P[8], x, P[9] * y);
+            const bool over = yr >= 0.0f;                      // the angle is still >= alpha
+            x = over ? xr : x;
+            y = over ? yr : y;
+        }
+        qx = x - P[0];
+        qy = y;
+    } else {
+        float phi = sd_atan2(p.y, p.x);
+        phi = (phi < 0.0f) ? SDFK_TWO_PI + phi : phi;
+        phi = sd_mod(phi, P[1], P[2]);
+        float r = sd_len2(p.x, p.y);
+        float s, c;
+        sd_sincos(phi, &s, &c);
+        qx = c * r - P[0];
+        qy = s * r;
+    }
     float h = sd_clip(sd_dot2(qx, qy, P[3], P[4]), 0.0f, P[7]);
     float len = sd_len2(sd_fma(-P[3], h, qx), sd_fma(-P[4], h, qy));
     return len * sd_sign(sd_dot2(qx, qy, P[5], P[6]));

@@ -107,6 +107,10 @@ _PRIMS = {
     "neu_circle_1": lambda ns: ns.NEUCircle(0.6, 1),
     "neu_circle_inf": lambda ns: ns.NEUCircle(0.6, np.inf),
     "ngon": lambda ns: ns.NGon(0.6, 5),
+    "ngon_3": lambda ns: ns.NGon(0.5, 3),
+    "ngon_8": lambda ns: ns.NGon(0.7, 8),
+    "ngon_16": lambda ns: ns.NGon(0.65, 16),
+    "ngon_17": lambda ns: ns.NGon(0.65, 17),          # beyond the rotation fold of the GPU kernel: by angle
     "rectangle": lambda ns: ns.Rectangle(0.9, 0.5),
     "rounded_rectangle": lambda ns: ns.RoundedRectangle(1.0, 0.7, (0.1, 0.05, 0.2, 0.0)),
     "segment": lambda ns: ns.Segment((-0.5, -0.2, 0.0), (0.6, 0.4, 0.0)),
@@ -125,7 +129,7 @@ _PRIMS = {
     "point_cloud2d": lambda ns: ns.PointCloud2D(CLOUD3),
 }
 _DISCONT_PRIMS = {"polygon_convex", "polygon_concave", "oriented_infinite_cone", "infinite_sector", "solid_angle",
-                  "sector", "cone", "triangle", "ngon"}
+                  "sector", "cone", "triangle", "ngon", "ngon_3", "ngon_8", "ngon_16", "ngon_17"}
 
 for _name, _make in _PRIMS.items():
     scene("prim_" + _name, _name in _DISCONT_PRIMS)(lambda ns, m=_make: placed(m(ns)))
