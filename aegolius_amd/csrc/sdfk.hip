@@ -489,9 +489,12 @@ static int rows_tiles() {   // tiles per workgroup of the row-block kernel
     static int v = [] { const char* e = getenv("SDFK_RTILES"); int t = e ? atoi(e) : 1; return (t >= 1 && t <= 64) ? t : 1; }();
     return v;
 }
-static int rows_wbricks() {
-    static int v = [] { const char* e = getenv("SDFK_RWBRICKS"); int t = e ? atoi(e) : 2; return (t >= 1 && t <= 16) ? t : 2; }();
-    return v;
+// bricks per wave of the row-block kernel: 2 — except for big trees (> 150 instructions, e.g. the 50-primitive 2-D
+// union), whose whole-tree probe is better shared by 16 bricks per workgroup than by 8 (measured -11 %)
+static int rows_wbricks(const sdfk_program* p) {
+    static int forced = [] { const char* e = getenv("SDFK_RWBRICKS"); int t = e ? atoi(e) : 0; return (t >= 1 && t <= 16) ? t : 0; }();
+    if (forced) return forced;
+    return (p && p->code.size() / 2 > 150) ? 4 : 2;
 }
 struct RowGeom {           // mirrors sdfk_rowgeom of the generated source
     unsigned L, nchunk, nbricks;
@@ -516,7 +519,7 @@ static bool rows_geometry(long long n, long long row_len, RowGeom* g) {
     return true;
 }
 static int tile_threads() { return 64 * tile_waves(); }
-static int rtc_compile(const std::string& src, std::vector<char>* out, std::string* log) {
+static int rtc_compile(const std::string& src, std::vector<char>* out, std::string* log, int rwb) {
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "sdfk_spec.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
         *log = "hiprtcCreateProgram failed";
@@ -527,7 +530,7 @@ static int rtc_compile(const std::string& src, std::vector<char>* out, std::stri
     snprintf(d_tile, sizeof d_tile, "-DSDFK_TWAVES=%d", tile_waves());
     snprintf(d_thr, sizeof d_thr, "-DSDFK_WBRICKS=%d", tile_wbricks());
     snprintf(d_np, sizeof d_np, "-DSDFK_NP=%d", rows_np());
-    snprintf(d_rwb, sizeof d_rwb, "-DSDFK_RWBRICKS=%d", rows_wbricks());
+    snprintf(d_rwb, sizeof d_rwb, "-DSDFK_RWBRICKS=%d", rwb);
     // -fno-honor-nans -mno-amdgpu-ieee: v_min/v_max without the canonicalising pre-op (same flags as the
     // hipcc build of the interpreter kernel, so both flavours stay bit-identical)
     std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17",
@@ -570,7 +573,7 @@ extern "C" int sdfk_program_compile_check(sdfk_program* p, size_t* code_size) {
     if (!src) return fail(-1, "null program");
     std::vector<char> co;
     std::string log;
-    if (rtc_compile(src, &co, &log) != 0) return fail(-3, log);
+    if (rtc_compile(src, &co, &log, rows_wbricks(p)) != 0) return fail(-3, log);
     if (code_size) *code_size = co.size();
     return 0;
 }
@@ -585,7 +588,7 @@ static std::shared_ptr<SpecKernel> get_spec(sdfk_program* p, int device) {
     const char* src = sdfk_program_source(p);
     std::vector<char> co;
     std::string log;
-    if (rtc_compile(src, &co, &log) != 0) {
+    if (rtc_compile(src, &co, &log, rows_wbricks(p)) != 0) {
         sk->failed = true;
         sk->error = log;
         return sk;
@@ -690,7 +693,7 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
             const float* co = arr->co;
             long long stride = arr->stride;
             void* args[] = {&prm, &tab, &co, &stride, &rg, &d_out};
-            const unsigned per_tile = (unsigned)(tile_waves() * rows_wbricks() * rows_tiles());
+            const unsigned per_tile = (unsigned)(tile_waves() * rows_wbricks(p) * rows_tiles());
             const unsigned tiles = (rg.nbricks + per_tile - 1) / per_tile;
             HIPCHK(hipModuleLaunchKernel(sk->rows, tiles, 1, 1, tile_threads(), 1, 1, 0, stream, args, nullptr));
             return 0;
@@ -712,7 +715,7 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
             rg.row0 = grid->start / grow;
             rg.yrows = grid->n2 > 1 ? 0 : 1;
             void* args[] = {&prm, &tab, &g, &rg, &d_out};
-            const unsigned per_tile = (unsigned)(tile_waves() * rows_wbricks() * rows_tiles());
+            const unsigned per_tile = (unsigned)(tile_waves() * rows_wbricks(p) * rows_tiles());
             const unsigned tiles = (rg.nbricks + per_tile - 1) / per_tile;
             HIPCHK(hipModuleLaunchKernel(sk->rows_grid, tiles, 1, 1, tile_threads(), 1, 1, 0, stream, args, nullptr));
             return 0;
@@ -832,7 +835,7 @@ extern "C" int sdfk_debug_row_masks(sdfk_program* p, const float* d_co, int64_t 
     const float* tab = d->d_tables;
     long long stride = row_stride;
     void* args[] = {&prm, &tab, &d_co, &stride, &rg, &d_masks};
-    const unsigned per_tile = (unsigned)(tile_waves() * rows_wbricks());
+    const unsigned per_tile = (unsigned)(tile_waves() * rows_wbricks(p));
     HIPCHK(hipModuleLaunchKernel(sk->rmask, (rg.nbricks + per_tile - 1) / per_tile, 1, 1, tile_threads(), 1, 1, 0, stream,
                                  args, nullptr));
     return 0;
