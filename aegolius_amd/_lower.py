@@ -133,7 +133,7 @@ class Lowerer:
             name, prm = "XLATE", c
         else:
             name, prm = "XFORM", np.concatenate([A.ravel(), c])
-        self._affine[len(self.code)] = (A, c)
+        self._affine[len(self.code)] = (A, c, self.lip_c.get(b, _lip.INF))
         self.emit(name, a, b, params=prm, _fold=False)
 
     def emit(self, opname, a, b=0, c=0, params=(), _fold=True):
@@ -151,13 +151,18 @@ class Lowerer:
             if a == b and last >= self._fold_floor and last in self._affine:
                 lw, lpoff = self.code[last]
                 if (lw >> 8) & 255 == a and all(np.isfinite(A2.ravel())) and all(np.isfinite(c2)):
-                    A1, c1 = self._affine.pop(last)
+                    A1, c1, lip_in = self._affine.pop(last)
                     src = (lw >> 16) & 255
                     self.code.pop()
                     del self.params[lpoff:]
+                    # the merged map starts from what `src` held BEFORE the first map: undo that map's factor on the
+                    # Lipschitz bound when it was applied in place (else the bound is multiplied twice — too small for
+                    # contractions, which would let the culling skip operands it must not)
+                    if src == a:
+                        self.lip_c[a] = lip_in
                     self._emit_affine(a, src, A2.dot(A1), A2.dot(c1) + c2)
                     return
-            self._affine[len(self.code)] = (A2, c2)
+            self._affine[len(self.code)] = (A2, c2, self.lip_c.get(b, _lip.INF))
         poff = len(self.params)
         self.params.extend(params)
         self.code.append((info.code | (a << 8) | (b << 16) | (c << 24), poff))

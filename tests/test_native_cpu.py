@@ -183,3 +183,28 @@ def test_header_is_valid_c_and_links(built, tmp_path):
     env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     run = subprocess.run([str(exe), str(_ops.BY_NAME["P_SPHERE"].code)], capture_output=True, text=True, env=env, timeout=300)
     assert run.returncode == 0 and "cabi ok" in run.stdout, (run.returncode, run.stdout, run.stderr)
+
+
+def test_folded_affine_chains_keep_the_lipschitz_bound():
+    """Consecutive in-place affine maps are merged into one instruction; the Lipschitz bound of the register must be
+    the bound of the merged map, not the first map's factor applied twice (found by tests/fuzz_random_trees.py, seed
+    9002 depth 4: a bound that is too small lets the culling kernels skip an operand they must evaluate)."""
+    from aegolius_amd._lower import Lowerer
+
+    def xform(k, shift):                      # q = k p - shift  (M = k I)
+        return list((np.eye(3) * k).ravel()) + list(shift)
+    L = Lowerer()
+    L.emit("XFORM", 1, 0, params=xform(0.5, (0.1, 0.0, 0.0)))
+    assert np.isclose(L.lip_c[1], 0.5)
+    L.emit("XFORM", 1, 1, params=xform(0.5, (0.0, 0.2, 0.0)))          # merged into the first
+    L.emit("CSCALE", 1, 1, params=[0.8])                                # and again
+    L.emit("XLATE", 1, 1, params=[0.3, 0.0, 0.0])
+    assert len(L.code) == 1 and np.isclose(L.lip_c[1], 0.5 * 0.5 * 0.8)
+    np.testing.assert_allclose(np.asarray(L.params[:9]).reshape(3, 3), np.eye(3) * 0.2)
+    # and through the public API: two nested contractions under a union give K = L_a + L_b of the true fields
+    a = ns.Sphere(0.3)
+    a.scale_sdf(0.5)                            # value scale 0.5, coordinates scaled by 2
+    a.set_scale(0.25)                           # node: coordinates / 0.25, value * 0.25
+    b = ns.Box(0.2, 0.2, 0.2)
+    low = lower_geometry(ns.CombineGeometry("UNION2").combine(a, b))
+    assert low.cull_sites.shape[0] == 1 and np.isclose(low.cull_k[0], 2.0, atol=1e-6)
