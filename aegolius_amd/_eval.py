@@ -100,9 +100,10 @@ def _grid_shape(n, resolution):
 
 
 def _plan_stages(lower):
-    """[(stage program or None, operator node)], final program: every staged operator gets its input from the
-    stage before it (innermost / first-met operators first). Operators that are handed coordinates only
-    (custom_modification, opaque callables) have no stage program of their own."""
+    """[(stage program or None, operator node, position key, geometry parameters)], final program, {key: field index}:
+    every staged operator gets its input from the stage before it (innermost / first-met operators first). Operators
+    that are handed coordinates only (custom_modification, opaque callables) have no stage program of their own.
+    Operators are identified by their POSITION in the tree (the same node object can be used at several places)."""
     from ._lower import NeedsStage
     from ._mods import FIELD_STAGE_OPS
     fields, stages = {}, []
@@ -110,24 +111,25 @@ def _plan_stages(lower):
         try:
             return stages, lower(fields=fields), fields
         except NeedsStage as need:
-            target = need.expr
+            node, key = need.expr, need.key
         while True:
             try:
-                if target.name in FIELD_STAGE_OPS:
-                    prog = lower(fields=fields, stop_at=target)
+                if node.name in FIELD_STAGE_OPS:
+                    prog = lower(fields=fields, stop_at=key)
+                    params = prog.stage_params
                 else:
-                    lower(fields=fields, stop_at=target, probe_axis=0)     # reachable with what is known so far?
+                    params = lower(fields=fields, stop_at=key, probe_axis=0).stage_params   # reachable so far?
                     prog = None
                 break
             except NeedsStage as inner:            # an operator nested in (or met before) the target: that one first
-                target = inner.expr
-        stages.append((prog, target))
-        fields[id(target)] = len(fields)
+                node, key = inner.expr, inner.key
+        stages.append((prog, node, key, params))
+        fields[key] = len(fields)
         if len(fields) > 32:
             raise NotImplementedError("more than 32 staged operators in one tree")
 
 
-def _apply_grid_op(lib, node, d_field, n, lower, fields, points4, d_scratch, shape=None):
+def _apply_grid_op(lib, node, key, d_field, n, lower, fields, points4, d_scratch, shape=None):
     """Run one operator in place on a device field of n points (`shape`: the field is a slab of planes of the grid
     the operator's co_resolution describes)."""
     name, args = node.name, node.args
@@ -153,7 +155,7 @@ def _apply_grid_op(lib, node, d_field, n, lower, fields, points4, d_scratch, sha
         # grid spacings as the operator sees them: coordinate i of the neighbour along axis i minus that of point 0
         seps = []
         for axis in range(3):
-            vals = _eval_few(lib, lower(fields=fields, stop_at=node, probe_axis=axis), points4, len(fields))
+            vals = _eval_few(lib, lower(fields=fields, stop_at=key, probe_axis=axis), points4, len(fields))
             seps.append(abs(float(vals[1 + axis]) - float(vals[0])))
         _engine.check(lib.sdfk_grid_signed(vp(d_field), dims[0], dims[1], dims[2], float(np.float32(min(seps))),
                                            0 if name == "signed_old" else 1, vp(d_scratch), None), "sdfk_grid_signed")
@@ -196,7 +198,7 @@ def _edge_detection_is_outermost(expr):
             return None
 
 
-def _run_host_op(lib, node, lowered, k, n, stride, d_aux, d_out, run_program, lower, known):
+def _run_host_op(lib, node, key, params, lowered, k, n, stride, d_aux, d_out, run_program, lower, known):
     """custom_post_process / custom_modification / an opaque SDF callable: user code on the host between two GPU
     stages. The field (or the coordinates the closure is handed) comes back over PCIe, the result goes up as
     auxiliary field k. Functional completeness, not a fast path."""
@@ -214,9 +216,8 @@ def _run_host_op(lib, node, lowered, k, n, stride, d_aux, d_out, run_program, lo
     else:
         co_here = np.empty((3, n), dtype=np.float64)
         for axis in range(3):
-            run_program(lower(fields=known, stop_at=node, probe_axis=axis), d_out, k)
+            run_program(lower(fields=known, stop_at=key, probe_axis=axis), d_out, k)
             co_here[axis] = fetch(d_out)
-        params = getattr(node, "stage_params", ())
         if node.name == "custom_modification":
             inner = node.inner
 
@@ -273,10 +274,10 @@ def _run_staged(lower, co, root=None):
         points4 = None
         known = {}
         from ._mods import HOST_OPS
-        for k, (lowered, node) in enumerate(stages):
+        for k, (lowered, node, key, params) in enumerate(stages):
             if node.name in HOST_OPS:
-                _run_host_op(lib, node, lowered, k, n, stride, d_aux, d_out, run_program, lower, known)
-                known[id(node)] = k
+                _run_host_op(lib, node, key, params, lowered, k, n, stride, d_aux, d_out, run_program, lower, known)
+                known[key] = k
                 continue
             run_program(lowered, d_aux + 4 * k * stride, k)
             if node.name in ("signed", "signed_old") and points4 is None:
@@ -284,8 +285,8 @@ def _run_staged(lower, co, root=None):
                 if len(shape) == 3:
                     idx = [0, shape[1] * shape[2], shape[2], 1]
                     points4 = np.stack([np.asarray(co[r])[idx] for r in range(3)]).astype(np.float64)
-            _apply_grid_op(lib, node, d_aux + 4 * k * stride, n, lower, known, points4, d_out)   # d_out doubles as scratch
-            known[id(node)] = k
+            _apply_grid_op(lib, node, key, d_aux + 4 * k * stride, n, lower, known, points4, d_out)   # d_out doubles as scratch
+            known[key] = k
         run_program(final, d_out, len(stages))
         out = np.empty(n, dtype=np.float32)
         _engine.check(lib.sdfk_memcpy_d2h(_engine._ptr(out), vp(d_out), n * 4), "d2h")
@@ -308,7 +309,7 @@ def _halo_planes(stages, grid_shape, n_total):
     """Planes of halo a slab needs so that its interior is exact after every operator of `stages`: the reach
     of each box / edge kernel along the first axis, times its iterations, summed over the chain."""
     halo = 0
-    for _low, node in stages:
+    for _low, node, _key, _params in stages:
         if node.name not in ("conv_averaging", "conv_edge_detection"):
             raise NotImplementedError(
                 "%r cannot run on a slab of the grid (it scans whole grid lines or runs user code on the whole "
@@ -356,11 +357,11 @@ def evaluate_slab_staged(lower, axes, plane0, planes, out_ptr):
                                                  _engine._ptr(ax[2]), n2, e0 * plane, n, vp(d_aux), n_aux, stride, vp(d_dst),
                                                  None, config.mode), "sdfk_eval_grid_aux")
         known = {}
-        for k, (lowered, node) in enumerate(stages):
+        for k, (lowered, node, key, _params) in enumerate(stages):
             row = d_aux + 4 * k * stride
             run_program(lowered, row, k)
-            _apply_grid_op(lib, node, row, n, lower, known, None, d_tmp, shape=ext_shape)
-            known[id(node)] = k
+            _apply_grid_op(lib, node, key, row, n, lower, known, None, d_tmp, shape=ext_shape)
+            known[key] = k
         run_program(final, d_tmp, len(stages))
         # hipMemcpy device-to-device through the plumbing entry point (any direction works for device pointers)
         _engine.check(lib.sdfk_memcpy_d2d(vp(out_ptr), vp(d_tmp + 4 * (plane0 - e0) * plane), planes * plane * 4), "d2d")

@@ -33,7 +33,7 @@ class LoweringError(Exception):
 
 
 class LoweredProgram:
-    __slots__ = ("code", "params", "tables", "result_reg", "n_creg", "n_vreg", "cull_sites", "cull_k")
+    __slots__ = ("code", "params", "tables", "result_reg", "n_creg", "n_vreg", "cull_sites", "cull_k", "stage_params")
 
     def __init__(self, code, params, tables, result_reg, n_creg, n_vreg, cull_sites=None, cull_k=None):
         self.code, self.params, self.tables = code, params, tables
@@ -41,6 +41,7 @@ class LoweredProgram:
         # brick-culling sites: rows (combiner index, a_start, a_end, b_start, b_end) + K = L_a + L_b
         self.cull_sites = np.zeros((0, 5), dtype=np.uint32) if cull_sites is None else cull_sites
         self.cull_k = np.zeros(0, dtype=np.float32) if cull_k is None else cull_k
+        self.stage_params = ()     # stage programs: the geometry parameters the staged operator's closure is called with
 
     def key(self):
         return (self.code.tobytes(), self.params.tobytes(), self.tables.tobytes(), self.result_reg,
@@ -55,17 +56,19 @@ class NeedsStage(Exception):
     """Lowering met a grid-neighbourhood operator (signed / conv_*) whose input field has not been computed
     by an earlier evaluation stage yet (see _eval._run_staged)."""
 
-    def __init__(self, expr):
-        Exception.__init__(self, "grid-neighbourhood operator %r needs a staged evaluation" % (expr.name,))
+    def __init__(self, expr, key=None):
+        Exception.__init__(self, "operator %r needs a staged evaluation" % (expr.name,))
         self.expr = expr
+        self.key = key          # where in the tree: the same node can occur at several places (Lowerer._stack)
 
 
 class StageStop(Exception):
     """Raised at the operator a stage program stops at: `vreg` holds the value that stage has to produce."""
 
-    def __init__(self, vreg):
+    def __init__(self, vreg, params=()):
         Exception.__init__(self)
         self.vreg = vreg
+        self.params = tuple(params)   # the geometry parameters the operator's closure is called with
 
 
 class Lowerer:
@@ -80,8 +83,10 @@ class Lowerer:
         self.lip_c = {0: 1.0}      # Lipschitz bound of each register w.r.t. the root point (_lipschitz.py)
         self.lip_v = {}
         self.cull = []             # (combiner index, a_start, a_end, b_start, b_end, K)
-        self.fields = {}           # id(grid-operator node) -> auxiliary field index (fields of earlier stages)
-        self.stop_at = None        # grid-operator node this (stage) program ends at
+        self.fields = {}           # position key of a staged operator -> auxiliary field index (earlier stages)
+        self.stop_at = None        # position key of the operator this (stage) program ends at
+        self._stack = []           # path from the root to the expression being lowered: the position key of a
+                                   # staged operator (the same node object may occur at several places of a tree)
         self.probe_axis = None     # with stop_at: produce coordinate component `probe_axis` there instead
         self._fold_floor = 0       # instructions below this index are never merged into (range boundaries)
         self._affine = {}          # instruction index -> (A (3,3), c (3,)) of an affine coordinate op, float64
@@ -207,6 +212,13 @@ class Lowerer:
 
     # ---- nodes: Euclidean transform around an expression (reference transformations.py:232-242) ----
     def lower_node(self, node, creg, mode):
+        self._stack.append(("n", id(node)))
+        try:
+            return self._lower_node(node, creg, mode)
+        finally:
+            self._stack.pop()
+
+    def _lower_node(self, node, creg, mode):
         if not _is_geometry(node):
             raise LoweringError("object %r is not an aegolius_amd geometry (needs the symbolic node protocol)"
                                 % (node,))
@@ -236,6 +248,15 @@ class Lowerer:
 
     # ---- expressions ----
     def lower_expr(self, expr, creg, mode, params):
+        if isinstance(expr, NodeSDF):              # (a fresh wrapper per lowering: the object it wraps is the identity)
+            return self.lower_node(expr.obj, creg, OWNED if mode == OWNED else FROZEN)
+        self._stack.append(id(expr))
+        try:
+            return self._lower_expr(expr, creg, mode, params)
+        finally:
+            self._stack.pop()
+
+    def _lower_expr(self, expr, creg, mode, params):
         if isinstance(expr, PrimSDF):
             v = self.new_v()
             expr.lower(self, v, creg, params)
@@ -256,7 +277,11 @@ class Lowerer:
 
     def lower_callable(self, fn, creg, mode, params):
         """Second-field argument of displacement / define_volume / recover_volume."""
-        return self.lower_expr(as_expr(fn), creg, mode, params)
+        self._stack.append("second")
+        try:
+            return self.lower_expr(as_expr(fn), creg, mode, params)
+        finally:
+            self._stack.pop()
 
     # ---- combiners (reference combine.py:51-78, 129-135, 154-160) ----
     def _lower_combine(self, expr, creg, mode):
@@ -298,7 +323,11 @@ class Lowerer:
             last = (i == len(kids) - 1)
             b_start = len(self.code)
             self._fold_floor = b_start                     # never merge across an operand-range boundary
-            v = self.lower_node(kid, creg, OWNED if (last and mode == OWNED) else FROZEN)
+            self._stack.append(("child", i))
+            try:
+                v = self.lower_node(kid, creg, OWNED if (last and mode == OWNED) else FROZEN)
+            finally:
+                self._stack.pop()
             if acc is None:
                 acc = v
             else:
@@ -351,7 +380,9 @@ def lower_geometry(node, fields=None, stop_at=None, probe_axis=None):
     try:
         v = L.lower_node(node, 0, OWNED)
     except StageStop as stop:
-        return L.finish(stop.vreg)
+        low = L.finish(stop.vreg)
+        low.stage_params = stop.params
+        return low
     if stop_at is not None:
         raise LoweringError("stage operator not reached")
     return L.finish(v)
@@ -375,7 +406,9 @@ def lower_expression(expr, params, fields=None, stop_at=None, probe_axis=None):
     try:
         v = L.lower_expr(expr, 0, OWNED, tuple(params))
     except StageStop as stop:
-        return L.finish(stop.vreg)
+        low = L.finish(stop.vreg)
+        low.stage_params = stop.params
+        return low
     if stop_at is not None:
         raise LoweringError("stage operator not reached")
     return L.finish(v)

@@ -424,24 +424,24 @@ FIELD_STAGE_OPS = GRID_OPS + ("custom_post_process",)
 
 def _staged_op(L, e, creg, mode, params):
     from ._lower import NeedsStage, StageStop
-    idx = L.fields.get(id(e))
+    key = tuple(L._stack)                      # WHERE this operator sits: one node object may be used at several places
+    idx = L.fields.get(key)
     if idx is not None:
         v = L.new_v()
         L.emit("V_FIELD", v, creg, idx)
         return v
-    if L.stop_at is e:
+    if L.stop_at == key:
         if L.probe_axis is not None:            # the coordinates this operator is handed (signed: grid spacings)
             v = L.new_v()
             L.emit("P_AXIS", v, creg, params=[0.0, float(L.probe_axis)])
         else:
             v = L.lower_expr(e.inner, creg, mode, params)
-        e.stage_params = tuple(params)          # the geometry parameters this closure is called with
-        raise StageStop(v)
+        raise StageStop(v, params)
     if L.stop_at is not None and e.name in FIELD_STAGE_OPS:
         # on the way to another operator: if that one lies inside this one, StageStop passes through here;
         # if not, this operator is met first and must get its own stage first
         L.lower_expr(e.inner, creg, mode, params)
-    raise NeedsStage(e)
+    raise NeedsStage(e, key)
 
 
 for _n in GRID_OPS + ("custom_modification", "custom_post_process"):

@@ -95,7 +95,7 @@ class _GpuSlabEvaluator:
             from ._eval import _halo_planes, _plan_stages
             self._lower = lambda **kw: lower_geometry(geometry, **kw)
             stages, _final, _ = _plan_stages(self._lower)
-            for _low, node in stages:
+            for _low, node, _key, _params in stages:
                 if node.name not in ("conv_averaging", "conv_edge_detection"):
                     raise NotImplementedError(
                         "the tree contains %r, which needs the whole field on one device: evaluate it with "

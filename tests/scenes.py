@@ -679,6 +679,32 @@ def _(ns):
     return u
 
 
+@scene("host_same_callable_used_twice_with_other_parameters")
+def _(ns):
+    # one Python function, two use sites, different parameters: each use is its own stage (stages are keyed by the
+    # position in the tree, not by the callable)
+    s = ns.Sphere(0.55)
+    s.displacement(_user_ripple, (0.03,))
+    s.displacement(_user_ripple, (-0.015,))
+    b = ns.Box(0.5, 0.4, 0.3)
+    b.displacement(_user_ripple, (0.05,))
+    b.move((0.3, 0.0, 0.1))
+    return ns.CombineGeometry("UNION2").combine(s, b)
+
+
+@scene("host_same_object_used_at_two_places")
+def _(ns):
+    # the SAME geometry object (with a user post-process inside) as a child of two different parents that hand it
+    # different coordinates
+    shared = ns.Torus(0.4, 0.12)
+    shared.custom_post_process(_user_tanh, (0.8, 0.5))
+    a = ns.CombineGeometry("UNION2").combine(shared, ns.Sphere(0.2))
+    a.move((0.4, 0.0, 0.0))
+    b = ns.CombineGeometry("INTERSECT2").combine(shared, ns.Box(1.2, 1.2, 0.4))
+    b.rotate(0.8, (1, 0, 0))
+    return ns.CombineGeometry("UNION2").combine(a, b)
+
+
 # -------------------------------------------------------------------------------------------------
 # grid-neighbourhood modifications (signed, conv_averaging, conv_edge_detection): these reshape the field to the
 # grid, so they are evaluated on whole generate_grid clouds, not on the shared point cloud.

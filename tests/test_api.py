@@ -228,7 +228,7 @@ def test_stage_plan_of_trees_with_grid_operators():
     u = ns.CombineGeometry("UNION2").combine(s, b)
     stages, final, fields = _plan_stages(lambda **kw: lower_geometry(u, **kw))
     names = lambda low: [_ops.OPS[w & 255].name for w in low.code[:, 0]]      # noqa: E731
-    assert [node.name for _, node in stages] == ["conv_averaging", "signed", "conv_averaging"]
+    assert [st[1].name for st in stages] == ["conv_averaging", "signed", "conv_averaging"]
     assert names(stages[0][0]) == ["XLATE", "P_SPHERE", "VABS"]
     assert names(stages[1][0])[-2:] == ["P_BOX", "VABS"]
     assert names(stages[2][0])[-1] == "V_FIELD" and stages[2][0].code[-1, 0] >> 24 == 1

@@ -46,7 +46,7 @@ def test_every_scene_lowers_to_a_valid_program(name, built):
         from aegolius_amd._eval import _plan_stages
         stages, low, _ = _plan_stages(lambda **kw: lower_geometry(obj, **kw))
         assert stages and any(_ops.OPS[w & 255].name == "V_FIELD" for w in low.code[:, 0])
-        for stage, _node in stages:
+        for stage in (st[0] for st in stages):
             if stage is not None:
                 assert built.Program(stage.code, stage.params, stage.tables, stage.result_reg).handle
     else:
