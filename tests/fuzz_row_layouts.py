@@ -1,6 +1,7 @@
 """Test-infrastructure script (GPU; not collected by pytest): the row-block kernel under random layouts — grid shapes
 with short / odd / long rows, row counts around multiples of the brick height, shifted (4-byte aligned) pointers,
-row-length hints that do not describe the data — against the plain kernel, bit for bit.
+row-length hints that do not describe the data — against the plain kernel, bit for bit; and the table flavour
+(sdfk_eval_grid_host) on random slabs of the same grids, whole rows and arbitrary ranges.
 
     python tests/fuzz_row_layouts.py [cases]
 """
@@ -57,6 +58,18 @@ def main(cases=80):
             _engine.check(lib.sdfk_memcpy_d2h(_engine._ptr(out), vp(d_out + 4 * mis), n * 4), "d2h")
             res.append(out)
         ok = np.array_equal(res[0], res[1], equal_nan=True)
+        if kind in (0, 1, 3):                                   # a real grid: the table flavour on random slabs
+            for _ in range(3):
+                whole_rows = bool(rng.integers(0, 2))
+                if whole_rows:
+                    r0 = int(rng.integers(0, n0 * n1))
+                    r1 = int(rng.integers(r0, n0 * n1)) + 1
+                    start, count = r0 * L, (r1 - r0) * L
+                else:
+                    start = int(rng.integers(0, n))
+                    count = int(rng.integers(1, n - start + 1))
+                got = prog.eval_grid_host(ax, start, count)
+                ok = ok and np.array_equal(got, res[0][start:start + count], equal_nan=True)
         failures += not ok
         print("case %d: grid %dx%dx%d hint %d kind %d misalign %d stride+%d tree %d  %s" % (
             case, n0, n1, L, hint, kind, mis, stride - n, case % len(progs), "ok" if ok else "MISMATCH at %d points" % int((res[0] != res[1]).sum())), flush=True)
