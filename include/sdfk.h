@@ -111,8 +111,10 @@ void sdfk_set_default_mode(int mode);
 int sdfk_debug_brick_masks(sdfk_program* prog, const float* d_co, int64_t n, int64_t row_stride, uint64_t* d_masks,
                            void* stream);
 /* The same for the row-block kernel of sdfk_eval_device_rows: 3 words per brick {skip bits of sites 0-31, of sites
- * 32-63, rows-uniform flag}; brick q covers rows [brick_rows*(q / nchunk), +brick_rows) and points
- * [32*(q % nchunk), +32) of each, nchunk = ceil(row_len / 32). With d_masks == NULL only *n_bricks and
+ * 32-63, kind: 1 = every row segment has one x and one y, 0 = not}. Bricks are WINDOWS of 32 points aligned in the flat
+ * array: window k of row r is line floor(r * row_len / 32) + k, so it starts up to 31 points before the row when
+ * row_len is no multiple of 32; brick q covers window q % nchunk of rows [brick_rows * (q / nchunk), + brick_rows),
+ * nchunk = row_len / 32 if that is exact, else (row_len + 62) / 32. With d_masks == NULL only *n_bricks and
  * *brick_rows are returned. */
 int sdfk_debug_row_masks(sdfk_program* prog, const float* d_co, int64_t n, int64_t row_stride, int64_t row_len,
                          uint64_t* d_masks, int64_t* n_bricks, int* brick_rows, void* stream);
