@@ -42,6 +42,10 @@ SIGNATURES = {
     "sdfk_grid_edge_detect": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "sdfk_grid_signed": (_int, [_vp, _i64, _i64, _i64, _c.c_float, _int, _vp, _vp]),
     "sdfk_eval_host": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _int, _int]),
+    "sdfk_eval_host_resident": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _int, _int]),
+    "sdfk_field_select_scratch": (_sz, [_i64]),
+    "sdfk_field_select": (_int, [_vp, _i64, _c.c_float, _vp, _i64, _c.POINTER(_i64), _vp, _vp]),
+    "sdfk_field_gradient": (_int, [_vp, _i64, _i64, _i64, _int, _int, _vp, _i64, _vp]),
     "sdfk_eval_grid": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _int]),
     "sdfk_eval_grid_host": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _int, _int]),
     "sdfk_set_default_mode": (None, [_int]),
@@ -245,6 +249,110 @@ class Program:
                 _lib.sdfk_program_destroy(h)
             except Exception:
                 pass
+
+
+class DeviceField:
+    """An (N,) float32 scalar field resident in HBM (what `create_resident` returns): the consumers of the field run
+    on it without the field ever crossing PCIe. Owns its device memory; `free()` (or garbage collection) releases it."""
+
+    def __init__(self, n, device=0):
+        require_gpu()
+        self.n, self.device = int(n), int(device)
+        check(lib().sdfk_set_device(self.device), "sdfk_set_device")
+        self.ptr = lib().sdfk_malloc(max(self.n, 1) * 4)
+        if not self.ptr:
+            raise SdfkError("DeviceField: out of device memory: " + last_error())
+
+    @classmethod
+    def from_host(cls, field, device=0):
+        host = np.ascontiguousarray(field, dtype=np.float32).ravel()
+        self = cls(host.size, device)
+        if host.size:
+            check(lib().sdfk_memcpy_h2d(_vp(self.ptr), _ptr(host), host.size * 4), "sdfk_memcpy_h2d")
+        return self
+
+    def _live(self):
+        if not self.ptr:
+            raise SdfkError("DeviceField has been freed")
+        check(lib().sdfk_set_device(self.device), "sdfk_set_device")
+
+    def numpy(self):
+        self._live()
+        out = np.empty(self.n, dtype=np.float32)
+        if self.n:
+            check(lib().sdfk_memcpy_d2h(_ptr(out), _vp(self.ptr), self.n * 4), "sdfk_memcpy_d2h")
+        return out
+
+    def count(self, threshold=0.0):
+        """Number of points with field <= threshold."""
+        self._live()
+        m = _i64(0)
+        check(lib().sdfk_field_select(_vp(self.ptr), self.n, float(threshold), None, 0, ctypes.byref(m), None, None),
+              "sdfk_field_select")
+        return m.value
+
+    def select(self, threshold=0.0):
+        """Ascending int64 indices of the points with field <= threshold (numpy.flatnonzero(field <= threshold));
+        only the indices cross PCIe."""
+        self._live()
+        L = lib()
+        m = _i64(0)
+        d_scratch = L.sdfk_malloc(L.sdfk_field_select_scratch(self.n))
+        d_index = None
+        try:
+            if not d_scratch:
+                raise SdfkError("select: out of device memory")
+            check(L.sdfk_field_select(_vp(self.ptr), self.n, float(threshold), None, 0, ctypes.byref(m), _vp(d_scratch),
+                                      None), "sdfk_field_select")
+            out = np.empty(m.value, dtype=np.int64)
+            if m.value:
+                d_index = L.sdfk_malloc(m.value * 8)
+                if not d_index:
+                    raise SdfkError("select: out of device memory")
+                check(L.sdfk_field_select(_vp(self.ptr), self.n, float(threshold), _vp(d_index), m.value, ctypes.byref(m),
+                                          _vp(d_scratch), None), "sdfk_field_select")
+                check(L.sdfk_memcpy_d2h(_ptr(out), _vp(d_index), out.size * 8), "sdfk_memcpy_d2h")
+            return out
+        finally:
+            for d in (d_scratch, d_index):
+                if d:
+                    L.sdfk_free(_vp(d))
+
+    def gradient(self, shape, normalize=True):
+        """numpy.gradient (unit spacing) of the field reshaped to `shape` (1 to 3 axes), every vector normalised
+        unless its norm is 0 -> (len(shape), N) float32 host array."""
+        self._live()
+        shape = tuple(int(x) for x in shape)
+        if not 1 <= len(shape) <= 3 or int(np.prod(shape)) != self.n:
+            raise ValueError("cannot reshape a field of %d points to %r" % (self.n, shape))
+        if min(shape) < 2:
+            raise ValueError("Shape of array too small to calculate a numerical gradient, at least (edge_order + 1) elements are required.")
+        dims = (1,) * (3 - len(shape)) + shape
+        L = lib()
+        stride = (self.n + 63) // 64 * 64
+        d_vec = L.sdfk_malloc(len(shape) * stride * 4)
+        if not d_vec:
+            raise SdfkError("gradient: out of device memory")
+        try:
+            check(L.sdfk_field_gradient(_vp(self.ptr), dims[0], dims[1], dims[2], len(shape), 1 if normalize else 0,
+                                        _vp(d_vec), stride, None), "sdfk_field_gradient")
+            out = np.empty((len(shape), self.n), dtype=np.float32)
+            for r in range(len(shape)):
+                check(L.sdfk_memcpy_d2h(_ptr(out[r]), _vp(d_vec + 4 * r * stride), self.n * 4), "sdfk_memcpy_d2h")
+            return out
+        finally:
+            L.sdfk_free(_vp(d_vec))
+
+    def free(self):
+        p, self.ptr = getattr(self, "ptr", None), None
+        if p and _lib is not None:
+            _lib.sdfk_free(_vp(p))
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def linspace_f32(lo, hi, n):

@@ -43,8 +43,10 @@ def program_for(lowered):
     return prog
 
 
-def _run(lowered, co):
+def _run(lowered, co, resident=False):
     axes = getattr(co, "grid_axes", None) if config.grid_fast_path else None
+    if resident:
+        return _run_resident(lowered, co, axes)
     if axes is not None:
         out = program_for(lowered).eval_grid_host(axes, device=config.device, mode=config.mode)
     else:
@@ -54,21 +56,44 @@ def _run(lowered, co):
     return out
 
 
-def evaluate_geometry(node, co):
-    return _evaluate(lambda **kw: lower_geometry(node, **kw), co, node.modified_object)
+def _run_resident(lowered, co, axes):
+    """Same evaluation, field left in HBM as an _engine.DeviceField."""
+    prog = program_for(lowered)
+    if axes is not None:
+        n = int(np.prod([np.asarray(a).size for a in axes]))
+        field = _engine.DeviceField(n, config.device)
+        prog.eval_grid(axes, 0, n, field.ptr, mode=config.mode)
+        _engine.check(_engine.lib().sdfk_sync(None), "sdfk_sync")
+        return field
+    co = np.asarray(co)
+    if co.ndim != 2 or co.shape[0] != 3:
+        raise ValueError("coordinates must have shape (3, N); got %r" % (co.shape,))
+    if co.dtype not in (np.float32, np.float64):
+        co = co.astype(np.float64)
+    co = np.ascontiguousarray(co)
+    n = co.shape[1]
+    field = _engine.DeviceField(n, config.device)
+    _engine.check(_engine.lib().sdfk_eval_host_resident(prog.handle, _engine._ptr(co), 0 if co.dtype == np.float32 else 1, n,
+                                                        n, _engine._vp(field.ptr), config.device, config.mode),
+                  "sdfk_eval_host_resident")
+    return field
+
+
+def evaluate_geometry(node, co, resident=False):
+    return _evaluate(lambda **kw: lower_geometry(node, **kw), co, node.modified_object, resident)
 
 
 def evaluate_expr(expr, co, params):
     return _evaluate(lambda **kw: lower_expression(expr, params, **kw), co, expr)
 
 
-def _evaluate(lower, co, root=None):
+def _evaluate(lower, co, root=None, resident=False):
     from ._lower import NeedsStage
     try:
         lowered = lower()
     except NeedsStage:
-        return _run_staged(lower, co, root)
-    return _run(lowered, co)
+        return _run_staged(lower, co, root, resident)
+    return _run(lowered, co, resident)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -233,7 +258,7 @@ def _run_host_op(lib, node, key, params, lowered, k, n, stride, d_aux, d_out, ru
     _engine.check(lib.sdfk_memcpy_h2d(vp(row), _engine._ptr(result), n * 4), "h2d")
 
 
-def _run_staged(lower, co, root=None):
+def _run_staged(lower, co, root=None, resident=False):
     _engine.require_gpu()
     lib = _engine.lib()
     _engine.check(lib.sdfk_set_device(config.device), "sdfk_set_device")
@@ -288,6 +313,10 @@ def _run_staged(lower, co, root=None):
             _apply_grid_op(lib, node, key, d_aux + 4 * k * stride, n, lower, known, points4, d_out)   # d_out doubles as scratch
             known[key] = k
         run_program(final, d_out, len(stages))
+        if resident:
+            field = _engine.DeviceField(n, config.device)
+            _engine.check(lib.sdfk_memcpy_d2d(vp(field.ptr), vp(d_out), n * 4), "d2d")
+            return field
         out = np.empty(n, dtype=np.float32)
         _engine.check(lib.sdfk_memcpy_d2h(_engine._ptr(out), vp(d_out), n * 4), "d2h")
     finally:

@@ -7,6 +7,7 @@ from .geom import GenericGeometry
 
 from .helper_functions import resolution_conversion, generate_grid, smarter_reshape
 from .helper_functions import vector_smarter_reshape, nd_vector_smarter_reshape
+from .vector_functions import from_sdf
 
 from .sdf_2D import *  # noqa: F401,F403
 from .sdf_3D import *  # noqa: F401,F403

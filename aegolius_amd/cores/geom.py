@@ -39,9 +39,20 @@ class GenericGeometry(EuclideanTransform, ModifyObject):
         self._sdf = self.modified_object
         return evaluate_geometry(self, co)
 
+    def create_resident(self, co):
+        """create(), but the field stays in HBM: returns an `aegolius_amd.DeviceField` (`.numpy()`, `.select()`,
+        `.gradient()`) so that thresholding and gradients run on the device without a PCIe round trip."""
+        self._sdf = self.modified_object
+        return evaluate_geometry(self, co, resident=True)
+
     def point_cloud(self, co):
-        """Interior points (field <= 0) as a (3, M) cloud with z = 0 (reference cores/geom.py:62-74)."""
-        mask = self.create(co) <= 0
-        pts = np.zeros((3, np.count_nonzero(mask)))
-        pts[:2, :] = np.asarray(co)[:2, mask]
+        """Interior points (field <= 0) as a (3, M) cloud with z = 0 (reference cores/geom.py:62-74). The mask is
+        applied on the device; only the indices of the interior points come back."""
+        field = self.create_resident(co)
+        try:
+            inside = field.select(0.0)
+        finally:
+            field.free()
+        pts = np.zeros((3, inside.size))
+        pts[:2, :] = np.asarray(co)[:2, inside]
         return pts

@@ -1037,8 +1037,9 @@ static int64_t detect_row_len(const T* co, int64_t n, int64_t stride) {
     return 0;
 }
 
-extern "C" int sdfk_eval_host(sdfk_program* p, const void* co, int co_dtype, int64_t n, int64_t row_stride, float* out,
-                              int device, int mode) {
+// out_on_device: `out` is device memory of the same device (the field stays resident, nothing comes back)
+static int eval_host_impl(sdfk_program* p, const void* co, int co_dtype, int64_t n, int64_t row_stride, float* out,
+                          int device, int mode, bool out_on_device) {
     if (!p) return fail(-1, "null program");
     if (n < 0 || (n > 0 && (!co || !out))) return fail(-1, "sdfk_eval_host: bad arguments");
     if (co_dtype != 0 && co_dtype != 1) return fail(-1, "sdfk_eval_host: co_dtype must be 0 (fp32) or 1 (fp64)");
@@ -1077,12 +1078,22 @@ extern "C" int sdfk_eval_host(sdfk_program* p, const void* co, int co_dtype, int
         if (rc == 0)
             rc = (row_len > 0 && m % row_len == 0) ? sdfk_eval_device_rows(p, d_co, m, stride, row_len, d_out, nullptr, mode)
                                                    : sdfk_eval_device(p, d_co, m, stride, d_out, nullptr, mode);
-        if (rc == 0 && hipMemcpy(out + s, d_out, (size_t)m * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
-            rc = fail(-6, "sdfk_eval_host: device-to-host copy failed");
+        if (rc == 0 && hipMemcpy(out + s, d_out, (size_t)m * sizeof(float),
+                                 out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(-6, "sdfk_eval_host: copy of the result failed");
     }
     (void)hipFree(d_co);
     (void)hipFree(d_out);
     return rc;
+}
+
+extern "C" int sdfk_eval_host(sdfk_program* p, const void* co, int co_dtype, int64_t n, int64_t row_stride, float* out,
+                              int device, int mode) {
+    return eval_host_impl(p, co, co_dtype, n, row_stride, out, device, mode, false);
+}
+extern "C" int sdfk_eval_host_resident(sdfk_program* p, const void* co, int co_dtype, int64_t n, int64_t row_stride,
+                                       float* d_out, int device, int mode) {
+    return eval_host_impl(p, co, co_dtype, n, row_stride, d_out, device, mode, true);
 }
 
 // ---- plumbing -----------------------------------------------------------------------------------
@@ -1152,3 +1163,4 @@ extern "C" int sdfk_stream_probe(const float* d_co, int64_t n, int64_t row_strid
 }
 
 #include "sdfk_gridops.inc"
+#include "sdfk_fieldops.inc"

@@ -89,6 +89,10 @@ int sdfk_eval_device_rows(sdfk_program* prog, const float* d_co, int64_t n, int6
  * through device memory in chunks, evaluates and copies the fp32 field back. */
 int sdfk_eval_host(sdfk_program* prog, const void* co, int co_dtype, int64_t n, int64_t row_stride, float* out,
                    int device, int mode);
+/* Same staging of host coordinates, but the field is written to d_out — n floats of DEVICE memory on `device` —
+ * and stays there for the field consumers below (nothing is copied back). */
+int sdfk_eval_host_resident(sdfk_program* prog, const void* co, int co_dtype, int64_t n, int64_t row_stride,
+                            float* d_out, int device, int mode);
 /* Evaluate directly on a regular grid without materialising coordinates (4 B/point of traffic):
  * point `start + i` of the flat index n = (ix*n1 + iy)*n2 + iz takes (ax0[ix], ax1[iy], ax2[iz]).
  * Replaces generate_grid + create (cores/helper_functions.py:23-93). Axis tables are HOST pointers. */
@@ -146,6 +150,25 @@ int sdfk_grid_box_average(float* d_field, int64_t n0, int64_t n1, int64_t n2, in
 int sdfk_grid_edge_detect(float* d_field, int64_t n0, int64_t n1, int64_t n2, void* d_scratch, void* stream);
 int sdfk_grid_signed(float* d_field, int64_t n0, int64_t n1, int64_t n2, float sep_min, int crop, void* d_scratch,
                      void* stream);
+
+/* ---- consumers of a resident field -------------------------------------------------------------
+ * What the reference does with the (N,) field right after create(), on the device, synchronous:
+ *   select    = the mask of GenericGeometry.point_cloud (cores/geom.py:62-74): the indices i, ascending, with
+ *               field[i] <= threshold (NaN never selected). *count always receives the size of the selection;
+ *               d_index == NULL counts only; otherwise d_index (DEVICE, capacity entries) must hold the selection.
+ *               d_scratch: sdfk_field_select_scratch(n) bytes of device memory (NULL: allocated and freed inside).
+ *               d_field must be 16-byte aligned.
+ *   gradient  = vector_functions.from_sdf (cores/vector_functions.py:130-140): numpy.gradient with unit spacing
+ *               (central differences, one-sided on the faces) over the LAST ncomp axes of the (n0, n1, n2) field
+ *               (the others must have length 1; every differentiated axis needs >= 2 points), then, if
+ *               normalize != 0, batch_normalize (cores/vector_modification_functions.py:14-20): each vector divided
+ *               by its norm unless the norm is 0. float64 arithmetic, fp32 result: row r of d_vec (DEVICE,
+ *               ncomp rows of row_stride floats) is the derivative along axis 3 - ncomp + r. */
+size_t sdfk_field_select_scratch(int64_t n);
+int sdfk_field_select(const float* d_field, int64_t n, float threshold, int64_t* d_index, int64_t capacity,
+                      int64_t* count, void* d_scratch, void* stream);
+int sdfk_field_gradient(const float* d_field, int64_t n0, int64_t n1, int64_t n2, int ncomp, int normalize,
+                        float* d_vec, int64_t row_stride, void* stream);
 
 /* ---- grid builder -----------------------------------------------------------------------------
  * numpy.linspace(lo, hi, n) in float64 (step = (hi-lo)/(n-1); y[i] = i*step + lo; y[n-1] = hi),

@@ -952,3 +952,25 @@ def _(e, co, params):
         m = (co[0] >= lx) * (co[0] < ux)
         interior[m] *= np.sign(np.dot(co[:2, m].T - points[:2, i], n))
     return _inner(e, co, params) * interior
+
+
+# =================================================================================================
+# consumers of the field
+# =================================================================================================
+def point_cloud(field, co):                          # C/geom.py:62-74
+    """Interior points of an already evaluated field: (3, M) float64, z = 0."""
+    mask = np.asarray(field) <= 0
+    pts = np.zeros((3, np.count_nonzero(mask)))
+    pts[:2, :] = np.asarray(co)[:2, mask]
+    return pts
+
+
+def from_sdf(field, co_resolution):                  # C/vector_functions.py:130-140
+    """Direction of the field's gradient on the grid: (D, N) float64."""
+    dimensions = np.asarray(co_resolution).shape[0]
+    g = _smarter_reshape(np.asarray(field, dtype=np.float64), co_resolution)
+    vec = np.asarray(np.gradient(g)).reshape(dimensions, -1)
+    m = norm(vec, axis=0)                            # batch_normalize, C/vector_modification_functions.py:14-20
+    keep = ~(m == 0)
+    vec[:, keep] = vec[:, keep] / m[keep]
+    return vec

@@ -59,6 +59,22 @@ def main():
             continue
         out["gridscene/" + name] = field
         meta["grid_scenes"][name] = {"grid": key, "shape": list(field.shape)}
+    # consumers of the field: interior point cloud and gradient direction. from_sdf is given the reference's field
+    # rounded to fp32 (stored as an input), so the fixture pins the operator and not the field's last bits.
+    meta["consumer_scenes"] = {}
+    for name, (build, key) in scenes.CONSUMER_SCENES.items():
+        co_g, res_g = scenes.grid_inputs(ref, key)
+        with contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):
+            obj = build(ref, res_g)
+            field = np.asarray(obj.create(co_g.copy()), dtype=np.float64)
+            cloud = np.asarray(obj.point_cloud(co_g.copy()), dtype=np.float64)
+            field32 = field.astype(np.float32)
+            vec = np.asarray(ref.from_sdf(field32.astype(np.float64), res_g), dtype=np.float64)
+        out["consumer/%s/field" % name] = field
+        out["consumer/%s/field32" % name] = field32
+        out["consumer/%s/cloud" % name] = cloud
+        out["consumer/%s/direction" % name] = vec
+        meta["consumer_scenes"][name] = {"grid": key, "interior": int(cloud.shape[1]), "direction_shape": list(vec.shape)}
     # grid builder
     grids = {"g3_even": ((2, 2, 2), (8, 8, 8)), "g3_mixed": ((2.0, 3.0, 1.0), (5, 8, 7)), "g3_scalar_res": ((4, 4, 4), 6),
              "g2": ((10, 6), (8, 5)), "g2_scalar_res": ((3, 3), 4), "g1": ((5,), (6,))}

@@ -845,3 +845,63 @@ def _(ns, res):
     u = ns.CombineGeometry("UNION").combine(a, b, c)
     u.rotate(0.0, (0, 0, 1))
     return u
+
+
+# -------------------------------------------------------------------------------------------------
+# consumers of the field: point_cloud (interior extraction) and from_sdf (gradient direction)
+#   CONSUMER_SCENES[name] = (builder(ns, co_resolution), grid key)
+# -------------------------------------------------------------------------------------------------
+CONSUMER_SCENES = {}
+
+
+def consumer_scene(name, grid):
+    def deco(fn):
+        assert name not in CONSUMER_SCENES, name
+        CONSUMER_SCENES[name] = (fn, grid)
+        return fn
+    return deco
+
+
+@consumer_scene("consume_sphere", "g3")
+def _(ns, res):
+    s = ns.Sphere(0.6)
+    s.move((0.1, -0.05, 0.2))
+    return s
+
+
+@consumer_scene("consume_smooth_union_3d", "g3")
+def _(ns, res):
+    a = ns.Box(0.7, 0.5, 0.9)
+    a.rotate(0.5, (1, 0.2, 0.4))
+    b = ns.Torus(0.5, 0.12)
+    b.move((0.2, 0.1, -0.3))
+    return ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(a, b, parameters=0.15)
+
+
+@consumer_scene("consume_flat_plateaus", "g3")
+def _(ns, res):
+    b = ns.Box(1.25, 1.05, 0.85)               # faces between lattice planes
+    b.hard_binarization(0.0)                   # 0 / 1 field: most gradients vanish, the rest sit on the faces
+    return b
+
+
+@consumer_scene("consume_empty_interior", "g3")
+def _(ns, res):
+    s = ns.Sphere(0.2)
+    s.move((5.0, 0.0, 0.0))                    # nothing inside the grid
+    return s
+
+
+@consumer_scene("consume_circle_2d", "g2")
+def _(ns, res):
+    c = ns.Circle(0.9)
+    c.move((0.3, -0.2, 0.0))
+    return c
+
+
+@consumer_scene("consume_rounded_rectangle_2d", "g2")
+def _(ns, res):
+    r = ns.RoundedRectangle(1.8, 1.1, (0.3, 0.1, 0.2, 0.0))
+    r.rotate(0.4, (0, 0, 1))
+    r.onion(0.1)
+    return r

@@ -1,0 +1,174 @@
+"""GPU parity of the field consumers: interior extraction (`GenericGeometry.point_cloud`,
+sdfk_field_select) and gradient direction (`from_sdf`, sdfk_field_gradient) on a field that stays in HBM.
+
+Selection is integer work: bit-exact against numpy.flatnonzero on the same fp32 field. The gradient direction is
+floating point: |gpu - ref| <= 1e-6 per component (unit vectors), zero vectors exactly zero, the reference being
+given the same fp32 field."""
+import numpy as np
+import pytest
+
+import scenes
+import aegolius_amd
+import aegolius_amd.cores as ns
+from aegolius_amd import DeviceField
+from oracle import sdf_oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def engine(built):
+    built.require_gpu()
+    return built
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 63, 1024, 8191, 8192, 8193, 70001, 1 << 20, (1 << 22) + 5])
+def test_select_equals_flatnonzero(n, engine):
+    rng = np.random.default_rng(n)
+    f = rng.normal(size=n).astype(np.float32)
+    f[rng.random(n) < 0.01] = np.nan                       # NaN is never selected (NumPy: nan <= t is False)
+    f[rng.random(n) < 0.01] = 0.0
+    dev = DeviceField.from_host(f)
+    for thr in (0.0, -0.5, 1.5, -10.0, 10.0):
+        with np.errstate(invalid="ignore"):
+            want = np.flatnonzero(f <= np.float32(thr))
+        got = dev.select(thr)
+        assert got.dtype == np.int64
+        np.testing.assert_array_equal(got, want)
+        assert dev.count(thr) == want.size
+    np.testing.assert_array_equal(dev.numpy(), f)
+    dev.free()
+    with pytest.raises(aegolius_amd._engine.SdfkError):
+        dev.select(0.0)
+
+
+def test_select_patterns_that_stress_the_scan(engine):
+    n = 3 * 8192 * 64 + 17
+    for f in (np.full(n, -1.0, np.float32), np.full(n, 1.0, np.float32),
+              np.where(np.arange(n) % 8192 == 8191, -1.0, 1.0).astype(np.float32),
+              np.where((np.arange(n) // 8192) % 2 == 0, -1.0, 1.0).astype(np.float32)):
+        dev = DeviceField.from_host(f)
+        np.testing.assert_array_equal(dev.select(0.0), np.flatnonzero(f <= 0))
+        dev.free()
+    assert DeviceField.from_host(np.zeros(0, np.float32)).select().size == 0
+
+
+@pytest.mark.parametrize("name", sorted(scenes.CONSUMER_SCENES))
+def test_point_cloud_matches_reference_golden(name, engine, golden):
+    data, _ = golden
+    build, key = scenes.CONSUMER_SCENES[name]
+    co, res = scenes.grid_inputs(ns, key)
+    ref_field = data["consumer/%s/field" % name]
+    ref_cloud = data["consumer/%s/cloud" % name]
+    for points in (co, ns.generate_grid(*scenes.GRIDS[key])[0]):     # plain array and tagged grid (no upload)
+        cloud = build(ns, res).point_cloud(points)
+        assert cloud.dtype == np.float64 and cloud.shape[0] == 3 and not cloud[2].any()
+        # the two clouds may differ only by points whose field is within tolerance of the threshold
+        mine = set(map(tuple, cloud[:2].T))
+        theirs = set(map(tuple, ref_cloud[:2].T))
+        grid = {tuple(p): v for p, v in zip(np.asarray(co)[:2].T, ref_field)} if co.shape[1] < 5000 else {}
+        for p in mine ^ theirs:
+            assert abs(grid[p]) <= TOL, (name, p, grid[p])
+        if name == "consume_flat_plateaus":                          # its field is exactly 0 / 1: nothing is close
+            np.testing.assert_array_equal(cloud, ref_cloud)
+    # and the interior is exactly the mask of OUR field
+    obj = build(ns, res)
+    field = obj.create(co)
+    np.testing.assert_array_equal(obj.point_cloud(co), sdf_oracle.point_cloud(field, co))
+
+
+def direction_check(got, want):
+    assert got.dtype == np.float32 and got.shape == want.shape
+    zero = np.linalg.norm(want, axis=0) == 0
+    assert not got[:, zero].any()
+    assert np.abs(got.astype(np.float64) - want).max() <= TOL
+
+
+@pytest.mark.parametrize("name", sorted(scenes.CONSUMER_SCENES))
+def test_from_sdf_matches_reference_golden(name, engine, golden):
+    data, _ = golden
+    build, key = scenes.CONSUMER_SCENES[name]
+    _, res = scenes.grid_inputs(ns, key)
+    field32 = data["consumer/%s/field32" % name]
+    want = data["consumer/%s/direction" % name]
+    direction_check(ns.from_sdf(field32, res), want)
+    direction_check(ns.from_sdf(field32.astype(np.float64), res), want)
+
+
+@pytest.mark.parametrize("shape", [(2, 2, 2), (3, 70, 129), (33, 17, 64), (35, 5, 200), (2, 300), (129, 65), (7, 2), (77,),
+                                   (2,), (5, 16, 1025 // 5)])
+def test_gradient_direction_on_random_fields(shape, engine):
+    rng = np.random.default_rng(sum(shape))
+    n = int(np.prod(shape))
+    f = rng.normal(size=n).astype(np.float32)
+    f[rng.random(n) < 0.3] = 0.25                              # plateaus: zero differences and zero vectors
+    res = tuple(s - 1 if s % 2 else s for s in shape)          # resolution_conversion maps it back to `shape`
+    assert sdf_oracle._smarter_reshape(f, res if len(res) > 1 else res[0]).shape == shape
+    want = sdf_oracle.from_sdf(f.astype(np.float64), res)
+    direction_check(ns.from_sdf(f, res), want)
+    dev = DeviceField.from_host(f)
+    raw = dev.gradient(shape, normalize=False)                  # numpy.gradient itself: exact in fp64, rounded once
+    np.testing.assert_array_equal(raw, np.asarray(np.gradient(f.astype(np.float64).reshape(shape))).reshape(len(shape), -1)
+                                  .astype(np.float32))
+    dev.free()
+
+
+def test_gradient_rejects_what_numpy_rejects(engine):
+    dev = DeviceField.from_host(np.zeros(12, np.float32))
+    with pytest.raises(ValueError):
+        dev.gradient((12, 1))
+    with pytest.raises(ValueError):
+        dev.gradient((5, 2))
+    with pytest.raises(ValueError):
+        np.gradient(np.zeros((12, 1)))
+
+
+def test_resident_field_feeds_both_consumers_without_a_round_trip(engine):
+    co, res = ns.generate_grid((2, 2, 2), (64, 48, 40))
+    a = ns.Sphere(0.5)
+    b = ns.Box(0.6, 0.4, 0.9)
+    b.rotate(0.7, (1, 1, 0))
+    b.move((0.3, 0.1, 0.0))
+    tree = ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(a, b, parameters=0.1)
+    host = tree.create(co)
+    dev = tree.create_resident(co)
+    assert isinstance(dev, DeviceField) and dev.n == host.size
+    np.testing.assert_array_equal(dev.numpy(), host)
+    np.testing.assert_array_equal(dev.select(), np.flatnonzero(host <= 0))
+    np.testing.assert_array_equal(ns.from_sdf(dev, res), ns.from_sdf(host, res))
+    direction_check(ns.from_sdf(dev, res), sdf_oracle.from_sdf(host.astype(np.float64), res))
+    # a plain (untagged) array takes the staging path and leaves the same field on the device
+    plain = tree.create_resident(np.array(co))
+    np.testing.assert_array_equal(plain.numpy(), host)
+    # staged trees (grid-neighbourhood operators) can stay resident too
+    s = ns.Sphere(0.6)
+    s.conv_averaging((3, 3, 3), 1, res)
+    np.testing.assert_array_equal(s.create_resident(co).numpy(), s.create(co))
+
+
+def test_consumers_at_scale(engine):
+    """513^3 (BASELINE cfg 2's single-box size): properties that need no CPU evaluation of the tree."""
+    co, res = ns.generate_grid((2, 2, 2), (512, 512, 512))
+    s = ns.Sphere(0.5)
+    s.move((0.125, -0.25, 0.0))
+    dev = s.create_resident(co)
+    idx = dev.select(0.0)
+    field = dev.numpy()
+    assert np.all(np.diff(idx) > 0)
+    assert idx.size == np.count_nonzero(field <= 0) and np.all(field[idx] <= 0)
+    # number of lattice points inside the sphere ~ its volume / cell volume
+    cell = (2.0 / 512) ** 3
+    assert abs(idx.size * cell / (4 / 3 * np.pi * 0.5 ** 3) - 1) < 1e-3
+    vec = ns.from_sdf(dev, res)
+    assert vec.shape == (3, field.size)
+    pick = np.random.default_rng(0).integers(0, field.size, 200000)
+    p = np.asarray(co)[:, pick].astype(np.float64) - np.array([[0.125], [-0.25], [0.0]])
+    r = np.linalg.norm(p, axis=0)
+    far = r > 0.05
+    np.testing.assert_allclose(np.linalg.norm(vec[:, pick].astype(np.float64), axis=0)[far], 1.0, atol=1e-6)
+    # the gradient of a distance field points radially; central differences on a 2/512 lattice are second order
+    assert np.abs(vec[:, pick][:, far] - (p / r)[:, far]).max() < 2e-3
+    cloud = s.point_cloud(co)
+    assert cloud.shape == (3, idx.size) and np.array_equal(cloud[:2], np.asarray(co)[:2, idx])

@@ -208,3 +208,16 @@ def test_folded_affine_chains_keep_the_lipschitz_bound():
     b = ns.Box(0.2, 0.2, 0.2)
     low = lower_geometry(ns.CombineGeometry("UNION2").combine(a, b))
     assert low.cull_sites.shape[0] == 1 and np.isclose(low.cull_k[0], 2.0, atol=1e-6)
+
+
+def test_no_gpu_means_an_error_never_a_cpu_result(built):
+    """The product path has no CPU evaluation: without an MI355X every entry point of the path raises."""
+    if built.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    import aegolius_amd.cores as ns
+    co, res = ns.generate_grid((2, 2, 2), (4, 4, 4))
+    s = ns.Sphere(0.5)
+    for call in (lambda: s.create(co), lambda: s.propagate(co), lambda: s.create_resident(co), lambda: s.point_cloud(co),
+                 lambda: ns.from_sdf(np.zeros(125), res), lambda: ns.sdf_sphere(np.asarray(co), 0.5)):
+        with pytest.raises(built.SdfkError, match="no HIP device|no CPU path"):
+            call()

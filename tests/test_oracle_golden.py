@@ -55,6 +55,35 @@ def test_oracle_matches_reference_on_grid_scenes(name, golden):
         assert (ref < 0).sum() > 30                  # the sign really is recovered
 
 
+@pytest.mark.parametrize("name", sorted(scenes.CONSUMER_SCENES))
+def test_oracle_consumers_match_reference(name, golden):
+    """point_cloud (interior extraction) and from_sdf (gradient direction) of the reference, on its own fields."""
+    data, meta = golden
+    build, key = scenes.CONSUMER_SCENES[name]
+    co, res = scenes.grid_inputs(ns, key)
+    field = data["consumer/%s/field" % name]
+    with np.errstate(all="ignore"):
+        assert rel_err(sdf_oracle.evaluate(build(ns, res), co.copy()), field).max() <= 1e-12
+    cloud = sdf_oracle.point_cloud(field, co)
+    np.testing.assert_array_equal(cloud, data["consumer/%s/cloud" % name])
+    assert cloud.shape == (3, meta["consumer_scenes"][name]["interior"])
+    field32 = data["consumer/%s/field32" % name]
+    np.testing.assert_array_equal(field32, field.astype(np.float32))
+    vec = sdf_oracle.from_sdf(field32.astype(np.float64), res)
+    np.testing.assert_array_equal(vec, data["consumer/%s/direction" % name])
+    lengths = np.linalg.norm(vec, axis=0)
+    assert np.all((np.abs(lengths - 1) < 1e-12) | (lengths == 0))
+
+
+def test_consumer_scenes_cover_the_edge_cases(golden):
+    _, meta = golden
+    assert set(meta["consumer_scenes"]) == set(scenes.CONSUMER_SCENES)
+    assert meta["consumer_scenes"]["consume_empty_interior"]["interior"] == 0
+    data = golden[0]
+    flat = data["consumer/consume_flat_plateaus/direction"]
+    assert (np.linalg.norm(flat, axis=0) == 0).mean() > 0.3        # zero gradients stay zero vectors
+
+
 @pytest.mark.parametrize("name", ALL)
 def test_transform_state_matches_reference(name, golden):
     """EuclideanTransform bookkeeping (scipy Rotation composition, centre, scale) equals the reference's."""
