@@ -162,8 +162,10 @@ int sdfk_grid_signed(float* d_field, int64_t n0, int64_t n1, int64_t n2, float s
  *               (central differences, one-sided on the faces) over the LAST ncomp axes of the (n0, n1, n2) field
  *               (the others must have length 1; every differentiated axis needs >= 2 points), then, if
  *               normalize != 0, batch_normalize (cores/vector_modification_functions.py:14-20): each vector divided
- *               by its norm unless the norm is 0. float64 arithmetic, fp32 result: row r of d_vec (DEVICE,
- *               ncomp rows of row_stride floats) is the derivative along axis 3 - ncomp + r. */
+ *               by its norm unless the norm is 0. fp32 arithmetic: the raw gradient (normalize == 0) equals
+ *               numpy's float64 result rounded to fp32, the direction is within 1e-6 per component. Row r of
+ *               d_vec (DEVICE, ncomp rows of row_stride floats) is the derivative along axis 3 - ncomp + r;
+ *               d_field, d_vec and row_stride * 4 must be 16-byte aligned. */
 size_t sdfk_field_select_scratch(int64_t n);
 int sdfk_field_select(const float* d_field, int64_t n, float threshold, int64_t* d_index, int64_t capacity,
                       int64_t* count, void* d_scratch, void* stream);

@@ -3,7 +3,7 @@ sdfk_field_select) and gradient direction (`from_sdf`, sdfk_field_gradient) on a
 
 Selection is integer work: bit-exact against numpy.flatnonzero on the same fp32 field. The gradient direction is
 floating point: |gpu - ref| <= 1e-6 per component (unit vectors), zero vectors exactly zero, the reference being
-given the same fp32 field."""
+given the same fp32 field; the raw (un-normalised) gradient equals numpy's rounded to fp32, bit for bit."""
 import numpy as np
 import pytest
 
@@ -30,8 +30,12 @@ def test_select_equals_flatnonzero(n, engine):
     f = rng.normal(size=n).astype(np.float32)
     f[rng.random(n) < 0.01] = np.nan                       # NaN is never selected (NumPy: nan <= t is False)
     f[rng.random(n) < 0.01] = 0.0
+    f[rng.random(n) < 0.01] = -0.0
+    f[rng.random(n) < 0.005] = np.inf
+    f[rng.random(n) < 0.005] = -np.inf
+    f[rng.random(n) < 0.005] = 1e-42                       # subnormal
     dev = DeviceField.from_host(f)
-    for thr in (0.0, -0.5, 1.5, -10.0, 10.0):
+    for thr in (0.0, -0.0, -0.5, 1.5, -10.0, 10.0, np.inf, -np.inf, 1e-45, np.nan):
         with np.errstate(invalid="ignore"):
             want = np.flatnonzero(f <= np.float32(thr))
         got = dev.select(thr)
@@ -62,21 +66,33 @@ def test_point_cloud_matches_reference_golden(name, engine, golden):
     co, res = scenes.grid_inputs(ns, key)
     ref_field = data["consumer/%s/field" % name]
     ref_cloud = data["consumer/%s/cloud" % name]
+    inside_ref = ref_field <= 0
     for points in (co, ns.generate_grid(*scenes.GRIDS[key])[0]):     # plain array and tagged grid (no upload)
-        cloud = build(ns, res).point_cloud(points)
+        obj = build(ns, res)
+        cloud = obj.point_cloud(points)
         assert cloud.dtype == np.float64 and cloud.shape[0] == 3 and not cloud[2].any()
-        # the two clouds may differ only by points whose field is within tolerance of the threshold
-        mine = set(map(tuple, cloud[:2].T))
-        theirs = set(map(tuple, ref_cloud[:2].T))
-        grid = {tuple(p): v for p, v in zip(np.asarray(co)[:2].T, ref_field)} if co.shape[1] < 5000 else {}
-        for p in mine ^ theirs:
-            assert abs(grid[p]) <= TOL, (name, p, grid[p])
+        inside = obj.create(points) <= 0
+        np.testing.assert_array_equal(cloud[:2], np.asarray(points)[:2, inside])      # the caller's own coordinates
+        # the two masks may differ only where the reference's field is within tolerance of the threshold
+        assert np.all(np.abs(ref_field[inside != inside_ref]) <= TOL)
         if name == "consume_flat_plateaus":                          # its field is exactly 0 / 1: nothing is close
-            np.testing.assert_array_equal(cloud, ref_cloud)
+            np.testing.assert_array_equal(inside, inside_ref)
+    np.testing.assert_array_equal(build(ns, res).point_cloud(co), ref_cloud if np.array_equal(inside, inside_ref) else
+                                  sdf_oracle.point_cloud(np.where(inside, -1.0, 1.0), co))
     # and the interior is exactly the mask of OUR field
     obj = build(ns, res)
     field = obj.create(co)
     np.testing.assert_array_equal(obj.point_cloud(co), sdf_oracle.point_cloud(field, co))
+
+
+def numpy_direction(f, shape):
+    """from_sdf's arithmetic on an arbitrary shape (resolution_conversion only produces odd extents)."""
+    vec = np.asarray(np.gradient(f.astype(np.float64).reshape(shape))).reshape(len(shape), -1)
+    m = np.linalg.norm(vec, axis=0)
+    keep = ~(m == 0)
+    raw = vec.copy()
+    vec[:, keep] = vec[:, keep] / m[keep]
+    return raw, vec
 
 
 def direction_check(got, want):
@@ -97,22 +113,53 @@ def test_from_sdf_matches_reference_golden(name, engine, golden):
     direction_check(ns.from_sdf(field32.astype(np.float64), res), want)
 
 
-@pytest.mark.parametrize("shape", [(2, 2, 2), (3, 70, 129), (33, 17, 64), (35, 5, 200), (2, 300), (129, 65), (7, 2), (77,),
-                                   (2,), (5, 16, 1025 // 5)])
+@pytest.mark.parametrize("shape", [(2, 2, 2), (3, 70, 129), (33, 17, 64), (35, 5, 201), (2, 300), (129, 65), (7, 2), (77,),
+                                   (2,), (5, 17, 1025), (4, 3, 5000), (3, 9000, 3), (40000, 3), (3, 40000)])
 def test_gradient_direction_on_random_fields(shape, engine):
     rng = np.random.default_rng(sum(shape))
     n = int(np.prod(shape))
     f = rng.normal(size=n).astype(np.float32)
     f[rng.random(n) < 0.3] = 0.25                              # plateaus: zero differences and zero vectors
-    res = tuple(s - 1 if s % 2 else s for s in shape)          # resolution_conversion maps it back to `shape`
-    assert sdf_oracle._smarter_reshape(f, res if len(res) > 1 else res[0]).shape == shape
-    want = sdf_oracle.from_sdf(f.astype(np.float64), res)
-    direction_check(ns.from_sdf(f, res), want)
+    raw, want = numpy_direction(f, shape)
     dev = DeviceField.from_host(f)
-    raw = dev.gradient(shape, normalize=False)                  # numpy.gradient itself: exact in fp64, rounded once
-    np.testing.assert_array_equal(raw, np.asarray(np.gradient(f.astype(np.float64).reshape(shape))).reshape(len(shape), -1)
-                                  .astype(np.float32))
+    direction_check(dev.gradient(shape), want)
+    # numpy.gradient itself: the fp32 difference is the float64 difference rounded once
+    np.testing.assert_array_equal(dev.gradient(shape, normalize=False), raw.astype(np.float32))
     dev.free()
+    if all(s % 2 for s in shape):                              # reachable through the reference's signature
+        res = tuple(s - 1 for s in shape)
+        np.testing.assert_array_equal(want, sdf_oracle.from_sdf(f.astype(np.float64), res))
+        direction_check(ns.from_sdf(f, res), want)
+
+
+@pytest.mark.parametrize("scale", [1e-42, 1e-30, 1e-12, 1e12, 1e30, 1.5e38])
+def test_gradient_direction_does_not_overflow_or_vanish(scale, engine):
+    """fp32 arithmetic with power-of-two scaling: squares of 1e30 or 1e-30 differences never reach the sum."""
+    shape = (9, 20, 67)
+    rng = np.random.default_rng(5)
+    f = (rng.uniform(-1, 1, size=int(np.prod(shape))) * scale).astype(np.float32)
+    f[rng.random(f.size) < 0.2] = np.float32(scale) * np.float32(0.5)
+    with np.errstate(all="ignore"):
+        _, want = numpy_direction(f, shape)
+    dev = DeviceField.from_host(f)
+    direction_check(dev.gradient(shape), want)
+    dev.free()
+
+
+def test_gradient_direction_with_nan_and_inf(engine):
+    shape = (6, 8, 40)
+    rng = np.random.default_rng(6)
+    f = rng.normal(size=int(np.prod(shape))).astype(np.float32)
+    f[[17, 400, 1333]] = np.nan
+    f[[55, 900]] = np.inf
+    with np.errstate(all="ignore"):
+        _, want = numpy_direction(f, shape)
+    dev = DeviceField.from_host(f)
+    got = dev.gradient(shape)
+    dev.free()
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    assert np.abs(got[ok].astype(np.float64) - want[ok]).max() <= TOL
 
 
 def test_gradient_rejects_what_numpy_rejects(engine):

@@ -1,0 +1,338 @@
+// Developer tool: candidate layouts for the gradient-direction kernel on an (n0, n1, n2) field (sdfk_fieldops.inc).
+//   hipcc --offload-arch=gfx950 -O3 -o gradbench tools/gradbench.hip && ./gradbench 1025
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <cmath>
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+struct GridDims { int n0, n1, n2; };
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+static __device__ __forceinline__ double dif(double lo, double c, double hi, int pos, int n) {
+    return pos == 0 ? hi - c : (pos == n - 1 ? c - lo : 0.5 * (hi - lo));
+}
+
+
+static __device__ __forceinline__ float dif32(float lo, float c, float hi, int pos, int n) {
+    return pos == 0 ? hi - c : (pos == n - 1 ? c - lo : 0.5f * (hi - lo));
+}
+// fp32 direction: scale by a power of two so that squares neither overflow nor vanish, v_rsq_f32 (1 ulp)
+static __device__ __forceinline__ void unit32(float& x, float& y, float& z) {
+    const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+    if (mx == 0.0f) return;
+    const int e = __builtin_amdgcn_frexp_expf(mx);
+    const float a = __builtin_amdgcn_ldexpf(x, -e), b = __builtin_amdgcn_ldexpf(y, -e), c = __builtin_amdgcn_ldexpf(z, -e);
+    const float r = __builtin_amdgcn_rsqf(fmaf(a, a, fmaf(b, b, c * c)));
+    x = a * r; y = b * r; z = c * r;
+}
+
+// ---- variant M: marching tile (16 rows x 64 columns, XSEG planes), optional XCD-contiguous block order ----
+template <bool REMAP, int ROWS, int XSEG, int MODE>   // MODE 0 full, 1 no stores (sum to one word), 2 stores only
+__global__ __launch_bounds__(256) void march(const float* __restrict__ f, GridDims d, float* __restrict__ out, long long stride,
+                                             unsigned gx, unsigned gy, unsigned total) {
+    unsigned L = blockIdx.x;
+    if (REMAP) {
+        const unsigned per = (total + 7) / 8;
+        L = (L % 8) * per + L / 8;
+        if (L >= total) return;
+    }
+    const unsigned bx = L % gx, by = (L / gx) % gy, bz = L / (gx * gy);
+    const int k = bx * 64 + (threadIdx.x & 63);
+    const int j0 = by * (4 * ROWS) + (threadIdx.x >> 6) * ROWS;
+    const int i0 = bz * XSEG;
+    if (k >= d.n2 || j0 >= d.n1) return;
+    const int i1 = i0 + XSEG < d.n0 ? i0 + XSEG : d.n0;
+    const long long plane = (long long)d.n1 * d.n2;
+    float prev[ROWS], cur[ROWS], next[ROWS];
+    long long idx = ((long long)i0 * d.n1 + j0) * d.n2 + k;
+    float acc = 0;
+    for (int r = 0; r < ROWS; ++r) {
+        const bool in = j0 + r < d.n1;
+        cur[r] = (in && MODE != 2) ? f[idx + (long long)r * d.n2] : 0.0f;
+        prev[r] = (in && i0 > 0 && MODE != 2) ? f[idx + (long long)r * d.n2 - plane] : cur[r];
+    }
+    for (int i = i0; i < i1; ++i, idx += plane) {
+        for (int r = 0; r < ROWS; ++r)
+            next[r] = (i + 1 < d.n0 && j0 + r < d.n1 && MODE != 2) ? f[idx + (long long)r * d.n2 + plane] : cur[r];
+        const float above = (j0 > 0 && MODE != 2) ? f[idx - d.n2] : cur[0];
+        const float below = (j0 + ROWS < d.n1 && MODE != 2) ? f[idx + (long long)ROWS * d.n2] : 0.0f;
+        for (int r = 0; r < ROWS; ++r) {
+            const int j = j0 + r;
+            if (j >= d.n1) break;
+            const long long p = idx + (long long)r * d.n2;
+            const double c = cur[r];
+            const float left = (k > 0 && MODE != 2) ? f[p - 1] : cur[r];
+            const float right = (k + 1 < d.n2 && MODE != 2) ? f[p + 1] : cur[r];
+            double g[3];
+            g[0] = dif(prev[r], c, next[r], i, d.n0);
+            g[1] = dif(r > 0 ? cur[r - 1] : above, c, r + 1 < ROWS ? cur[r + 1] : below, j, d.n1);
+            g[2] = dif(left, c, right, k, d.n2);
+            const double m = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+            if (m != 0.0) { g[0] /= m; g[1] /= m; g[2] /= m; }
+            if (MODE == 1) acc += (float)(g[0] + g[1] + g[2]);
+            else
+                for (int a = 0; a < 3; ++a) __builtin_nontemporal_store((float)g[a], out + (long long)a * stride + p);
+        }
+        for (int r = 0; r < ROWS; ++r) { prev[r] = cur[r]; cur[r] = next[r]; }
+    }
+    if (MODE == 1 && acc == 12345.678f) out[0] = acc;
+}
+
+// ---- variant F: flat aligned quads, no marching (plane neighbours through L2 / MALL), XCD-contiguous chunks ----
+template <bool REMAP, int MODE, int MATH>
+__global__ __launch_bounds__(256) void flat(const float* __restrict__ f, GridDims d, float* __restrict__ out, long long stride,
+                                            long long n, unsigned total) {
+    unsigned L = blockIdx.x;
+    if (REMAP) {
+        const unsigned per = (total + 7) / 8;
+        L = (L % 8) * per + L / 8;
+        if (L >= total) return;
+    }
+    const long long p = ((long long)L * 256 + threadIdx.x) * 4;
+    if (p >= n) return;
+    const long long plane = (long long)d.n1 * d.n2;
+    int k = (int)(p % d.n2);
+    const long long r = p / d.n2;
+    int j = (int)(r % d.n1), i = (int)(r / d.n1);
+    float c[6], ylo[4], yhi[4], xlo[4], xhi[4];          // c[0] = f[p-1] .. c[5] = f[p+4]
+    const bool inner = p >= plane + 1 && p + plane + 5 <= n;
+    if (inner) {
+        const f4 cc = *(const f4*)(f + p);
+        const f4u a = *(const f4u*)(f + p - d.n2), b = *(const f4u*)(f + p + d.n2);
+        const f4u u = *(const f4u*)(f + p - plane), v = *(const f4u*)(f + p + plane);
+        c[0] = f[p - 1]; c[5] = f[p + 4];
+        for (int e = 0; e < 4; ++e) { c[e + 1] = cc[e]; ylo[e] = a[e]; yhi[e] = b[e]; xlo[e] = u[e]; xhi[e] = v[e]; }
+    } else {
+        for (int e = -1; e < 5; ++e) c[e + 1] = (p + e >= 0 && p + e < n) ? f[p + e] : 0.0f;
+        for (int e = 0; e < 4; ++e) {
+            const long long q = p + e;
+            ylo[e] = q - d.n2 >= 0 ? f[q - d.n2] : 0.0f;
+            yhi[e] = q + d.n2 < n ? f[q + d.n2] : 0.0f;
+            xlo[e] = q - plane >= 0 ? f[q - plane] : 0.0f;
+            xhi[e] = q + plane < n ? f[q + plane] : 0.0f;
+        }
+    }
+    f4 o[3];
+    for (int e = 0; e < 4; ++e) {
+        if (MATH == 0) {
+            double g[3];
+            const double cc = c[e + 1];
+            g[0] = dif(xlo[e], cc, xhi[e], i, d.n0);
+            g[1] = dif(ylo[e], cc, yhi[e], j, d.n1);
+            g[2] = dif(c[e], cc, c[e + 2], k, d.n2);
+            const double m = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+            if (m != 0.0) { g[0] /= m; g[1] /= m; g[2] /= m; }
+            o[0][e] = (float)g[0]; o[1][e] = (float)g[1]; o[2][e] = (float)g[2];
+        } else {
+            float gx = dif32(xlo[e], c[e + 1], xhi[e], i, d.n0), gy = dif32(ylo[e], c[e + 1], yhi[e], j, d.n1),
+                  gz = dif32(c[e], c[e + 1], c[e + 2], k, d.n2);
+            unit32(gx, gy, gz);
+            o[0][e] = gx; o[1][e] = gy; o[2][e] = gz;
+        }
+        if (++k == d.n2) { k = 0; if (++j == d.n1) { j = 0; ++i; } }
+    }
+    if (MODE == 1) {
+        if (o[0][0] + o[1][1] + o[2][2] == 12345.678f) out[0] = 1;
+        return;
+    }
+    if (p + 4 <= n) {
+        for (int a = 0; a < 3; ++a) __builtin_nontemporal_store(o[a], (f4*)(out + (long long)a * stride + p));
+    } else {
+        for (int a = 0; a < 3; ++a)
+            for (int e = 0; p + e < n; ++e) out[(long long)a * stride + p + e] = o[a][e];
+    }
+}
+
+
+// ---- variant B: flat aligned quads in BAND order: an XCD sweeps the planes i of one band of TJ rows, so the plane
+// neighbours p +- n1*n2 are lines its own L2 fetched a moment ago (reuse distance ~2 band-planes) ----
+template <int TJ, int STORE, int MATH>   // STORE 0 nontemporal, 1 plain, 2 none
+__global__ __launch_bounds__(256) void band(const float* __restrict__ f, GridDims d, float* __restrict__ out, long long stride,
+                                            long long n, unsigned S, unsigned total) {
+    const unsigned per = (total + 7) / 8;
+    const unsigned L = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (L >= total) return;
+    const unsigned s = L % S, i = (L / S) % (unsigned)d.n0, b = L / (S * (unsigned)d.n0);
+    const long long plane = (long long)d.n1 * d.n2;
+    const long long lo = ((long long)i * d.n1 + (long long)b * TJ) * d.n2;
+    const int jhi = (int)(b + 1) * TJ < d.n1 ? (int)(b + 1) * TJ : d.n1;
+    const long long hi = ((long long)i * d.n1 + jhi) * d.n2;
+    const long long a0 = (lo + 3) & ~3ll, a1 = (hi + 3) & ~3ll;
+    const long long p = a0 + ((long long)s * 256 + threadIdx.x) * 4;
+    if (p >= a1 || p >= n) return;
+    // position of p: it lies in plane i except for the quad that starts in the next plane's first row (never: p < hi rounded up)
+    long long q = p - (long long)i * plane;
+    int ii = (int)i;
+    if (q >= plane) { q -= plane; ++ii; }
+    int j = (int)(q / d.n2), k = (int)(q - (long long)j * d.n2);
+    float c[6], ylo[4], yhi[4], xlo[4], xhi[4];
+    const bool inner = p >= plane + 1 && p + plane + 5 <= n;
+    if (inner) {
+        const f4 cc = *(const f4*)(f + p);
+        const f4u a = *(const f4u*)(f + p - d.n2), bb = *(const f4u*)(f + p + d.n2);
+        const f4u u = *(const f4u*)(f + p - plane), v = *(const f4u*)(f + p + plane);
+        c[0] = f[p - 1]; c[5] = f[p + 4];
+        for (int e = 0; e < 4; ++e) { c[e + 1] = cc[e]; ylo[e] = a[e]; yhi[e] = bb[e]; xlo[e] = u[e]; xhi[e] = v[e]; }
+    } else {
+        for (int e = -1; e < 5; ++e) c[e + 1] = (p + e >= 0 && p + e < n) ? f[p + e] : 0.0f;
+        for (int e = 0; e < 4; ++e) {
+            const long long t = p + e;
+            ylo[e] = t - d.n2 >= 0 ? f[t - d.n2] : 0.0f;
+            yhi[e] = t + d.n2 < n ? f[t + d.n2] : 0.0f;
+            xlo[e] = t - plane >= 0 ? f[t - plane] : 0.0f;
+            xhi[e] = t + plane < n ? f[t + plane] : 0.0f;
+        }
+    }
+    f4 o[3];
+    for (int e = 0; e < 4; ++e) {
+        if (MATH == 0) {
+            double g[3];
+            const double cc = c[e + 1];
+            g[0] = dif(xlo[e], cc, xhi[e], ii, d.n0);
+            g[1] = dif(ylo[e], cc, yhi[e], j, d.n1);
+            g[2] = dif(c[e], cc, c[e + 2], k, d.n2);
+            const double m = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+            if (m != 0.0) { g[0] /= m; g[1] /= m; g[2] /= m; }
+            o[0][e] = (float)g[0]; o[1][e] = (float)g[1]; o[2][e] = (float)g[2];
+        } else {
+            float gx = dif32(xlo[e], c[e + 1], xhi[e], ii, d.n0), gy = dif32(ylo[e], c[e + 1], yhi[e], j, d.n1),
+                  gz = dif32(c[e], c[e + 1], c[e + 2], k, d.n2);
+            unit32(gx, gy, gz);
+            o[0][e] = gx; o[1][e] = gy; o[2][e] = gz;
+        }
+        if (++k == d.n2) { k = 0; if (++j == d.n1) { j = 0; ++ii; } }
+    }
+    if (STORE == 2) {
+        if (o[0][0] + o[1][1] + o[2][2] == 12345.678f) out[0] = 1;
+        return;
+    }
+    if (p + 4 <= n) {
+        for (int a = 0; a < 3; ++a) {
+            if (STORE == 0) __builtin_nontemporal_store(o[a], (f4*)(out + (long long)a * stride + p));
+            else *(f4*)(out + (long long)a * stride + p) = o[a];
+        }
+    } else {
+        for (int a = 0; a < 3; ++a)
+            for (int e = 0; p + e < n; ++e) out[(long long)a * stride + p + e] = o[a][e];
+    }
+}
+
+
+// ---- floors: what a 4 B in / 12 B out stream costs without the stencil ----
+template <int MODE>   // 0 stores only, 1 centre read only, 2 centre read + 3 stores, 3 = 2 with plain stores
+__global__ __launch_bounds__(256) void stream(const float* __restrict__ f, float* __restrict__ out, long long stride, long long n) {
+    const long long p = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p + 4 > n) return;
+    f4 v = {1.0f, 2.0f, 3.0f, 4.0f};
+    if (MODE != 0) v = __builtin_nontemporal_load((const f4*)(f + p));
+    if (MODE == 1) {
+        if (v[0] + v[1] + v[2] + v[3] == 12345.678f) out[0] = 1;
+        return;
+    }
+    for (int a = 0; a < 3; ++a) {
+        if (MODE == 3) *(f4*)(out + (long long)a * stride + p) = v * (float)(a + 1);
+        else __builtin_nontemporal_store(v * (float)(a + 1), (f4*)(out + (long long)a * stride + p));
+    }
+}
+
+static void reference(const std::vector<float>& f, int n0, int n1, int n2, std::vector<float>& out, long long stride) {
+    auto at = [&](int i, int j, int k) { return (double)f[((size_t)i * n1 + j) * n2 + k]; };
+    auto d1 = [](double lo, double c, double hi, int pos, int n) { return pos == 0 ? hi - c : pos == n - 1 ? c - lo : 0.5 * (hi - lo); };
+    for (int i = 0; i < n0; ++i) for (int j = 0; j < n1; ++j) for (int k = 0; k < n2; ++k) {
+        const double c = at(i, j, k);
+        double g[3] = {d1(i ? at(i - 1, j, k) : 0, c, i + 1 < n0 ? at(i + 1, j, k) : 0, i, n0),
+                       d1(j ? at(i, j - 1, k) : 0, c, j + 1 < n1 ? at(i, j + 1, k) : 0, j, n1),
+                       d1(k ? at(i, j, k - 1) : 0, c, k + 1 < n2 ? at(i, j, k + 1) : 0, k, n2)};
+        const double m = std::sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+        for (int a = 0; a < 3; ++a) out[(size_t)a * stride + ((size_t)i * n1 + j) * n2 + k] = (float)(m != 0 ? g[a] / m : g[a]);
+    }
+}
+
+int main(int argc, char** argv) {
+    const int res = argc > 1 ? atoi(argv[1]) : 1025;
+    GridDims d{res, res, res};
+    const long long n = (long long)res * res * res, stride = (n + 63) / 64 * 64;
+    float *df, *dout;
+    CHK(hipMalloc(&df, n * 4));
+    CHK(hipMalloc(&dout, stride * 12));
+    std::vector<float> h((size_t)n);
+    unsigned s = 12345;
+    for (long long i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h[(size_t)i] = (s >> 20) % 7 == 0 ? 0.25f : (float)(s >> 8) / 16777216.0f; }
+    CHK(hipMemcpy(df, h.data(), n * 4, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    std::vector<float> ref, got;
+    const bool verify = res <= 200;
+    if (verify) { ref.resize((size_t)stride * 3); got.resize((size_t)stride * 3); reference(h, res, res, res, ref, stride); }
+    auto run = [&](const char* name, auto launch) {
+        float best = 1e9;
+        for (int rep = 0; rep < 4; ++rep) {
+            CHK(hipEventRecord(e0));
+            launch();
+            CHK(hipEventRecord(e1));
+            CHK(hipEventSynchronize(e1));
+            CHK(hipGetLastError());
+            float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) best = ms;
+        }
+        const char* ok = "";
+        if (verify && !strstr(name, "abl")) {
+            CHK(hipMemcpy(got.data(), dout, (size_t)stride * 12, hipMemcpyDeviceToHost));
+            size_t bad = 0;
+            double worst = 0;
+            for (int a = 0; a < 3; ++a) for (long long i = 0; i < n; ++i) {
+                bad += got[(size_t)a * stride + i] != ref[(size_t)a * stride + i];
+                worst = std::fmax(worst, std::fabs((double)got[(size_t)a * stride + i] - ref[(size_t)a * stride + i]));
+            }
+            ok = bad ? "  differs" : "  exact";
+            if (bad) printf("   %zu values differ, max abs err %.3g\n", bad, worst);
+            CHK(hipMemset(dout, 0, (size_t)stride * 12));
+        }
+        printf("%-28s %8.3f ms  %7.1f GB/s (16 B/pt)%s\n", name, best, 16.0 * n / best / 1e6, ok);
+    };
+#define MARCH(REMAP, ROWS, XSEG, MODE, label) { \
+        const unsigned gx = (res + 63) / 64, gy = (res + 4 * ROWS - 1) / (4 * ROWS), gz = (res + XSEG - 1) / XSEG, total = gx * gy * gz; \
+        const unsigned launch_n = REMAP ? ((total + 7) / 8) * 8 : total; \
+        run(label, [&] { hipLaunchKernelGGL((march<REMAP, ROWS, XSEG, MODE>), dim3(launch_n), dim3(256), 0, 0, df, d, dout, stride, gx, gy, total); }); }
+    MARCH(false, 4, 32, 0, "march r4 x32")
+    MARCH(true, 4, 32, 0, "march r4 x32 xcd")
+    MARCH(true, 4, 128, 0, "march r4 x128 xcd")
+    MARCH(true, 2, 32, 0, "march r2 x32 xcd")
+    MARCH(true, 8, 32, 0, "march r8 x32 xcd")
+    MARCH(true, 4, 32, 1, "march r4 x32 xcd abl-nostore")
+    MARCH(true, 4, 32, 2, "march r4 x32 xcd abl-noload")
+    {
+        const unsigned total = (unsigned)((n + 1023) / 1024), launch_n = ((total + 7) / 8) * 8;
+        run("flat", [&] { hipLaunchKernelGGL((flat<false, 0, 0>), dim3(total), dim3(256), 0, 0, df, d, dout, stride, n, total); });
+        run("flat xcd", [&] { hipLaunchKernelGGL((flat<true, 0, 0>), dim3(launch_n), dim3(256), 0, 0, df, d, dout, stride, n, total); });
+        run("flat f32", [&] { hipLaunchKernelGGL((flat<false, 0, 1>), dim3(total), dim3(256), 0, 0, df, d, dout, stride, n, total); });
+        run("flat xcd f32", [&] { hipLaunchKernelGGL((flat<true, 0, 1>), dim3(launch_n), dim3(256), 0, 0, df, d, dout, stride, n, total); });
+        run("flat xcd f32 abl-nostore", [&] { hipLaunchKernelGGL((flat<true, 1, 1>), dim3(launch_n), dim3(256), 0, 0, df, d, dout, stride, n, total); });
+        run("flat xcd abl-nostore", [&] { hipLaunchKernelGGL((flat<true, 1, 0>), dim3(launch_n), dim3(256), 0, 0, df, d, dout, stride, n, total); });
+    }
+
+#define BAND(TJ, STORE, MATH, label) { \
+        const unsigned nb = (res + TJ - 1) / TJ, S = (unsigned)(((long long)TJ * res + 4 + 1023) / 1024), total = S * res * nb; \
+        const unsigned launch_n = ((total + 7) / 8) * 8; \
+        run(label, [&] { hipLaunchKernelGGL((band<TJ, STORE, MATH>), dim3(launch_n), dim3(256), 0, 0, df, d, dout, stride, n, S, total); }); }
+    BAND(16, 0, 0, "band tj16")
+    BAND(8, 0, 1, "band tj8 f32")
+    BAND(16, 0, 1, "band tj16 f32")
+    BAND(32, 0, 1, "band tj32 f32")
+    BAND(64, 0, 1, "band tj64 f32")
+    BAND(16, 1, 1, "band tj16 f32 plain stores")
+    BAND(16, 2, 1, "band tj16 f32 abl-nostore")
+    BAND(32, 2, 1, "band tj32 f32 abl-nostore")
+    {
+        const unsigned nblk = (unsigned)((n + 1023) / 1024);
+        run("abl stream: 3 stores", [&] { hipLaunchKernelGGL((stream<0>), dim3(nblk), dim3(256), 0, 0, df, dout, stride, n); });
+        run("abl stream: read", [&] { hipLaunchKernelGGL((stream<1>), dim3(nblk), dim3(256), 0, 0, df, dout, stride, n); });
+        run("abl stream: read + 3 stores", [&] { hipLaunchKernelGGL((stream<2>), dim3(nblk), dim3(256), 0, 0, df, dout, stride, n); });
+        run("abl stream: read + 3 plain", [&] { hipLaunchKernelGGL((stream<3>), dim3(nblk), dim3(256), 0, 0, df, dout, stride, n); });
+    }
+    return 0;
+}
