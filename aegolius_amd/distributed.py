@@ -119,3 +119,97 @@ class _GpuSlabEvaluator:
         stream = torch.cuda.current_stream().cuda_stream
         self._prog.eval_grid(axes, start, count, out.data_ptr(), stream=stream)
         return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# consumers of the field, sharded the same way: no data-path collective either
+# ---------------------------------------------------------------------------------------------------
+def _world(group):
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def _grid(size, resolution):
+    from .cores.helper_functions import grid_axes
+    axes64, res = grid_axes(size, resolution)
+    shape = tuple(int(a.size) for a in axes64 if a.size > 1)
+    return [a.astype(np.float32) for a in axes64], res, shape
+
+
+def interior_indices_sharded(geometry, size, resolution, threshold=0.0, group=None, evaluate_slab=None, select_slab=None,
+                             world_rank=None):
+    """GenericGeometry.point_cloud's mask, sharded: this rank's ascending GLOBAL flat indices with field <= threshold
+    (an int64 torch tensor; the ranks' results, concatenated in rank order, are numpy.flatnonzero of the whole field).
+    `world_rank=(W, r)` overrides the process group (slabs emulated on one device)."""
+    axes, res, shape = _grid(size, resolution)
+    world, rank = world_rank or _world(group)
+    n_total = int(np.prod(shape))
+    start, count = slab_bounds(n_total, world, rank, shape[-1])
+    evaluate_slab = evaluate_slab or _GpuSlabEvaluator(geometry)
+    if getattr(evaluate_slab, "staged", False):
+        raise NotImplementedError("sharded consumers take pointwise trees (no grid-neighbourhood operators)")
+    local = evaluate_slab(axes, start, count)
+    return (select_slab or _gpu_select)(local, threshold) + start, res
+
+
+def gradient_direction_sharded(geometry, size, resolution, group=None, evaluate_slab=None, gradient_slab=None,
+                               world_rank=None):
+    """vector_functions.from_sdf, sharded: this rank's (D, count) slab of unit gradient vectors, count = its whole
+    planes of the first axis. Each rank evaluates its slab plus ONE halo plane per inner side (recomputed, not
+    exchanged: 2 planes against N/W) so that the central differences across slab boundaries are the single-GPU ones;
+    the one-sided differences stay on the global faces. Left distributed, like the field itself."""
+    axes, res, shape = _grid(size, resolution)
+    world, rank = world_rank or _world(group)
+    n_total = int(np.prod(shape))
+    plane = n_total // shape[0]
+    start, count = slab_bounds(n_total, world, rank, plane)
+    evaluate_slab = evaluate_slab or _GpuSlabEvaluator(geometry)
+    if getattr(evaluate_slab, "staged", False):
+        raise NotImplementedError("sharded consumers take pointwise trees (no grid-neighbourhood operators)")
+    gradient_slab = gradient_slab or _gpu_gradient
+    p0, p1 = start // plane, (start + count) // plane
+    if p1 == p0:
+        return gradient_slab(evaluate_slab(axes, 0, 2 * plane), (2,) + shape[1:])[:, :0], res
+    h0, h1 = (1 if p0 > 0 else 0), (1 if p1 < shape[0] else 0)
+    if p1 - p0 + h0 + h1 < 2:                                  # a one-plane grid cannot be differentiated (numpy agrees)
+        raise ValueError("Shape of array too small to calculate a numerical gradient, at least (edge_order + 1) elements "
+                         "are required.")
+    ext = evaluate_slab(axes, (p0 - h0) * plane, (p1 - p0 + h0 + h1) * plane)
+    vec = gradient_slab(ext, (p1 - p0 + h0 + h1,) + shape[1:])
+    return vec[:, h0 * plane:h0 * plane + count], res
+
+
+def _gpu_select(local, threshold):
+    """sdfk_field_select on a torch CUDA tensor -> int64 CUDA tensor of local indices."""
+    import ctypes
+    import torch
+    from . import _engine
+    lib, vp = _engine.lib(), _engine._vp
+    torch.cuda.synchronize()
+    n = local.numel()
+    m = ctypes.c_int64(0)
+    scratch = torch.empty(lib.sdfk_field_select_scratch(n), dtype=torch.uint8, device=local.device)
+    _engine.check(lib.sdfk_field_select(vp(local.data_ptr()), n, float(threshold), None, 0, ctypes.byref(m),
+                                        vp(scratch.data_ptr()), None), "sdfk_field_select")
+    index = torch.empty(m.value, dtype=torch.int64, device=local.device)
+    if m.value:
+        _engine.check(lib.sdfk_field_select(vp(local.data_ptr()), n, float(threshold), vp(index.data_ptr()), m.value,
+                                            ctypes.byref(m), vp(scratch.data_ptr()), None), "sdfk_field_select")
+    return index
+
+
+def _gpu_gradient(ext, shape):
+    """sdfk_field_gradient on a torch CUDA tensor holding a slab of `shape` -> (D, points) view of unit vectors."""
+    import torch
+    from . import _engine
+    lib, vp = _engine.lib(), _engine._vp
+    torch.cuda.synchronize()
+    n = ext.numel()
+    stride = (n + 63) // 64 * 64
+    dims = (1,) * (3 - len(shape)) + tuple(shape)
+    vec = torch.empty((len(shape), stride), dtype=torch.float32, device=ext.device)
+    _engine.check(lib.sdfk_field_gradient(vp(ext.data_ptr()), dims[0], dims[1], dims[2], len(shape), 1,
+                                          vp(vec.data_ptr()), stride, None), "sdfk_field_gradient")
+    return vec[:, :n]

@@ -219,3 +219,28 @@ def test_consumers_at_scale(engine):
     assert np.abs(vec[:, pick][:, far] - (p / r)[:, far]).max() < 2e-3
     cloud = s.point_cloud(co)
     assert cloud.shape == (3, idx.size) and np.array_equal(cloud[:2], np.asarray(co)[:2, idx])
+
+
+@pytest.mark.parametrize("size,resolution", [((2, 2, 2), (40, 24, 66)), ((3, 3), (200, 130))])
+def test_sharded_consumers_equal_the_single_device_result(size, resolution, engine):
+    """§8(e) for the consumers: slabs (with their recomputed halo plane) emulated on one device, every rank's part
+    concatenated — bit-identical to select / from_sdf on the whole field."""
+    import torch
+    from aegolius_amd.distributed import gradient_direction_sharded, interior_indices_sharded
+    a = ns.Sphere(0.55)
+    b = ns.Box(0.5, 0.9, 0.4)
+    b.rotate(0.5, (0, 1, 1))
+    b.move((0.2, -0.1, 0.1))
+    tree = ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(a, b, parameters=0.12)
+    co, res = ns.generate_grid(size, resolution)
+    dev = tree.create_resident(co)
+    want_idx = dev.select(0.0)
+    want_vec = ns.from_sdf(dev, resolution)
+    for world in (1, 2, 3, 8):
+        vec = [gradient_direction_sharded(tree, size, resolution, world_rank=(world, r))[0] for r in range(world)]
+        assert all(v.is_cuda and v.dtype == torch.float32 for v in vec)
+        np.testing.assert_array_equal(torch.cat(vec, dim=1).cpu().numpy(), want_vec)
+        idx = [interior_indices_sharded(tree, size, resolution, world_rank=(world, r))[0] for r in range(world)]
+        assert all(i.is_cuda and i.dtype == torch.int64 for i in idx)
+        np.testing.assert_array_equal(torch.cat(idx).cpu().numpy(), want_idx)
+    assert want_idx.size > 100
