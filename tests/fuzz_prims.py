@@ -110,8 +110,17 @@ def main(which="reference", first=0, count=400):
                     tol, allowed = 1e-6, (max(1, int(0.005 * want.size)) if kind in JUMPY else 0)
             err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
             err[np.isnan(got) & np.isnan(want)] = 0
-            bad, worst = int((~(err <= tol)).sum()), float(np.nanmax(err))
+            off = ~(err <= tol)
+            note = ""
+            if which != "reference" and off.any():
+                # points where the reference itself moves as much under a one-ulp change of its fp32 input
+                sens = scenes.input_sensitivity(lambda c: sdf_oracle.evaluate(build(ns, seed)[0], c), co)
+                conditioned = off & (np.abs(got - want) <= 8.0 * sens)
+                note = " (%d more within 8x the input sensitivity)" % conditioned.sum() if conditioned.any() else ""
+                off &= ~conditioned
+            bad, worst = int(off.sum()), float(np.nanmax(err))
             ok = bad <= allowed
+            kind += note
         except Exception as exc:  # noqa: BLE001
             ok, bad, worst = False, -1, float("nan")
             print("seed %d (%s) raised %r" % (seed, kind, exc))

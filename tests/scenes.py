@@ -905,3 +905,18 @@ def _(ns, res):
     r.rotate(0.4, (0, 0, 1))
     r.onion(0.1)
     return r
+
+
+def input_sensitivity(evaluate, co, trials=5, seed=12345):
+    """How far the REFERENCE arithmetic (float64 oracle, `evaluate(co) -> field`) moves when every coordinate changes
+    by one fp32 ulp: per-point max |f(co') - f(co)| over a few seeded perturbations. A GPU deviation within a small
+    multiple of this is the conditioning of the scene (steep value maps, fractional powers near an axis), not an
+    error of the kernel; the fuzzers report such points separately."""
+    rng = np.random.default_rng(seed)
+    base = np.asarray(evaluate(co.copy()), dtype=np.float64)
+    worst = np.zeros_like(base)
+    for _ in range(trials):
+        moved = co * (1.0 + 6e-8 * rng.choice([-1.0, 1.0], size=co.shape))
+        with np.errstate(all="ignore"):
+            worst = np.fmax(worst, np.abs(np.asarray(evaluate(moved), dtype=np.float64) - base))
+    return worst
