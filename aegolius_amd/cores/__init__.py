@@ -3,11 +3,32 @@ scalar-field path: `from aegolius_amd.cores import Sphere, CombineGeometry, gene
 from .combine import CombineGeometry
 from .transformations import EuclideanTransform
 from .modifications import ModifyObject
-from .geom import GenericGeometry
+from .geom import GenericGeometry, VectorField
+from .modifications import ModifyVectorObject
 
 from .helper_functions import resolution_conversion, generate_grid, smarter_reshape
 from .helper_functions import vector_smarter_reshape, nd_vector_smarter_reshape
 from .vector_functions import from_sdf
+from .vector_functions import cartesian_define, cylindrical_define, spherical_define
+from .vector_functions import radial_vector_field_cylindrical, radial_vector_field_spherical
+from .vector_functions import hyperbolic_vector_field_cylindrical, awn_vector_field_cylindrical
+from .vector_functions import aar_vector_field_cylindrical, vortex_vector_field_cylindrical, aav_vector_field_cylindrical
+from .vector_functions import x_vector_field, y_vector_field, z_vector_field
+
+from .vector_modification_functions import batch_normalize
+from .vector_modification_functions import add_vectors, subtract_vectors, rescale_vectors
+from .vector_modification_functions import rotate_vectors_phi, rotate_vectors_theta
+from .vector_modification_functions import rotate_vectors_x_axis, rotate_vectors_y_axis, rotate_vectors_z_axis
+from .vector_modification_functions import rotate_vectors_axis
+from .vector_modification_functions import revolve_field_x, revolve_field_y, revolve_field_z
+
+from .geom_vector import CartesianVectorField, CylindricalVectorField, SphericalVectorField
+from .geom_vector import RadialSphericalVectorField
+from .geom_vector import RadialCylindricalVectorField, HyperbolicCylindricalVectorField
+from .geom_vector import AngledRadialCylindricalVectorField, WindingCylindricalVectorField
+from .geom_vector import VortexCylindricalVectorField, AngledVortexCylindricalVectorField
+from .geom_vector import XVectorField, YVectorField, ZVectorField
+from .geom_vector import VectorFieldFromSDF
 
 from .sdf_2D import *  # noqa: F401,F403
 from .sdf_3D import *  # noqa: F401,F403

@@ -8,7 +8,7 @@ every child object) to ONE fused GPU program and runs it through libsdfk.so.
 import numpy as np
 
 from .._eval import evaluate_geometry
-from .modifications import ModifyObject
+from .modifications import ModifyObject, ModifyVectorObject
 from .transformations import EuclideanTransform
 
 
@@ -56,3 +56,54 @@ class GenericGeometry(EuclideanTransform, ModifyObject):
         pts = np.zeros((3, inside.size))
         pts[:2, :] = np.asarray(co)[:2, inside]
         return pts
+
+
+class VectorField(ModifyVectorObject):
+    """Constructs a VectorField object from a vector field function (reference cores/geom.py:213-362).
+
+    Args:
+        vf: The vector field function - vf(p, *vf_parameters): a definition of `aegolius_amd.cores.vector_functions`
+            (lowered to the GPU kernel), a field returned by a modification method, or any callable returning a
+            (3, N) array (run on the host; the modifications still run on the GPU).
+        vf_parameters: The parameters of the vector field function.
+    """
+
+    def __init__(self, vf, *vf_parameters):
+        ModifyVectorObject.__init__(self, vf)
+        self._vf_parameters = vf_parameters
+        self._vf = self.vf
+
+    def _evaluate(self, p, out):
+        from .._vector import evaluate
+        self._vf = self.vf
+        return evaluate(self._vf, p, self._vf_parameters, out)
+
+    def create(self, p):
+        """Applies the modifications and returns the map of the vector field, shape (3, N)."""
+        return self._evaluate(p, "vector")
+
+    def propagate(self, p, *parameters_):
+        """Same as create(); extra arguments are ignored."""
+        return self._evaluate(p, "vector")
+
+    def x(self, p, *parameters_):
+        """x component of the modified field, shape (N,)."""
+        return self._evaluate(p, "x")
+
+    def y(self, p, *parameters_):
+        return self._evaluate(p, "y")
+
+    def z(self, p, *parameters_):
+        return self._evaluate(p, "z")
+
+    def phi(self, p, *parameters_):
+        """Azimuthal angle arctan2(v_y, v_x) of every vector."""
+        return self._evaluate(p, "phi")
+
+    def theta(self, p, *parameters_):
+        """Polar angle arccos(v_z) of every vector."""
+        return self._evaluate(p, "theta")
+
+    def length(self, p, *parameters_):
+        """Length of every vector."""
+        return self._evaluate(p, "length")

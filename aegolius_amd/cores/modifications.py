@@ -210,4 +210,86 @@ class ModifyObject:
                           label=post_process_name)
 
 
-__all__ = ["ModifyObject", "SDFExpr"]
+class ModifyVectorObject:
+    """All the modifications which can be applied to a vector field (reference cores/modifications.py:1666-1975): same
+    methods, same bookkeeping (`modifications`, `modified_object`, `original_object`, the public `vf` /
+    `original_vf`). Every method wraps the current field and returns the new one — an `aegolius_amd._vector.VecClosure`,
+    callable as `vf(p, *params)` like the reference's closures, evaluated as one GPU kernel.
+
+    Args:
+        vf: Vector field function vf(p, *parameters).
+    """
+
+    def __init__(self, vf):
+        from .._vector import as_closure
+        self._mod = []
+        self.original_vf = vf
+        self.vf = as_closure(vf)
+
+    @property
+    def modifications(self):
+        """All the modifications which were applied to the vector field in chronological order."""
+        return self._mod
+
+    @property
+    def modified_object(self):
+        return self.vf
+
+    @property
+    def original_object(self):
+        return self.original_vf
+
+    def _wrap(self, name, *args):
+        from .._vector import as_closure
+        self._mod.append(name)
+        self.vf = as_closure(self.vf).then(name, *args)
+        return self.vf
+
+    def add(self, second_field):
+        """Adds a number, a vector, or a vector field of the same shape (:1712-1730)."""
+        return self._wrap("add", second_field)
+
+    def subtract(self, second_field):
+        return self._wrap("subtract", second_field)
+
+    def rescale(self, second_field):
+        """Multiplies by a number, a per-point number or a field of the same shape (:1752-1770)."""
+        return self._wrap("rescale", second_field)
+
+    def rotate_phi(self, phi):
+        """Turns the vectors about z by a spatially dependent or independent angle (:1772-1790)."""
+        return self._wrap("rotate_phi", phi)
+
+    def rotate_theta(self, theta):
+        """Turns the vectors in their own meridional plane (:1792-1810)."""
+        return self._wrap("rotate_theta", theta)
+
+    def rotate_x(self, alpha):
+        return self._wrap("rotate_x", alpha)
+
+    def rotate_y(self, alpha):
+        return self._wrap("rotate_y", alpha)
+
+    def rotate_z(self, alpha):
+        return self._wrap("rotate_z", alpha)
+
+    def rotate_axis(self, axis, alpha):
+        """Turns the vectors about one axis, or one axis per point, by alpha (:1872-1893); axes are used as given."""
+        return self._wrap("rotate_axis", axis, alpha)
+
+    def revolution_x(self, co):
+        """Revolves a 2D vector field about the x-axis of the coordinate system `co` (3, N) (:1895-1914)."""
+        return self._wrap("revolution_x", co)
+
+    def revolution_y(self, co):
+        return self._wrap("revolution_y", co)
+
+    def revolution_z(self, co):
+        return self._wrap("revolution_z", co)
+
+    def normalize(self):
+        """Divides every vector by its length; zero vectors stay zero (:1956-1975)."""
+        return self._wrap("normalize")
+
+
+__all__ = ["ModifyObject", "ModifyVectorObject", "SDFExpr"]

@@ -33,3 +33,33 @@ def from_sdf(sdf_, co_resolution):
     if config.output_dtype is not np.float32:
         vec = vec.astype(config.output_dtype)
     return vec
+
+
+# ---- field definitions (reference cores/vector_functions.py:15-127) -------------------------------------------------
+# Each is a tag the lowering recognises (aegolius_amd._vector.LEAVES); called directly it evaluates on the GPU.
+def _definition(name, doc):
+    def fn(p, *params):
+        from .._vector import VecClosure, evaluate
+        return evaluate(VecClosure(fn), p, params)
+    fn.__name__ = fn.__qualname__ = name
+    fn.__doc__ = doc
+    fn._vec_leaf = name
+    return fn
+
+
+cartesian_define = _definition("cartesian_define", "(ux, uy, uz) = p (:15-20).")
+spherical_define = _definition("spherical_define", "(r, phi, theta) = p -> r (cos phi sin theta, sin phi sin theta, cos theta) (:23-32).")
+cylindrical_define = _definition("cylindrical_define", "(r, phi, z) = p -> (r cos phi, r sin phi, z) (:35-43).")
+radial_vector_field_spherical = _definition("radial_vector_field_spherical", "r / |r|, zero at the origin (:46-48).")
+radial_vector_field_cylindrical = _definition("radial_vector_field_cylindrical", "(x, y, 0) / |(x, y)| (:51-55).")
+hyperbolic_vector_field_cylindrical = _definition(
+    "hyperbolic_vector_field_cylindrical", "Raises TypeError for every input, as the reference does (:58-61).")
+awn_vector_field_cylindrical = _definition(
+    "awn_vector_field_cylindrical", "Raises TypeError for every input, as the reference does (:64-68).")
+vortex_vector_field_cylindrical = _definition("vortex_vector_field_cylindrical", "The radial cylindrical field turned by 90 degrees (:71-79).")
+aar_vector_field_cylindrical = _definition("aar_vector_field_cylindrical", "The radial cylindrical field turned by alpha (:82-94).")
+aav_vector_field_cylindrical = _definition("aav_vector_field_cylindrical", "The vortex field turned by alpha (:97-109).")
+x_vector_field = _definition("x_vector_field", "(1, 0, 0) everywhere (:112-115).")
+y_vector_field = _definition("y_vector_field", "(0, 1, 0) everywhere (:118-121).")
+z_vector_field = _definition("z_vector_field", "(0, 0, 1) everywhere (:124-127).")
+from_sdf._vec_leaf = "from_sdf"

@@ -172,6 +172,36 @@ int sdfk_field_select(const float* d_field, int64_t n, float threshold, int64_t*
 int sdfk_field_gradient(const float* d_field, int64_t n0, int64_t n1, int64_t n2, int ncomp, int normalize,
                         float* d_vec, int64_t row_stride, void* stream);
 
+/* ---- vector-field programs ----------------------------------------------------------------------
+ * The reference's vector-field path (cores/geom.py:213-362 VectorField; cores/vector_functions.py:15-127 field
+ * definitions; cores/modifications.py:1666-1975 ModifyVectorObject; cores/vector_modification_functions.py:14-160)
+ * as ONE pointwise kernel: instruction 0 turns the input triple p into a vector, the others are the modifications
+ * in the order they were applied. op = opcode | kindA << 8 | kindB << 12; kinds: 0 none, 1 number (imm[0] for A,
+ * imm[3] for B), 2 3-vector (imm[0..2]), 3 one row of `streams` (src = row index: a per-point number), 4 three rows
+ * (src = first row: a per-point vector), 5 the input triple p itself (revolutions about the axes of the same
+ * coordinates). Opcodes (A / B operands):
+ *   0 p itself | 1 (r, phi, theta) = p | 2 (r, phi, z) = p | 3 p/|p| | 4 (x, y, 0)/|(x, y)| | 5 vortex |
+ *   6 radial-cylindrical turned by A | 7 vortex turned by A | 8 constant A | 9 rows A                (initialisers)
+ *   10 v + A | 11 v - A | 12 v * A | 13 turn about z by A | 14 about x | 15 about y | 16 polar turn by A |
+ *   17 turn about axis A by angle B | 18 / 19 / 20 revolve about x / y / z with coordinates A | 21 normalise.
+ * out_kind: 0 the vector (3 rows) | 1 x | 2 y | 3 z | 4 atan2(y, x) | 5 acos(z) | 6 length (1 row).
+ * fp32 arithmetic; zero vectors stay zero under normalisation. Asynchronous on `stream` (device flavour). */
+typedef struct {
+    int32_t op;
+    int32_t src[2];
+    float imm[4];
+} sdfk_vec_instr;
+/* d_p, d_out: 16-byte aligned, row strides multiples of 4 floats; d_streams: n_streams rows of stream_stride floats. */
+int sdfk_vec_eval_device(const sdfk_vec_instr* prog, int n_instr, const float* d_p, int64_t n, int64_t p_stride,
+                         const float* d_streams, int n_streams, int64_t stream_stride, int out_kind, float* d_out,
+                         int64_t out_stride, void* stream);
+/* HOST arrays staged through the device in chunks: p (dtype 0 = fp32, 1 = fp64; (3, n) contiguous) or, when ax0..ax2
+ * are given, the generate_grid cloud of those tables (expanded on the device); streams (n_streams, n) fp32; out (3, n)
+ * or (n,) fp32. */
+int sdfk_vec_eval_host(const sdfk_vec_instr* prog, int n_instr, const void* p, int p_dtype, int64_t n, const float* ax0,
+                       int64_t n0, const float* ax1, int64_t n1, const float* ax2, int64_t n2, const float* streams,
+                       int n_streams, int out_kind, float* out, int device);
+
 /* ---- grid builder -----------------------------------------------------------------------------
  * numpy.linspace(lo, hi, n) in float64 (step = (hi-lo)/(n-1); y[i] = i*step + lo; y[n-1] = hi),
  * rounded to fp32 — the per-axis table of generate_grid (cores/helper_functions.py:56-88). */

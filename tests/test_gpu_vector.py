@@ -1,0 +1,185 @@
+"""GPU parity of the vector-field path: every scene of tests/vector_scenes.py through the product API
+(`aegolius_amd.cores`, libsdfk.so's sdfk_vec_eval_host) against the golden vectors of the real reference.
+
+Tolerance: |gpu - ref| <= 1e-6 * max(1, |ref|) per component; zero vectors of the reference are exactly zero here.
+Where a scene is ill-conditioned at a point (arccos at the poles, a difference of nearly equal vectors that is then
+normalised) the bound is 8x what the float64 oracle itself moves under a one-ulp (fp32) change of its inputs."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+import vector_scenes as vs
+import aegolius_amd.cores as ns
+from aegolius_amd import _vector
+from oracle import vector_oracle as vo
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def engine(built):
+    built.require_gpu()
+    return built
+
+
+@pytest.fixture(scope="module")
+def vgolden():
+    data = np.load(os.path.join(HERE, "golden", "vector_golden.npz"))
+    with open(os.path.join(HERE, "golden", "vector_golden_meta.json")) as f:
+        return data, json.load(f)
+
+
+@pytest.fixture(scope="module")
+def aux():
+    return vs.inputs()
+
+
+def close(got, ref, slack=None):
+    assert got.dtype == np.float32 and got.shape == ref.shape
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    bound = TOL * np.maximum(1.0, np.abs(ref))
+    if slack is not None:
+        bound = np.maximum(bound, slack)
+    err = np.abs(got.astype(np.float64) - ref)
+    bad = ~(err <= bound) & ~np.isnan(ref)
+    assert not bad.any(), "%d values off, worst %.3g" % (bad.sum(), np.nanmax(err))
+    assert not got[ref == 0].any() or np.abs(got[ref == 0]).max() <= TOL
+
+
+def input_sensitivity(name, aux, trials=4):
+    """How far the float64 oracle moves when every input (positions, angles, second fields) changes by one fp32 ulp:
+    the conditioning of the scene (differences of nearly equal vectors before a normalisation, arccos at the poles)."""
+    rng = np.random.default_rng(99)
+
+    def run(arrays):
+        field, key, read = vs.SCENES[name](ns, arrays)
+        with np.errstate(all="ignore"):
+            return vo.evaluate(field.vf, arrays[key], field._vf_parameters, "vector" if read == "create" else read)
+    base = run(aux)
+    worst = np.zeros_like(base)
+    for _ in range(trials):
+        moved = {k: v * (1.0 + 6e-8 * rng.choice([-1.0, 1.0], size=v.shape)) for k, v in aux.items()}
+        worst = np.fmax(worst, np.abs(run(moved) - base))
+    return worst
+
+
+@pytest.mark.parametrize("name", sorted(vs.SCENES))
+def test_scene_matches_reference_golden(name, engine, vgolden, aux):
+    ref = vgolden[0]["scene/" + name]
+    mine = {k: v.copy() for k, v in aux.items()}
+    got = vs.run(ns, name, mine)
+    for k in aux:                                              # inputs are never modified
+        np.testing.assert_array_equal(mine[k], aux[k])
+    slack = 8.0 * input_sensitivity(name, aux)                 # never more than the reference's own conditioning
+    if name.endswith("theta"):                                 # arccos(v_z): an fp32 v_z (a few 1e-7) costs 1 / sin(theta)
+        field, key, _ = vs.SCENES[name](ns, aux)
+        vz = vo.evaluate(field.vf, aux[key], field._vf_parameters, "z")
+        slack = np.maximum(slack, 3e-7 / np.sqrt(np.maximum(1.0 - vz * vz, 1e-12)))
+    assert np.nanmedian(slack) <= 4 * TOL, "a scene that is ill-conditioned everywhere pins nothing"
+    close(got, ref, slack)
+    if ref.ndim == 2 and "normalize" in name:
+        lengths = np.linalg.norm(got.astype(np.float64), axis=0)
+        assert np.all((np.abs(lengths - 1) < 1e-6) | (lengths == 0))
+
+
+@pytest.mark.parametrize("name", sorted(vs.FUNCTIONS))
+def test_array_level_function_matches_reference_golden(name, engine, vgolden, aux):
+    got = vs.FUNCTIONS[name](ns, {k: v.copy() for k, v in aux.items()})
+    close(np.asarray(got, dtype=np.float32), vgolden[0]["function/" + name])
+
+
+def test_batch_normalize_is_in_place_like_the_reference(engine, aux):
+    vec = aux["second"].copy()
+    out = ns.batch_normalize(vec)
+    assert out is vec and np.abs(np.linalg.norm(vec, axis=0) - 1).max() < 1e-6
+
+
+def test_grid_input_is_expanded_on_the_device(engine):
+    """A generate_grid cloud handed to a vector field is never uploaded: same result as the plain array."""
+    co, _ = ns.generate_grid((2, 2, 2), (20, 16, 12))
+    alpha = np.linspace(-3, 3, co.shape[1])
+    for build in (lambda: ns.RadialSphericalVectorField(), lambda: ns.AngledVortexCylindricalVectorField(alpha)):
+        a, b = build(), build()
+        for f, p in ((a, co), (b, np.array(co))):
+            f.rotate_y(alpha)
+            f.revolution_x(p)
+            f.normalize()
+        np.testing.assert_array_equal(a.create(co), b.create(np.array(co)))
+        ref = vo.evaluate(a.vf, np.asarray(co, dtype=np.float32).astype(np.float64), a._vf_parameters)
+        # the grid tables are fp32: compare against the oracle on the fp32-rounded coordinates
+        close(a.create(co), ref, slack=4e-6)
+
+
+def test_vector_field_from_sdf_feeds_a_chain(engine):
+    co, res = ns.generate_grid((2, 2, 2), (24, 20, 16))
+    sdf = ns.Sphere(0.6).create(co)
+    f = ns.VectorFieldFromSDF(res)
+    np.testing.assert_array_equal(f.create(sdf), ns.from_sdf(sdf, res))
+    f.rotate_z(0.5)
+    f.add((0.0, 0.0, 0.25))
+    f.normalize()
+    ref = vo.evaluate(f.vf, sdf.astype(np.float64), f._vf_parameters)
+    close(f.create(sdf), ref, slack=2e-6)
+
+
+def test_ragged_sizes_and_the_device_entry_point(engine):
+    lib, vp = engine.lib(), ctypes.c_void_p
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 3, 5, 1023, 1024, 1025, 4099):
+        p = rng.normal(size=(3, n)).astype(np.float32)
+        ang = rng.uniform(-3, 3, n).astype(np.float32)
+        f = ns.RadialCylindricalVectorField()
+        f.rotate_x(ang)
+        f.normalize()
+        got = f.create(p)
+        close(got, vo.evaluate(f.vf, p.astype(np.float64), ()))
+        # the same program through sdfk_vec_eval_device on caller-owned device memory
+        instr, rows = _vector.lower_only(f.vf, p, ())
+        prog = (_vector.VecInstr * len(instr))()
+        for k, (op, ka, kb, src, imm) in enumerate(instr):
+            prog[k].op = op | ka << 8 | kb << 12
+            prog[k].src[0], prog[k].src[1] = src
+            for j in range(4):
+                prog[k].imm[j] = imm[j]
+        stride = (n + 63) // 64 * 64
+        d = lib.sdfk_malloc(stride * 4 * 7)
+        for r in range(3):
+            engine.check(lib.sdfk_memcpy_h2d(vp(d + 4 * r * stride), engine._ptr(p[r]), n * 4), "h2d")
+        if rows:                                               # n = 1: a one-value angle is an immediate
+            engine.check(lib.sdfk_memcpy_h2d(vp(d + 4 * 3 * stride), engine._ptr(rows[0]), n * 4), "h2d")
+        engine.check(lib.sdfk_vec_eval_device(prog, len(instr), vp(d), n, stride, vp(d + 4 * 3 * stride), len(rows), stride, 0,
+                                              vp(d + 4 * 4 * stride), stride, None), "sdfk_vec_eval_device")
+        engine.check(lib.sdfk_sync(None), "sync")
+        dev = np.empty((3, n), np.float32)
+        for r in range(3):
+            engine.check(lib.sdfk_memcpy_d2h(engine._ptr(dev[r]), vp(d + 4 * (4 + r) * stride), n * 4), "d2h")
+        lib.sdfk_free(vp(d))
+        np.testing.assert_array_equal(dev, got)
+    assert ns.CartesianVectorField().create(np.zeros((3, 0))).shape == (3, 0)
+
+
+def test_malformed_programs_are_rejected(engine):
+    lib = engine.lib()
+    prog = (_vector.VecInstr * 2)()
+    out = np.zeros((3, 4), np.float32)
+    p = np.zeros((3, 4), np.float32)
+
+    def run(n_instr=2, n_streams=0):
+        return lib.sdfk_vec_eval_host(prog, n_instr, engine._ptr(p), 0, 4, None, 0, None, 0, None, 0, None, n_streams, 0,
+                                      engine._ptr(out), 0)
+    prog[0].op, prog[1].op = _vector.OP["ADD"] | _vector.K_IMM1 << 8, _vector.OP["NORMALIZE"]
+    assert run() != 0 and "initialiser" in engine.last_error()
+    prog[0].op, prog[1].op = _vector.OP["INIT_P"], 99
+    assert run() != 0
+    prog[1].op = _vector.OP["ROT_Z"] | _vector.K_ROW1 << 8
+    prog[1].src[0] = 0
+    assert run() != 0 and "stream row" in engine.last_error()
+    prog[1].op = _vector.OP["NORMALIZE"] | _vector.K_IMM1 << 8
+    assert run() != 0 and "operand kind" in engine.last_error()
+    prog[1].op = _vector.OP["NORMALIZE"]
+    assert run() == 0
