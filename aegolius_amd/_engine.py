@@ -47,6 +47,9 @@ SIGNATURES = {
     "sdfk_field_select": (_int, [_vp, _i64, _c.c_float, _vp, _i64, _c.POINTER(_i64), _vp, _vp]),
     "sdfk_field_gradient": (_int, [_vp, _i64, _i64, _i64, _int, _int, _vp, _i64, _vp]),
     "sdfk_vec_eval_device": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _i64, _int, _vp, _i64, _vp]),
+    "sdfk_vec_set_interpret": (None, [_int]),
+    "sdfk_vec_source": (_c.c_char_p, [_vp, _int, _int, _int]),
+    "sdfk_vec_compile_check": (_int, [_vp, _int, _int, _int, _c.POINTER(_sz)]),
     "sdfk_vec_eval_host": (_int, [_vp, _int, _vp, _int, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _int, _int, _vp, _int]),
     "sdfk_eval_grid": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _int]),
     "sdfk_eval_grid_host": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _int, _int]),

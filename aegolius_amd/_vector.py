@@ -287,6 +287,17 @@ def _run(b, p_arr, grid_axes, out_kind, config):
     return out
 
 
+def program_array(instr):
+    """ctypes array of a lower_only() instruction list."""
+    prog = (VecInstr * len(instr))()
+    for k, (op, ka, kb, src, imm) in enumerate(instr):
+        prog[k].op = op | ka << 8 | kb << 12
+        prog[k].src[0], prog[k].src[1] = src
+        for j in range(4):
+            prog[k].imm[j] = imm[j]
+    return prog
+
+
 def lower_only(closure, p, params=()):
     """(instructions, stream rows) of closure(p, *params) without running it — CPU tests of the lowering."""
     closure = as_closure(closure)

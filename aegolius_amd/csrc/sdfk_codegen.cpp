@@ -9,6 +9,8 @@
 // text of sdfk_device.h / sdfk_access.h, generated at build time by __graft_entry__.build()
 #include "sdfk_embedded.inc"
 
+std::string sdfk_vector_prelude() { return std::string(kEmbeddedDevice) + "\n" + kEmbeddedVecdev + "\n"; }
+
 static const char kWrappers[] = R"SDFKW(
 template <int VEC, typename SRC>
 static __device__ __forceinline__ void sdfk_body(const float* __restrict__ PRM, const float* __restrict__ TAB,

@@ -31,4 +31,7 @@ struct sdfk_cullsite {
 std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32_t* code, size_t n_instr,
                                  int result_reg, const std::vector<sdfk_cullsite>& sites);
 
+// Text every chain-specialised vector kernel starts with: sdfk_device.h followed by sdfk_vecdev.h.
+std::string sdfk_vector_prelude();
+
 #endif

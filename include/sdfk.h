@@ -195,6 +195,14 @@ typedef struct {
 int sdfk_vec_eval_device(const sdfk_vec_instr* prog, int n_instr, const float* d_p, int64_t n, int64_t p_stride,
                          const float* d_streams, int n_streams, int64_t stream_stride, int out_kind, float* d_out,
                          int64_t out_stride, void* stream);
+/* By default a chain's TOPOLOGY (opcodes, operand kinds, stream rows, read-out) is compiled once per process with
+ * hiprtc into a straight-line kernel (immediates stay run-time values); sdfk_vec_set_interpret(1) — or
+ * SDFK_VEC_INTERPRET=1 in the environment — runs the interpreter kernel instead. Both give the same bits.
+ * sdfk_vec_source: the generated HIP source (valid until the next call on the thread); sdfk_vec_compile_check:
+ * compile it for gfx950 without a device. */
+void sdfk_vec_set_interpret(int on);
+const char* sdfk_vec_source(const sdfk_vec_instr* prog, int n_instr, int n_streams, int out_kind);
+int sdfk_vec_compile_check(const sdfk_vec_instr* prog, int n_instr, int n_streams, int out_kind, size_t* code_size);
 /* HOST arrays staged through the device in chunks: p (dtype 0 = fp32, 1 = fp64; (3, n) contiguous) or, when ax0..ax2
  * are given, the generate_grid cloud of those tables (expanded on the device); streams (n_streams, n) fp32; out (3, n)
  * or (n,) fp32. */

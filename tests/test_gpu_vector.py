@@ -183,3 +183,34 @@ def test_malformed_programs_are_rejected(engine):
     assert run() != 0 and "operand kind" in engine.last_error()
     prog[1].op = _vector.OP["NORMALIZE"]
     assert run() == 0
+
+
+@pytest.mark.parametrize("name", sorted(vs.SCENES))
+def test_specialised_and_interpreter_kernels_give_the_same_bits(name, engine, aux):
+    """The hiprtc kernel of a chain's topology and the interpreter kernel call the same device functions."""
+    lib = engine.lib()
+    try:
+        lib.sdfk_vec_set_interpret(1)
+        interpreted = vs.run(ns, name, {k: v.copy() for k, v in aux.items()})
+    finally:
+        lib.sdfk_vec_set_interpret(0)
+    specialised = vs.run(ns, name, {k: v.copy() for k, v in aux.items()})
+    np.testing.assert_array_equal(specialised, interpreted)
+
+
+def test_one_compiled_kernel_serves_every_chain_of_the_same_shape(engine, aux):
+    import time
+    def chain(angle, vec):
+        f = ns.VortexCylindricalVectorField()
+        f.rotate_y(angle)
+        f.add(vec)
+        f.rotate_x(aux["alpha"])
+        f.normalize()
+        return f
+    first = chain(0.123, (1.0, 0.0, 0.5))
+    first.create(aux["p"])                                      # builds (or finds) the kernel of this topology
+    t0 = time.perf_counter()
+    other = chain(-2.5, (0.0, 3.0, 0.25))
+    got = other.create(aux["p"])
+    assert time.perf_counter() - t0 < 0.2                       # new numbers, same shape: no compilation
+    close(got, vo.evaluate(other.vf, aux["p"], ()), slack=8.0 * 1e-7)

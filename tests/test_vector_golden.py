@@ -119,3 +119,19 @@ def test_lowering_of_a_chain(aux):
         g = ns.CartesianVectorField()
         g.rotate_x(np.zeros(7))
         _vector.lower_only(g.vf, aux["p"], ())
+
+
+@pytest.mark.parametrize("name", ["long_chain", "read_out_theta", "read_out_length", "rotate_axis_per_point", "cartesian",
+                                  "revolution_y_other_cloud", "angled_vortex_per_point", "spherical_components"])
+def test_chain_specialised_source_compiles_for_gfx950(name, built, aux):
+    """hiprtc cross-compiles the straight-line kernel of a chain without a GPU (the build check of the vector path)."""
+    import ctypes
+    field, key, read = vs.SCENES[name](ns, aux)
+    instr, rows = _vector.lower_only(field.vf, aux[key], field._vf_parameters)
+    prog = _vector.program_array(instr)
+    kind = _vector.OUT_KINDS["vector" if read == "create" else read]
+    src = built.lib().sdfk_vec_source(prog, len(instr), len(rows), kind).decode()
+    assert src.count("sdfk_vec_apply(") >= len(instr) and "sdfk_vspec" in src
+    size = ctypes.c_size_t(0)
+    built.check(built.lib().sdfk_vec_compile_check(prog, len(instr), len(rows), kind, ctypes.byref(size)), "compile")
+    assert size.value > 1000

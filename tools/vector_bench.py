@@ -39,7 +39,12 @@ def main(res=1024):
         for j in range(4):
             prog[k].imm[j] = imm[j]
     out = {"grid": [a.size for a in axes], "points": n, "instructions": len(instr)}
-    for label, kind, nbytes in (("chain_to_vector", 0, 28.0 * n), ("chain_to_length", 6, 20.0 * n)):
+    for label, kind, nbytes, interpret in (("chain_to_vector", 0, 28.0 * n, 0), ("chain_to_length", 6, 20.0 * n, 0),
+                                           ("chain_to_vector_interpreter_kernel", 0, 28.0 * n, 1)):
+        lib.sdfk_vec_set_interpret(interpret)
+        _engine.check(lib.sdfk_vec_eval_device(prog, len(instr), vp(d_p), n, stride, vp(d_s), 1, stride, kind, vp(d_o),
+                                               stride, None), "sdfk_vec_eval_device")     # builds the kernel: not timed
+        _engine.check(lib.sdfk_sync(None), "sync")
         best = 1e9
         for _ in range(5):
             e0, e1 = _engine.Event(), _engine.Event()
@@ -50,6 +55,7 @@ def main(res=1024):
             best = min(best, e0.elapsed_ms(e1))
         out[label] = {"ms": round(best, 4), "algorithmic_GB": nbytes / 1e9, "GB/s": round(nbytes / best / 1e6, 1),
                       "frac_of_8TB/s": round(nbytes / best / 1e6 / 8000, 3)}
+    lib.sdfk_vec_set_interpret(0)
     for d in (d_p, d_s, d_o):
         lib.sdfk_free(vp(d))
     print(json.dumps(out, indent=1))
