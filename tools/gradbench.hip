@@ -171,7 +171,13 @@ __global__ __launch_bounds__(256) void band(const float* __restrict__ f, GridDim
     int j = (int)(q / d.n2), k = (int)(q - (long long)j * d.n2);
     float c[6], ylo[4], yhi[4], xlo[4], xhi[4];
     const bool inner = p >= plane + 1 && p + plane + 5 <= n;
-    if (inner) {
+    if (inner && MATH == 2) {                                 // timing only: what aligned neighbour loads would cost
+        const f4 cc = *(const f4*)(f + p);
+        const f4 a = *(const f4*)(f + ((p - d.n2) & ~3ll)), bb = *(const f4*)(f + ((p + d.n2) & ~3ll));
+        const f4 u = *(const f4*)(f + ((p - plane) & ~3ll)), v = *(const f4*)(f + ((p + plane) & ~3ll));
+        c[0] = __shfl_up(cc[3], 1, 64); c[5] = __shfl_down(cc[0], 1, 64);
+        for (int e = 0; e < 4; ++e) { c[e + 1] = cc[e]; ylo[e] = __shfl_down(a[e], 1, 64) + a[(e + 1) & 3]; yhi[e] = bb[e]; xlo[e] = u[e]; xhi[e] = v[e]; }
+    } else if (inner) {
         const f4 cc = *(const f4*)(f + p);
         const f4u a = *(const f4u*)(f + p - d.n2), bb = *(const f4u*)(f + p + d.n2);
         const f4u u = *(const f4u*)(f + p - plane), v = *(const f4u*)(f + p + plane);
@@ -323,6 +329,8 @@ int main(int argc, char** argv) {
     BAND(8, 0, 1, "band tj8 f32")
     BAND(16, 0, 1, "band tj16 f32")
     BAND(32, 0, 1, "band tj32 f32")
+    BAND(32, 0, 2, "band tj32 f32 abl-aligned-loads")
+    BAND(32, 2, 2, "band tj32 f32 abl-aligned-loads-nostore")
     BAND(64, 0, 1, "band tj64 f32")
     BAND(16, 1, 1, "band tj16 f32 plain stores")
     BAND(16, 2, 1, "band tj16 f32 abl-nostore")
