@@ -171,7 +171,12 @@ __global__ __launch_bounds__(256) void band(const float* __restrict__ f, GridDim
     int j = (int)(q / d.n2), k = (int)(q - (long long)j * d.n2);
     float c[6], ylo[4], yhi[4], xlo[4], xhi[4];
     const bool inner = p >= plane + 1 && p + plane + 5 <= n;
-    if (inner && MATH == 2) {                                 // timing only: what aligned neighbour loads would cost
+    if (inner && MATH == 3) {                                 // timing only: no plane-neighbour loads (what marching would save)
+        const f4 cc = *(const f4*)(f + p);
+        const f4u a = *(const f4u*)(f + p - d.n2), bb = *(const f4u*)(f + p + d.n2);
+        c[0] = f[p - 1]; c[5] = f[p + 4];
+        for (int e = 0; e < 4; ++e) { c[e + 1] = cc[e]; ylo[e] = a[e]; yhi[e] = bb[e]; xlo[e] = a[e]; xhi[e] = bb[e]; }
+    } else if (inner && MATH == 2) {                          // timing only: what aligned neighbour loads would cost
         const f4 cc = *(const f4*)(f + p);
         const f4 a = *(const f4*)(f + ((p - d.n2) & ~3ll)), bb = *(const f4*)(f + ((p + d.n2) & ~3ll));
         const f4 u = *(const f4*)(f + ((p - plane) & ~3ll)), v = *(const f4*)(f + ((p + plane) & ~3ll));
@@ -218,7 +223,8 @@ __global__ __launch_bounds__(256) void band(const float* __restrict__ f, GridDim
     }
     if (p + 4 <= n) {
         for (int a = 0; a < 3; ++a) {
-            if (STORE == 0) __builtin_nontemporal_store(o[a], (f4*)(out + (long long)a * stride + p));
+            if (STORE == 3) *(f4u*)(out + (long long)a * stride + p + 1) = o[a];   // timing only: 4-byte-aligned 16-byte stores
+            else if (STORE == 0) __builtin_nontemporal_store(o[a], (f4*)(out + (long long)a * stride + p));
             else *(f4*)(out + (long long)a * stride + p) = o[a];
         }
     } else {
@@ -329,6 +335,8 @@ int main(int argc, char** argv) {
     BAND(8, 0, 1, "band tj8 f32")
     BAND(16, 0, 1, "band tj16 f32")
     BAND(32, 0, 1, "band tj32 f32")
+    BAND(32, 0, 3, "band tj32 f32 abl-no-plane-loads")
+    BAND(32, 3, 1, "band tj32 f32 abl-unaligned-stores")
     BAND(32, 0, 2, "band tj32 f32 abl-aligned-loads")
     BAND(32, 2, 2, "band tj32 f32 abl-aligned-loads-nostore")
     BAND(64, 0, 1, "band tj64 f32")
