@@ -214,3 +214,31 @@ def test_one_compiled_kernel_serves_every_chain_of_the_same_shape(engine, aux):
     got = other.create(aux["p"])
     assert time.perf_counter() - t0 < 0.2                       # new numbers, same shape: no compilation
     close(got, vo.evaluate(other.vf, aux["p"], ()), slack=8.0 * 1e-7)
+
+
+def test_vector_chain_at_scale(engine):
+    """513^3 (BASELINE cfg 2's single-box size) through the product API on a generate_grid cloud (expanded on the
+    device): size-independent properties plus 100,000 sampled points against the oracle."""
+    co, _ = ns.generate_grid((2, 2, 2), (512, 512, 512))
+    n = co.shape[1]
+    f = ns.RadialSphericalVectorField()
+    f.rotate_phi(0.3)
+    f.revolution_z(co)
+    f.add((0.0, 0.0, 0.5))
+    f.normalize()
+    got = f.create(co)
+    assert got.shape == (3, n) and got.dtype == np.float32
+    pick = np.random.default_rng(11).integers(0, n, 100000)
+    sample = np.asarray(co)[:, pick].astype(np.float32).astype(np.float64)     # the grid tables are fp32
+    g = ns.RadialSphericalVectorField()
+    g.rotate_phi(0.3)
+    g.revolution_z(sample)
+    g.add((0.0, 0.0, 0.5))
+    g.normalize()
+    want = vo.evaluate(g.vf, sample, ())
+    close(got[:, pick], want, slack=4e-6)
+    lengths = np.linalg.norm(got[:, pick].astype(np.float64), axis=0)
+    assert np.abs(lengths - 1).max() < 1e-6
+    # the read-outs agree with the vector they are taken from
+    np.testing.assert_array_equal(f.z(co), got[2])
+    assert np.abs(f.length(co)[pick] - 1).max() < 1e-6
