@@ -9,7 +9,7 @@ The geometry objects record a symbolic expression tree; `create()` lowers it to 
 program and runs it as ONE fused per-point HIP kernel (libsdfk.so, gfx950). There is no CPU path.
 """
 from ._eval import config  # noqa: F401
-from ._engine import DeviceField  # noqa: F401
+from ._engine import DeviceField, DeviceVectorField  # noqa: F401
 from . import cores  # noqa: F401
 
 __version__ = "0.1.0"

@@ -348,6 +348,71 @@ class DeviceField:
         finally:
             L.sdfk_free(_vp(d_vec))
 
+    def gradient_resident(self, shape, normalize=True):
+        """gradient() of a 3-D field, left on the device as a DeviceVectorField."""
+        self._live()
+        shape = tuple(int(x) for x in shape)
+        if len(shape) != 3 or int(np.prod(shape)) != self.n:
+            raise ValueError("gradient_resident takes a 3-D grid of %d points; got %r" % (self.n, shape))
+        if min(shape) < 2:
+            raise ValueError("Shape of array too small to calculate a numerical gradient, at least (edge_order + 1) elements are required.")
+        out = DeviceVectorField(self.n, self.device)
+        check(lib().sdfk_field_gradient(_vp(self.ptr), shape[0], shape[1], shape[2], 3, 1 if normalize else 0, _vp(out.ptr),
+                                        out.stride, None), "sdfk_field_gradient")
+        return out
+
+    def free(self):
+        p, self.ptr = getattr(self, "ptr", None), None
+        if p and _lib is not None:
+            _lib.sdfk_free(_vp(p))
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceVectorField:
+    """A (3, N) float32 vector field resident in HBM (what `VectorField.create_resident` returns): three rows of
+    `stride` floats. Usable as the input, a second field or the revolution coordinates of another vector-field chain
+    without crossing PCIe. Owns its device memory."""
+
+    def __init__(self, n, device=0):
+        require_gpu()
+        self.n, self.device = int(n), int(device)
+        self.stride = (self.n + 63) // 64 * 64
+        check(lib().sdfk_set_device(self.device), "sdfk_set_device")
+        self.ptr = lib().sdfk_malloc(max(self.stride, 64) * 3 * 4)
+        if not self.ptr:
+            raise SdfkError("DeviceVectorField: out of device memory: " + last_error())
+
+    shape = property(lambda self: (3, self.n))
+
+    @classmethod
+    def from_host(cls, vec, device=0):
+        host = np.ascontiguousarray(vec, dtype=np.float32)
+        if host.ndim != 2 or host.shape[0] != 3:
+            raise ValueError("a vector field has shape (3, N); got %r" % (host.shape,))
+        self = cls(host.shape[1], device)
+        for r in range(3):
+            if self.n:
+                check(lib().sdfk_memcpy_h2d(_vp(self.ptr + 4 * r * self.stride), _ptr(host[r]), self.n * 4), "sdfk_memcpy_h2d")
+        return self
+
+    def row_ptr(self, r):
+        if not self.ptr:
+            raise SdfkError("DeviceVectorField has been freed")
+        return self.ptr + 4 * r * self.stride
+
+    def numpy(self):
+        check(lib().sdfk_set_device(self.device), "sdfk_set_device")
+        out = np.empty((3, self.n), dtype=np.float32)
+        for r in range(3):
+            if self.n:
+                check(lib().sdfk_memcpy_d2h(_ptr(out[r]), _vp(self.row_ptr(r)), self.n * 4), "sdfk_memcpy_d2h")
+        return out
+
     def free(self):
         p, self.ptr = getattr(self, "ptr", None), None
         if p and _lib is not None:

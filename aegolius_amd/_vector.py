@@ -37,6 +37,9 @@ class _Builder:
         self._seen = {}
 
     def _row(self, a):
+        if isinstance(a, tuple):                                 # (device pointer, owner): a row that is already in HBM
+            self.rows.append(a)
+            return len(self.rows) - 1
         a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
         if a.size != self.n:
             raise ValueError("operands could not be broadcast together with shapes (3,%d) (%d,)" % (self.n, a.size))
@@ -46,6 +49,16 @@ class _Builder:
     def rows_of(self, arr, count):
         """First stream row of a (count, N) operand; identical arrays are uploaded once."""
         key = (id(arr), count)
+        if key not in self._seen and isinstance(arr, (_engine.DeviceField, _engine.DeviceVectorField)):
+            if arr.n != self.n:
+                raise ValueError("operands could not be broadcast together with shapes (3,%d) (%d,)" % (self.n, arr.n))
+            if isinstance(arr, _engine.DeviceField):
+                first = self._row((arr.ptr, arr))
+            else:
+                first = self._row((arr.row_ptr(0), arr))
+                self._row((arr.row_ptr(1), arr))
+                self._row((arr.row_ptr(2), arr))
+            self._seen[key] = (first, arr)
         if key not in self._seen:
             a = np.asarray(arr)
             first = self._row(a if count == 1 else a[0])
@@ -77,6 +90,9 @@ class _Builder:
     # ---- operand classification: what NumPy's broadcasting does in the reference --------------------------------------
     def number_or_row(self, value, what):
         """A spatially independent or dependent number (angles): scalar or (N,)."""
+        dev = self.device_operand(value, 1)
+        if dev is not None:
+            return dev
         a = np.asarray(value, dtype=np.float64)
         if a.size == 1:
             return K_IMM1, float(a.reshape(-1)[0])
@@ -88,12 +104,27 @@ class _Builder:
     def addend(self, value):
         """add_vectors / subtract_vectors (cores/vector_modification_functions.py:23-36): size 3 -> one vector for every
         point, anything else is broadcast against (3, N)."""
+        dev = self.device_operand(value, None)
+        if dev is not None:
+            return dev
         a = np.asarray(value, dtype=np.float64)
         if a.size == 3:
             if a.shape not in ((3,), (1, 3)) and self.n != 3:    # np.add(vec.T, add_vec): (N, 3) against a column fails
                 raise ValueError("operands could not be broadcast together with shapes (%d,3) %s " % (self.n, a.shape))
             return K_IMM3, a.reshape(-1)
         return self.broadcast(a, value)
+
+    def device_operand(self, value, rows):
+        """A DeviceField (one number per point) or DeviceVectorField (one vector per point) used as an operand."""
+        if isinstance(value, tuple) and len(value) == 1:
+            value = value[0]                                     # the ready-made classes wrap their angle in a 1-tuple
+        if isinstance(value, _engine.DeviceField) and rows in (1, None):
+            return K_ROW1, self.rows_of(value, 1)
+        if isinstance(value, _engine.DeviceVectorField) and rows in (3, None):
+            return K_ROW3, self.rows_of(value, 3)
+        if isinstance(value, (_engine.DeviceField, _engine.DeviceVectorField)):
+            raise ValueError("a %s cannot be used here" % type(value).__name__)
+        return None
 
     def broadcast(self, a, value):
         """numpy broadcasting of an operand against (3, N)."""
@@ -109,6 +140,9 @@ class _Builder:
 
     def vectors(self, value, what):
         """One 3-vector or one per point (rotation axes)."""
+        dev = self.device_operand(value, 3)
+        if dev is not None:
+            return dev
         a = np.asarray(value, dtype=np.float64)
         if a.size == 3:
             return K_IMM3, a.reshape(-1)
@@ -120,6 +154,9 @@ class _Builder:
         """The coordinate cloud of a revolution: the evaluation's own input when it is the same array."""
         if co is self.p:
             return K_P, None
+        dev = self.device_operand(co, 3)
+        if dev is not None:
+            return dev
         a = np.asarray(co)
         if a.shape != (3, self.n):
             raise ValueError("the coordinates of a revolution must have shape (3, %d); got %r" % (self.n, a.shape))
@@ -168,7 +205,8 @@ def _apply_mod(b, name, args):
     if name in ("add", "subtract"):
         b.emit("ADD" if name == "add" else "SUB", b.addend(args[0]))
     elif name == "rescale":
-        b.emit("MUL", b.broadcast(np.asarray(args[0], dtype=np.float64), args[0]))
+        dev = b.device_operand(args[0], None)
+        b.emit("MUL", dev if dev is not None else b.broadcast(np.asarray(args[0], dtype=np.float64), args[0]))
     elif name in ("rotate_phi", "rotate_z"):
         b.emit("ROT_Z", b.number_or_row(args[0], "the angle"))
     elif name == "rotate_x":
@@ -209,8 +247,10 @@ def _leaf_name(fn):
     return getattr(fn, "_vec_leaf", None)
 
 
-def evaluate(closure, p, params, out="vector"):
-    """closure(p, *params) of the reference -> (3, N) array (or (N,) for a component / angle / length read-out)."""
+def evaluate(closure, p, params, out="vector", resident=False):
+    """closure(p, *params) of the reference -> (3, N) array (or (N,) for a component / angle / length read-out).
+    `resident`: leave the result in HBM (DeviceVectorField / DeviceField). `p` and any per-point operand may already
+    live there (DeviceVectorField / DeviceField): nothing of theirs crosses PCIe."""
     from ._eval import config
     closure = as_closure(closure)
     leaf = closure.leaf
@@ -221,7 +261,15 @@ def evaluate(closure, p, params, out="vector"):
         inner = inner.leaf
     mods = prefix + closure.mods
     name = _leaf_name(inner)
-    if name == "from_sdf":                                       # VectorFieldFromSDF: p is the (N,) field
+    if name == "from_sdf" and isinstance(p, _engine.DeviceField) and (mods or resident):
+        from ._eval import _grid_shape                           # a resident SDF: its gradient never leaves the device
+        shape = _grid_shape(p.n, params[0])
+        if len(shape) != 3:
+            raise NotImplementedError("modifications of a from_sdf field need a 3-D grid")
+        p_arr, grid_axes = p.gradient_resident(shape), None
+        b = _Builder(p.n, None)
+        b.emit("INIT_P")
+    elif name == "from_sdf":                                     # VectorFieldFromSDF: p is the (N,) field
         from .cores.vector_functions import from_sdf
         start = np.asarray(from_sdf(p, *params))
         if not mods and out == "vector":
@@ -234,8 +282,8 @@ def evaluate(closure, p, params, out="vector"):
     elif name in LEAVES:
         if name in STRICT_ARITY and params:
             raise TypeError("%s() takes 1 positional argument but %d were given" % (name, 1 + len(params)))
-        p_arr = p if isinstance(p, np.ndarray) else np.asarray(p, dtype=np.float64)
-        if p_arr.ndim != 2 or p_arr.shape[0] != 3:
+        p_arr = p if isinstance(p, (np.ndarray, _engine.DeviceVectorField)) else np.asarray(p, dtype=np.float64)
+        if len(p_arr.shape) != 2 or p_arr.shape[0] != 3:
             raise ValueError("vector fields take a (3, N) array; got shape %r" % (p_arr.shape,))
         grid_axes = getattr(p, "grid_axes", None) if config.grid_fast_path else None
         b = _Builder(p_arr.shape[1], p)
@@ -255,7 +303,67 @@ def evaluate(closure, p, params, out="vector"):
         b.emit("INIT_P")
     for mod_name, args in mods:
         _apply_mod(b, mod_name, args)
+    on_device = resident or isinstance(p_arr, _engine.DeviceVectorField) or any(isinstance(r, tuple) for r in b.rows)
+    if on_device:
+        return _run_device(b, p_arr, grid_axes, OUT_KINDS[out], config, resident)
     return _run(b, p_arr, grid_axes, OUT_KINDS[out], config)
+
+
+def _run_device(b, p_arr, grid_axes, out_kind, config, resident):
+    """The chain on whole device arrays through sdfk_vec_eval_device: p is expanded from the grid tables, taken from a
+    DeviceVectorField or uploaded; operand rows that already live in HBM are copied device-to-device into the streams
+    array, host rows are uploaded; the result stays there when `resident`."""
+    _engine.require_gpu()
+    lib, vp = _engine.lib(), _engine._vp
+    n = b.n
+    _engine.check(lib.sdfk_set_device(config.device), "sdfk_set_device")
+    prog = (VecInstr * len(b.instr))(*b.instr)
+    stride = (n + 63) // 64 * 64
+    own_p = None
+    d_streams = None
+    result = _engine.DeviceVectorField(n, config.device) if out_kind == 0 else _engine.DeviceField(stride, config.device)
+    try:
+        if isinstance(p_arr, _engine.DeviceVectorField):
+            d_p, p_stride = p_arr.ptr, p_arr.stride
+        else:
+            own_p = _engine.DeviceVectorField(n, config.device)
+            d_p, p_stride = own_p.ptr, own_p.stride
+            if grid_axes is not None:
+                _engine.grid_fill(d_p, p_stride, grid_axes, 0, n)
+            else:
+                host = np.ascontiguousarray(p_arr, dtype=np.float32)
+                for r in range(3):
+                    if n:
+                        _engine.check(lib.sdfk_memcpy_h2d(vp(own_p.row_ptr(r)), _engine._ptr(host[r]), n * 4), "h2d")
+        if b.rows:
+            d_streams = lib.sdfk_malloc(len(b.rows) * stride * 4)
+            if not d_streams:
+                raise _engine.SdfkError("vector chain: out of device memory")
+            for k, row in enumerate(b.rows):
+                dst = vp(d_streams + 4 * k * stride)
+                if isinstance(row, tuple):
+                    _engine.check(lib.sdfk_memcpy_d2d(dst, vp(row[0]), n * 4), "d2d")
+                elif n:
+                    _engine.check(lib.sdfk_memcpy_h2d(dst, _engine._ptr(row), n * 4), "h2d")
+        out_stride = result.stride if out_kind == 0 else stride
+        _engine.check(lib.sdfk_vec_eval_device(prog, len(b.instr), vp(d_p), n, p_stride, vp(d_streams) if d_streams else None,
+                                               len(b.rows), stride, out_kind, vp(result.ptr), out_stride, None),
+                      "sdfk_vec_eval_device")
+        _engine.check(lib.sdfk_sync(None), "sdfk_sync")
+    finally:
+        if own_p is not None:
+            own_p.free()
+        if d_streams:
+            lib.sdfk_free(vp(d_streams))
+    if out_kind != 0:
+        result.n = n                                             # allocated with the padded length: 16-byte row ends
+    if resident:
+        return result
+    out = result.numpy()
+    result.free()
+    if config.output_dtype is not np.float32:
+        out = out.astype(config.output_dtype)
+    return out
 
 
 def _run(b, p_arr, grid_axes, out_kind, config):

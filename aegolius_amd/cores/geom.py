@@ -82,6 +82,15 @@ class VectorField(ModifyVectorObject):
         """Applies the modifications and returns the map of the vector field, shape (3, N)."""
         return self._evaluate(p, "vector")
 
+    def create_resident(self, p):
+        """create(), but the field stays in HBM: returns an `aegolius_amd.DeviceVectorField` (`.numpy()`), usable as
+        the input, a second field or the revolution coordinates of another chain. `p` may itself be a
+        DeviceVectorField (for `VectorFieldFromSDF`: a DeviceField from `GenericGeometry.create_resident`), and so may
+        every per-point operand handed to a modification or a field constructor."""
+        from .._vector import evaluate
+        self._vf = self.vf
+        return evaluate(self._vf, p, self._vf_parameters, "vector", resident=True)
+
     def propagate(self, p, *parameters_):
         """Same as create(); extra arguments are ignored."""
         return self._evaluate(p, "vector")

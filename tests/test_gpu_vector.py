@@ -242,3 +242,57 @@ def test_vector_chain_at_scale(engine):
     # the read-outs agree with the vector they are taken from
     np.testing.assert_array_equal(f.z(co), got[2])
     assert np.abs(f.length(co)[pick] - 1).max() < 1e-6
+
+
+def test_resident_pipeline_from_sdf_to_vector_field(engine):
+    """SDF fields and vector fields that stay in HBM feed a chain as angle, second field, coordinates and input: the
+    result equals, bit for bit, the same chain fed with the downloaded arrays."""
+    from aegolius_amd import DeviceField, DeviceVectorField
+    co, res = ns.generate_grid((2, 2, 2), (40, 36, 32))
+    n = co.shape[1]
+    ball = ns.Sphere(0.6)
+    ball.move((0.1, 0.0, -0.2))
+    slab = ns.Box(1.2, 0.8, 0.4)
+    slab.rotate(0.4, (1, 1, 0))
+    sdf_dev, ang_dev = ball.create_resident(co), slab.create_resident(co)
+    sdf, ang = sdf_dev.numpy(), ang_dev.numpy()
+    second = np.random.default_rng(2).normal(size=(3, n)).astype(np.float32)
+    second_dev = DeviceVectorField.from_host(second)
+    np.testing.assert_array_equal(second_dev.numpy(), second)
+
+    def chain(angle, field2):
+        f = ns.AngledRadialCylindricalVectorField(angle)
+        f.rotate_theta(angle)
+        f.add(field2)
+        f.revolution_z(co)
+        f.rescale(angle)
+        f.normalize()
+        return f
+    on_device = chain(ang_dev, second_dev).create_resident(co)
+    assert isinstance(on_device, DeviceVectorField) and on_device.shape == (3, n)
+    from_host = chain(ang, second).create(co)
+    np.testing.assert_array_equal(on_device.numpy(), from_host)
+    np.testing.assert_array_equal(chain(ang_dev, second_dev).create(co), from_host)       # device operands, host result
+    close(from_host, vo.evaluate(chain(ang.astype(np.float64), second.astype(np.float64)).vf,
+                                 np.asarray(co, dtype=np.float32).astype(np.float64), (ang.astype(np.float64),)), slack=4e-6)
+    # a resident vector field as the INPUT of the next chain, and a read-out of it
+    nxt = ns.CartesianVectorField()
+    nxt.rotate_axis(second_dev, 0.7)
+    nxt.subtract(on_device)
+    expect = ns.CartesianVectorField()
+    expect.rotate_axis(second, 0.7)
+    expect.subtract(from_host)
+    np.testing.assert_array_equal(nxt.create(on_device), expect.create(from_host))
+    np.testing.assert_array_equal(nxt.length(on_device), expect.length(from_host))
+    # the gradient direction of a resident SDF enters a chain without leaving the device
+    g = ns.VectorFieldFromSDF(res)
+    g.rotate_z(ang_dev)
+    g.normalize()
+    h = ns.VectorFieldFromSDF(res)
+    h.rotate_z(ang)
+    h.normalize()
+    np.testing.assert_array_equal(g.create_resident(sdf_dev).numpy(), h.create(sdf))
+    bad = ns.CartesianVectorField()
+    bad.add(DeviceField.from_host(np.zeros(5, np.float32)))     # a field of another size
+    with pytest.raises(ValueError):
+        bad.create(co)
