@@ -309,13 +309,44 @@ def evaluate(closure, p, params, out="vector", resident=False):
     return _run(b, p_arr, grid_axes, OUT_KINDS[out], config)
 
 
-def _run_device(b, p_arr, grid_axes, out_kind, config, resident):
+def evaluate_slab(field, axes, start, count, out="vector", resident=False):
+    """Points [start, start + count) of field.create(generate_grid cloud of `axes`) — the multi-GPU path
+    (aegolius_amd.distributed.vector_field_sharded). The chain is lowered for the WHOLE cloud (operand shapes are
+    checked against N) and run on the slab: coordinates expanded on the device from the tables, per-point operands
+    sliced on their way up. `field` is a VectorField whose leaf is one of the built-in definitions."""
+    from ._eval import config
+    closure = as_closure(field.vf)
+    mods, inner = closure.mods, closure.leaf
+    while isinstance(inner, VecClosure):
+        mods, inner = inner.mods + mods, inner.leaf
+    name = _leaf_name(inner)
+    if name not in LEAVES:
+        raise NotImplementedError("sharded evaluation takes the built-in field definitions (got %r)" % (name or inner,))
+    n_total = int(np.prod([np.asarray(a).size for a in axes]))
+    if not (0 <= start and start + count <= n_total):
+        raise ValueError("slab [%d, %d) outside the grid of %d points" % (start, start + count, n_total))
+    whole = _GridCloud(n_total)
+    b = _Builder(n_total, whole)
+    LEAVES[name](b, field._vf_parameters)
+    for mod_name, args in mods:
+        _apply_mod(b, mod_name, [whole if getattr(a, "grid_axes", None) is not None else a for a in args])
+    return _run_device(b, None, axes, OUT_KINDS[out], config, resident, (int(start), int(count)))
+
+
+class _GridCloud:
+    """Stands for the generate_grid cloud itself while a chain is lowered for a slab (revolutions about its axes)."""
+
+    def __init__(self, n):
+        self.shape = (3, n)
+
+
+def _run_device(b, p_arr, grid_axes, out_kind, config, resident, slab=None):
     """The chain on whole device arrays through sdfk_vec_eval_device: p is expanded from the grid tables, taken from a
     DeviceVectorField or uploaded; operand rows that already live in HBM are copied device-to-device into the streams
     array, host rows are uploaded; the result stays there when `resident`."""
     _engine.require_gpu()
     lib, vp = _engine.lib(), _engine._vp
-    n = b.n
+    first, n = slab if slab is not None else (0, b.n)
     _engine.check(lib.sdfk_set_device(config.device), "sdfk_set_device")
     prog = (VecInstr * len(b.instr))(*b.instr)
     stride = (n + 63) // 64 * 64
@@ -329,7 +360,7 @@ def _run_device(b, p_arr, grid_axes, out_kind, config, resident):
             own_p = _engine.DeviceVectorField(n, config.device)
             d_p, p_stride = own_p.ptr, own_p.stride
             if grid_axes is not None:
-                _engine.grid_fill(d_p, p_stride, grid_axes, 0, n)
+                _engine.grid_fill(d_p, p_stride, grid_axes, first, n)
             else:
                 host = np.ascontiguousarray(p_arr, dtype=np.float32)
                 for r in range(3):
@@ -342,9 +373,10 @@ def _run_device(b, p_arr, grid_axes, out_kind, config, resident):
             for k, row in enumerate(b.rows):
                 dst = vp(d_streams + 4 * k * stride)
                 if isinstance(row, tuple):
-                    _engine.check(lib.sdfk_memcpy_d2d(dst, vp(row[0]), n * 4), "d2d")
+                    if n:
+                        _engine.check(lib.sdfk_memcpy_d2d(dst, vp(row[0] + 4 * first), n * 4), "d2d")
                 elif n:
-                    _engine.check(lib.sdfk_memcpy_h2d(dst, _engine._ptr(row), n * 4), "h2d")
+                    _engine.check(lib.sdfk_memcpy_h2d(dst, _engine._ptr(row[first:first + n]), n * 4), "h2d")
         out_stride = result.stride if out_kind == 0 else stride
         _engine.check(lib.sdfk_vec_eval_device(prog, len(b.instr), vp(d_p), n, p_stride, vp(d_streams) if d_streams else None,
                                                len(b.rows), stride, out_kind, vp(result.ptr), out_stride, None),

@@ -213,3 +213,19 @@ def _gpu_gradient(ext, shape):
     _engine.check(lib.sdfk_field_gradient(vp(ext.data_ptr()), dims[0], dims[1], dims[2], len(shape), 1,
                                           vp(vec.data_ptr()), stride, None), "sdfk_field_gradient")
     return vec[:, :n]
+
+
+def vector_field_sharded(field, size, resolution, out="vector", group=None, resident=False, evaluate_slab=None,
+                         world_rank=None):
+    """VectorField.create (or a read-out: out = x | y | z | phi | theta | length) on generate_grid(size, resolution),
+    this rank computing only its slab of whole grid rows: pointwise, so no halo and no collective. Per-point operands
+    of the chain (angles, second fields) are given for the WHOLE grid and sliced here; a revolution about the grid's own
+    coordinates uses the slab's. Returns (slab, resolution): a host array, or a DeviceVectorField / DeviceField when
+    `resident`."""
+    axes, res, shape = _grid(size, resolution)
+    world, rank = world_rank or _world(group)
+    n_total = int(np.prod(shape))
+    start, count = slab_bounds(n_total, world, rank, shape[-1])
+    if evaluate_slab is None:
+        from ._vector import evaluate_slab
+    return evaluate_slab(field, axes, start, count, out, resident), res

@@ -204,3 +204,27 @@ def test_sharded_consumers_under_a_process_group():
     np.testing.assert_array_equal(np.concatenate([g[1] for g in got], axis=1),
                                   sdf_oracle.from_sdf(field.astype(np.float64), (6, 8, 10)))
     np.testing.assert_array_equal(np.concatenate([g[2] for g in got]), np.flatnonzero(field <= 0))
+
+
+def test_sharded_vector_field_partitions_whole_rows():
+    """vector_field_sharded hands every rank a slab of whole grid rows that together cover the cloud exactly once
+    (the per-slab evaluator is a recorder here; the GPU evaluator is covered by tests/test_gpu_vector.py)."""
+    sys.path.insert(0, ROOT)
+    import aegolius_amd.cores as ns
+    from aegolius_amd.distributed import vector_field_sharded
+    field = ns.RadialSphericalVectorField()
+    for size, resolution, row in (((2, 2, 2), (6, 8, 10), 11), ((3, 3), (12, 8), 9)):
+        for world in (1, 2, 3, 5):
+            seen = []
+
+            def record(f, axes, start, count, out, resident):
+                assert f is field and out == "length" and not resident and start % row == 0 and count % row == 0
+                seen.append((start, count))
+                return np.zeros(count)
+            for r in range(world):
+                slab, res = vector_field_sharded(field, size, resolution, out="length", evaluate_slab=record,
+                                                 world_rank=(world, r))
+                assert slab.shape == (seen[-1][1],)
+            n = int(np.prod([a for a in ns.generate_grid(size, resolution)[0].shape[1:]]))
+            assert seen[0][0] == 0 and sum(c for _, c in seen) == n
+            assert all(a[0] + a[1] == b[0] for a, b in zip(seen, seen[1:]))

@@ -296,3 +296,26 @@ def test_resident_pipeline_from_sdf_to_vector_field(engine):
     bad.add(DeviceField.from_host(np.zeros(5, np.float32)))     # a field of another size
     with pytest.raises(ValueError):
         bad.create(co)
+
+
+def test_sharded_vector_field_equals_the_whole_cloud(engine):
+    """§8(e) for vector fields: slabs of whole rows emulated on one device, per-point operands sliced per rank."""
+    from aegolius_amd.distributed import vector_field_sharded
+    size, resolution = (2, 2, 2), (20, 18, 26)
+    co, _ = ns.generate_grid(size, resolution)
+    n = co.shape[1]
+    rng = np.random.default_rng(8)
+    ang, second = rng.uniform(-3, 3, n), rng.normal(size=(3, n))
+    f = ns.AngledVortexCylindricalVectorField(ang)
+    f.rotate_x(ang)
+    f.add(second)
+    f.revolution_y(co)
+    f.normalize()
+    whole, whole_phi = f.create(co), f.phi(co)
+    for world in (1, 2, 3, 7):
+        parts = [vector_field_sharded(f, size, resolution, world_rank=(world, r))[0] for r in range(world)]
+        np.testing.assert_array_equal(np.concatenate(parts, axis=1), whole)
+        phis = [vector_field_sharded(f, size, resolution, out="phi", world_rank=(world, r))[0] for r in range(world)]
+        np.testing.assert_array_equal(np.concatenate(phis), whole_phi)
+    dev, _ = vector_field_sharded(f, size, resolution, world_rank=(2, 1), resident=True)
+    np.testing.assert_array_equal(dev.numpy(), whole[:, n - dev.n:])
