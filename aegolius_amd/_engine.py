@@ -45,6 +45,7 @@ SIGNATURES = {
     "sdfk_eval_host_resident": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _int, _int]),
     "sdfk_field_select_scratch": (_sz, [_i64]),
     "sdfk_field_select": (_int, [_vp, _i64, _c.c_float, _vp, _i64, _c.POINTER(_i64), _vp, _vp]),
+    "sdfk_field_select_finish": (_int, [_i64, _i64, _vp, _i64, _vp, _vp]),
     "sdfk_field_gradient": (_int, [_vp, _i64, _i64, _i64, _int, _int, _vp, _i64, _vp]),
     "sdfk_vec_eval_device": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _i64, _int, _vp, _i64, _vp]),
     "sdfk_vec_set_interpret": (None, [_int]),
@@ -314,8 +315,8 @@ class DeviceField:
                 d_index = L.sdfk_malloc(m.value * 8)
                 if not d_index:
                     raise SdfkError("select: out of device memory")
-                check(L.sdfk_field_select(_vp(self.ptr), self.n, float(threshold), _vp(d_index), m.value, ctypes.byref(m),
-                                          _vp(d_scratch), None), "sdfk_field_select")
+                check(L.sdfk_field_select_finish(self.n, m.value, _vp(d_index), m.value, _vp(d_scratch), None),
+                      "sdfk_field_select_finish")
                 check(L.sdfk_memcpy_d2h(_ptr(out), _vp(d_index), out.size * 8), "sdfk_memcpy_d2h")
             return out
         finally:

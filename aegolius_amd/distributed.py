@@ -195,8 +195,8 @@ def _gpu_select(local, threshold):
                                         vp(scratch.data_ptr()), None), "sdfk_field_select")
     index = torch.empty(m.value, dtype=torch.int64, device=local.device)
     if m.value:
-        _engine.check(lib.sdfk_field_select(vp(local.data_ptr()), n, float(threshold), vp(index.data_ptr()), m.value,
-                                            ctypes.byref(m), vp(scratch.data_ptr()), None), "sdfk_field_select")
+        _engine.check(lib.sdfk_field_select_finish(n, m.value, vp(index.data_ptr()), m.value, vp(scratch.data_ptr()), None),
+                      "sdfk_field_select_finish")
     return index
 
 

@@ -156,7 +156,9 @@ int sdfk_grid_signed(float* d_field, int64_t n0, int64_t n1, int64_t n2, float s
  *   select    = the mask of GenericGeometry.point_cloud (cores/geom.py:62-74): the indices i, ascending, with
  *               field[i] <= threshold (NaN never selected). *count always receives the size of the selection;
  *               d_index == NULL counts only; otherwise d_index (DEVICE, capacity entries) must hold the selection.
- *               d_scratch: sdfk_field_select_scratch(n) bytes of device memory (NULL: allocated and freed inside).
+ *               d_scratch: sdfk_field_select_scratch(n) bytes (about n / 8) of 8-byte-aligned device memory (NULL:
+ *               allocated and freed inside). The field is read once: the count pass leaves 4 flag bits per quad in
+ *               the scratch, the scatter pass works from those.
  *               d_field must be 16-byte aligned.
  *   gradient  = vector_functions.from_sdf (cores/vector_functions.py:130-140): numpy.gradient with unit spacing
  *               (central differences, one-sided on the faces) over the LAST ncomp axes of the (n0, n1, n2) field
@@ -167,6 +169,9 @@ int sdfk_grid_signed(float* d_field, int64_t n0, int64_t n1, int64_t n2, float s
  *               d_vec (DEVICE, ncomp rows of row_stride floats) is the derivative along axis 3 - ncomp + r;
  *               d_field, d_vec and row_stride * 4 must be 16-byte aligned. */
 size_t sdfk_field_select_scratch(int64_t n);
+/* Second half of a selection whose count-only call (d_index == NULL, caller-owned d_scratch) has just run on a field
+ * of n points: writes the `count` indices that call announced without reading the field again. */
+int sdfk_field_select_finish(int64_t n, int64_t count, int64_t* d_index, int64_t capacity, void* d_scratch, void* stream);
 int sdfk_field_select(const float* d_field, int64_t n, float threshold, int64_t* d_index, int64_t capacity,
                       int64_t* count, void* d_scratch, void* stream);
 int sdfk_field_gradient(const float* d_field, int64_t n0, int64_t n1, int64_t n2, int ncomp, int normalize,

@@ -1,5 +1,6 @@
 """Developer tool (GPU): time the field consumers on a resident field (default 1025^3, BASELINE cfg 2's grid).
-Algorithmic traffic per point: select = 8 B (the field is read twice: count, scatter) + 8 B per selected point;
+Algorithmic traffic per point: select = 4 B (the field is read once; 1/8 B of packed flags goes to scratch and back) + 8 B
+per selected point;
 gradient = 4 B read + 4 B written per component (16 B for a 3-D grid)."""
 import ctypes
 import json
@@ -48,9 +49,13 @@ def main(res=1024):
 
     timed("select_count_only", lambda: _engine.check(
         lib.sdfk_field_select(vp(d_f), n, 0.0, None, 0, ctypes.byref(m), vp(d_s), None), "count"), 4.0 * n)
+    def two_step():                                             # what DeviceField.select does: count, allocate, finish
+        _engine.check(lib.sdfk_field_select(vp(d_f), n, 0.0, None, 0, ctypes.byref(m), vp(d_s), None), "count")
+        _engine.check(lib.sdfk_field_select_finish(n, m.value, vp(d_i), m.value, vp(d_s), None), "finish")
+    timed("select_count_then_finish", two_step, 4.0 * n + 8.0 * m.value)
     timed("select", lambda: _engine.check(
         lib.sdfk_field_select(vp(d_f), n, 0.0, vp(d_i), m.value, ctypes.byref(m), vp(d_s), None), "select"),
-        8.0 * n + 8.0 * m.value)
+        4.0 * n + 8.0 * m.value)
     timed("gradient_direction", lambda: _engine.check(
         lib.sdfk_field_gradient(vp(d_f), n0, n1, n2, 3, 1, vp(d_v), stride, None), "gradient"), 16.0 * n)
     timed("gradient_raw", lambda: _engine.check(
