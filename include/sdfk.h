@@ -143,6 +143,7 @@ int sdfk_eval_grid_aux(sdfk_program* prog, const float* ax0, int64_t n0, const f
  *                  else boundary = field < sep_min (the smallest grid spacing), scan-line parity along axes 0 and 1,
  *                  2x2x1 average, inner crop + edge pad (crop = 0: signed_old, :163-218, without it),
  *                  field *= (1 - 2*(average > 0.5)). */
+/* d_field: 16-byte aligned (sdfk_field_min and sdfk_grid_signed read it in 16-byte pieces). */
 int sdfk_field_min(const float* d_field, int64_t n, float* out_min, void* stream);
 /* d_scratch: n0*n1*n2*4 bytes of device memory for the operator's work arrays (NULL: allocated and freed inside). */
 int sdfk_grid_box_average(float* d_field, int64_t n0, int64_t n1, int64_t n2, int k0, int k1, int k2, int iterations,
