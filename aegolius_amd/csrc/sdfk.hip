@@ -24,6 +24,7 @@
 #include <thread>
 #include <string>
 #include <vector>
+#include <unistd.h>
 
 #include "../../include/sdfk.h"
 #include "sdfk_device.h"
@@ -519,9 +520,69 @@ static bool rows_geometry(long long n, long long row_len, RowGeom* g) {
     return true;
 }
 static int tile_threads() { return 64 * tile_waves(); }
+// Optional on-disk cache of hiprtc code objects (opt-in: SDFK_CACHE_DIR=<directory>): a new process then loads the
+// kernels of tree / chain shapes it has seen before instead of compiling them (≈ 0.3 s per primitive). The file name
+// is a 64-bit FNV-1a hash of the source, the options and the hiprtc version, plus the source length.
+static std::string rtc_cache_path(const std::string& src, const std::string& opts) {
+    const char* dir = getenv("SDFK_CACHE_DIR");
+    if (!dir || !*dir) return std::string();
+    int major = 0, minor = 0;
+    (void)hiprtcVersion(&major, &minor);
+    unsigned long long h = 1469598103934665603ull;
+    auto mix = [&](const std::string& t) {
+        for (unsigned char c : t) {
+            h ^= c;
+            h *= 1099511628211ull;
+        }
+    };
+    mix(src);
+    mix(opts);
+    mix(std::to_string(major) + "." + std::to_string(minor) + "/abi" + std::to_string(SDFK_ABI_VERSION));
+    char name[96];
+    snprintf(name, sizeof name, "/sdfk-%016llx-%zu.co", h, src.size());
+    return std::string(dir) + name;
+}
+static bool rtc_cache_read(const std::string& path, std::vector<char>* out) {
+    if (path.empty()) return false;
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    bool ok = false;
+    if (fseek(f, 0, SEEK_END) == 0) {
+        const long size = ftell(f);
+        if (size > 0 && fseek(f, 0, SEEK_SET) == 0) {
+            out->resize((size_t)size);
+            ok = fread(out->data(), 1, (size_t)size, f) == (size_t)size;
+        }
+    }
+    fclose(f);
+    return ok;
+}
+static void rtc_cache_write(const std::string& path, const std::vector<char>& co) {
+    if (path.empty() || co.empty()) return;
+    const std::string tmp = path + ".tmp" + std::to_string((long long)getpid());
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return;                                            // a cache that cannot be written is no error
+    const bool ok = fwrite(co.data(), 1, co.size(), f) == co.size();
+    fclose(f);
+    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());   // atomic: readers never see a partial file
+}
+
+static int rtc_compile_uncached(const std::string& src, std::vector<char>* out, std::string* log, int rwb, std::string* optkey);
 static int rtc_compile(const std::string& src, std::vector<char>* out, std::string* log, int rwb) {
-    hiprtcProgram prog;
-    if (hiprtcCreateProgram(&prog, src.c_str(), "sdfk_spec.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+    std::string optkey;
+    if (getenv("SDFK_CACHE_DIR")) {
+        (void)rtc_compile_uncached(std::string(), nullptr, nullptr, rwb, &optkey);      // options only
+        const std::string path = rtc_cache_path(src, optkey);
+        if (rtc_cache_read(path, out)) return 0;
+        const int rc = rtc_compile_uncached(src, out, log, rwb, nullptr);
+        if (rc == 0) rtc_cache_write(path, *out);
+        return rc;
+    }
+    return rtc_compile_uncached(src, out, log, rwb, nullptr);
+}
+static int rtc_compile_uncached(const std::string& src, std::vector<char>* out, std::string* log, int rwb, std::string* optkey) {
+    hiprtcProgram prog = nullptr;                              // optkey != NULL: only the option string is wanted
+    if (!optkey && hiprtcCreateProgram(&prog, src.c_str(), "sdfk_spec.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
         *log = "hiprtcCreateProgram failed";
         return -1;
     }
@@ -548,6 +609,10 @@ static int rtc_compile(const std::string& src, std::vector<char>* out, std::stri
         }
     }
     for (const std::string& x : extra) opts.push_back(x.c_str());
+    if (optkey) {                                              // the caller only wants the option string (cache key)
+        for (const char* o : opts) *optkey += std::string(o) + " ";
+        return 0;
+    }
     hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
     size_t ls = 0;
     hiprtcGetProgramLogSize(prog, &ls);

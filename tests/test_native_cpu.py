@@ -221,3 +221,23 @@ def test_no_gpu_means_an_error_never_a_cpu_result(built):
                  lambda: ns.from_sdf(np.zeros(125), res), lambda: ns.sdf_sphere(np.asarray(co), 0.5)):
         with pytest.raises(built.SdfkError, match="no HIP device|no CPU path"):
             call()
+
+
+def test_disk_cache_of_compiled_kernels_is_opt_in_and_reused(built, tmp_path, monkeypatch):
+    """SDFK_CACHE_DIR: the code object of a tree shape is written once and loaded by the next compile of that shape."""
+    import ctypes
+    import time
+    low = lower_geometry(scenes.SCENES[sorted(scenes.SCENES)[3]](ns))
+    prog = built.Program.from_lowered(low)
+    monkeypatch.delenv("SDFK_CACHE_DIR", raising=False)
+    assert prog.compile_check() > 0 and not list(tmp_path.iterdir())           # off by default: nothing written
+    monkeypatch.setenv("SDFK_CACHE_DIR", str(tmp_path))
+    t0 = time.perf_counter()
+    size = prog.compile_check()
+    cold = time.perf_counter() - t0
+    files = list(tmp_path.iterdir())
+    assert len(files) == 1 and files[0].suffix == ".co" and files[0].stat().st_size == size
+    t0 = time.perf_counter()
+    assert prog.compile_check() == size
+    assert time.perf_counter() - t0 < 0.5 * cold                               # read back, not compiled
+    assert len(list(tmp_path.iterdir())) == 1
