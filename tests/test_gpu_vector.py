@@ -319,3 +319,22 @@ def test_sharded_vector_field_equals_the_whole_cloud(engine):
         np.testing.assert_array_equal(np.concatenate(phis), whole_phi)
     dev, _ = vector_field_sharded(f, size, resolution, world_rank=(2, 1), resident=True)
     np.testing.assert_array_equal(dev.numpy(), whole[:, n - dev.n:])
+
+
+def test_the_example_of_the_integration_notes(engine):
+    from aegolius_amd.cores import AngledRadialCylindricalVectorField, VectorFieldFromSDF, Sphere, generate_grid
+    co, res = generate_grid((2, 2, 2), (48, 48, 48))
+    angle = Sphere(0.6).create_resident(co)
+    field = AngledRadialCylindricalVectorField(angle)
+    field.revolution_z(co)
+    field.normalize()
+    directions = field.create(co)
+    assert directions.shape == (3, co.shape[1]) and directions.dtype == np.float32
+    host = AngledRadialCylindricalVectorField(angle.numpy())
+    host.revolution_z(co)
+    host.normalize()
+    np.testing.assert_array_equal(directions, host.create(co))
+    np.testing.assert_array_equal(field.create_resident(co).numpy(), directions)
+    normals = VectorFieldFromSDF(res).create(Sphere(0.6).create(co))
+    lengths = np.linalg.norm(normals.astype(np.float64), axis=0)
+    assert normals.shape == (3, co.shape[1]) and np.all((np.abs(lengths - 1) < 1e-6) | (lengths == 0))
