@@ -135,3 +135,41 @@ def test_chain_specialised_source_compiles_for_gfx950(name, built, aux):
     size = ctypes.c_size_t(0)
     built.check(built.lib().sdfk_vec_compile_check(prog, len(instr), len(rows), kind, ctypes.byref(size)), "compile")
     assert size.value > 1000
+
+
+def test_operand_classification_follows_numpy_broadcasting(aux):
+    """Which operands become immediates, rows or errors — decided at lowering, before any GPU call."""
+    n = aux["p"].shape[1]
+    K = _vector
+
+    def kinds(apply):
+        f = ns.CartesianVectorField()
+        apply(f)
+        instr, rows = K.lower_only(f.vf, aux["p"], ())
+        return instr[-1][1], instr[-1][2], len(rows)
+    assert kinds(lambda f: f.add(2)) == (K.K_IMM1, K.K_NONE, 0)
+    assert kinds(lambda f: f.add(np.float32(2))) == (K.K_IMM1, K.K_NONE, 0)
+    assert kinds(lambda f: f.add([1, 2, 3])) == (K.K_IMM3, K.K_NONE, 0)
+    assert kinds(lambda f: f.add(np.ones((1, 3)))) == (K.K_IMM3, K.K_NONE, 0)
+    assert kinds(lambda f: f.add(np.ones(n))) == (K.K_ROW1, K.K_NONE, 1)
+    assert kinds(lambda f: f.add(np.ones((1, n)))) == (K.K_ROW1, K.K_NONE, 1)
+    assert kinds(lambda f: f.subtract(np.ones((3, n)))) == (K.K_ROW3, K.K_NONE, 3)
+    assert kinds(lambda f: f.rescale(np.ones((3, 1)))) == (K.K_IMM3, K.K_NONE, 0)
+    assert kinds(lambda f: f.rotate_axis(np.ones((3, n)), np.ones(n))) == (K.K_ROW3, K.K_ROW1, 4)
+    assert kinds(lambda f: f.rotate_axis((0, 0, 1), 0.5)) == (K.K_IMM3, K.K_IMM1, 0)
+    assert kinds(lambda f: f.revolution_x(aux["p"])) == (K.K_P, K.K_NONE, 0)
+    assert kinds(lambda f: f.revolution_x(aux["co2"])) == (K.K_ROW3, K.K_NONE, 3)
+    for bad in (lambda f: f.add(np.ones((3, 1))), lambda f: f.add(np.ones(n + 1)), lambda f: f.rescale((1, 2, 3)),
+                lambda f: f.rescale(np.ones((2, n))), lambda f: f.rotate_x(np.ones((3, n))),
+                lambda f: f.rotate_axis(np.ones((2, n)), 0.1), lambda f: f.revolution_z(np.ones((3, n - 1)))):
+        with pytest.raises(ValueError):
+            kinds(bad)
+    # NumPy raises for the same shapes
+    vec = np.zeros((3, n))
+    for operand in (np.ones(n + 1), np.ones((2, n))):
+        with pytest.raises(ValueError):
+            np.add(vec, operand)
+    with pytest.raises(ValueError):
+        np.add(vec.T, np.ones((3, 1)))
+    with pytest.raises(ValueError):
+        np.multiply(vec, (1, 2, 3))
