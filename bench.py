@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--mode", default="auto", choices=["auto", "interpret", "nocull"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-allgather", action="store_true")
+    ap.add_argument("--no-next-rows", action="store_true", help="skip the field-consumer extras (selection, gradient)")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host_path extra (it launches the "
                     "same kernel on a small array, which skews per-kernel averages under rocprofv3)")
     ap.add_argument("--no-rows", action="store_true", help="do not pass the row-length layout hint (flat 128-point bricks)")
@@ -232,6 +233,56 @@ def main():
                      "note": "sdfk_eval_host: pageable host (3, M) float32 in, (M,) float32 out, synchronous staging"}
         del hco
 
+    # the consumers of the field on the field this run has just produced, resident in HBM: separate
+    # numbers, never `value`; any failure is reported, not raised (the headline line must survive)
+    next_rows = None
+    if rank == 0 and world == 1 and not args.no_next_rows:
+        try:
+            import ctypes
+            lib, vp = _engine.lib(), ctypes.c_void_p
+            torch.cuda.synchronize()
+            scratch = torch.empty(lib.sdfk_field_select_scratch(count), dtype=torch.uint8, device=dev)
+            selected = ctypes.c_int64(0)
+            _engine.check(lib.sdfk_field_select(vp(out.data_ptr()), count, 0.0, None, 0, ctypes.byref(selected),
+                                                vp(scratch.data_ptr()), vp(stream)), "sdfk_field_select")
+            index = torch.empty(max(selected.value, 1), dtype=torch.int64, device=dev)
+            vec = torch.empty((3, stride), dtype=torch.float32, device=dev)
+
+            def best_ms(fn, reps=3):
+                best = 1e30
+                for _ in range(reps):
+                    e0, e1 = _engine.Event(), _engine.Event()
+                    e0.record(stream)
+                    fn()
+                    e1.record(stream)
+                    best = min(best, e0.elapsed_ms(e1))
+                return best
+
+            def select():
+                _engine.check(lib.sdfk_field_select(vp(out.data_ptr()), count, 0.0, None, 0, ctypes.byref(selected),
+                                                    vp(scratch.data_ptr()), vp(stream)), "sdfk_field_select")
+                _engine.check(lib.sdfk_field_select_finish(count, selected.value, vp(index.data_ptr()), selected.value,
+                                                           vp(scratch.data_ptr()), vp(stream)), "sdfk_field_select_finish")
+
+            flat = axes[2].size == 1                              # 2-D grids: (1, n0, n1), two components
+            dims = (1, axes[0].size, axes[1].size) if flat else (axes[0].size, axes[1].size, axes[2].size)
+
+            def gradient():
+                _engine.check(lib.sdfk_field_gradient(vp(out.data_ptr()), dims[0], dims[1], dims[2], 2 if flat else 3, 1,
+                                                      vp(vec.data_ptr()), stride, vp(stream)), "sdfk_field_gradient")
+            sel_ms, grad_ms = best_ms(select), best_ms(gradient)
+            sel_bytes = 4.0 * count + 8.0 * selected.value
+            next_rows = {
+                "interior_selection": {"ms": sel_ms, "selected": selected.value, "bytes": sel_bytes,
+                                       "frac_of_hbm_peak": sel_bytes / (sel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                "gradient_direction": {"ms": grad_ms, "bytes": (12.0 if flat else 16.0) * count,
+                                       "frac_of_hbm_peak": (12.0 if flat else 16.0) * count / (grad_ms * 1e-3) / 1e9
+                                       / HBM_PEAK_GBPS},
+                "note": "sdfk_field_select (+ _finish) and sdfk_field_gradient on the resident field of this run"}
+            del scratch, index, vec
+        except Exception as exc:  # noqa: BLE001
+            next_rows = {"error": repr(exc)}
+
     allgather = None
     if world > 1 and not args.no_allgather and not rehearse:
         pad = (n_total - (world - 1) * per)                   # largest slab
@@ -285,6 +336,8 @@ def main():
             line["host_path"] = host_path
         if grid_path:
             line["grid_path"] = grid_path
+        if next_rows:
+            line["next_rows"] = next_rows
         if allgather:
             line["allgather"] = allgather
         if world == 1 and args.cpu_seconds > 0:
