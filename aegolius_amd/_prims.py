@@ -212,8 +212,9 @@ TREE_THRESHOLD = 256     # tables up to this many points are scanned (P_NEAREST*
 TREE_LEAF = 32           # points per leaf box, leaf boxes per top box
 
 
-def build_point_tree(points32):
-    """(M, 3) float32 points -> flat float32 table for P_NEARTREE and the number of top boxes.
+def build_point_tree(points32, with_order=False):
+    """(M, 3) float32 points -> flat float32 table for P_NEARTREE and the number of top boxes
+    (with_order: also the index of the tree's first point and the original indices of the points in leaf order).
     k-d median splits along the longest axis down to leaves of <= TREE_LEAF points; consecutive leaves (spatially
     coherent in k-d order) are grouped TREE_LEAF at a time under one top box. Boxes are the exact float32 bounds
     of their points."""
@@ -250,6 +251,8 @@ def build_point_tree(points32):
         row[0:3], row[3:6], row[6], row[7] = boxes[:, 0:3].min(axis=0), boxes[:, 3:6].max(axis=0), leaf_base + 8 * first, last - first
     if table.size >= (1 << 24):
         raise ValueError("nearest-point table too large (indices are carried as fp32)")
+    if with_order:
+        return table, n_top, point_base, np.concatenate(leaves)
     return table, n_top
 
 

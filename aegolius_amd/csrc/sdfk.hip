@@ -212,10 +212,11 @@ static int table_rows_ok(const sdfk_program* p, int op, const float* P, std::str
         case SDFK_OP_P_NEAREST2: row = 2; break;
         case SDFK_OP_P_SHAPESIGN: row = 6; break;
         case SDFK_OP_CURVEINST: row = (P[2] != 0.0f) ? 12 : 3; break;
+        case SDFK_OP_CURVEINSTT:
         case SDFK_OP_P_NEARTREE: {
             // every index the kernel will follow stays inside the table; leaves are non-empty
             if (cnt < 1) return bad("point tree without top boxes");
-            if (P[2] != 2.0f && P[2] != 3.0f) return bad("point tree dimension must be 2 or 3");
+            if (op == SDFK_OP_P_NEARTREE && P[2] != 2.0f && P[2] != 3.0f) return bad("point tree dimension must be 2 or 3");
             if (off + 8 * cnt > nt) return bad("point tree: top boxes out of range");
             const float* t = p->tables.data() + off;
             const long long room = nt - off;
@@ -229,6 +230,13 @@ static int table_rows_ok(const sdfk_program* p, int op, const float* P, std::str
                     const long long pfirst = (long long)pf, pcount = (long long)pn;
                     if (!(pf >= 0.0f) || !(pn >= 1.0f) || (float)pfirst != pf || (float)pcount != pn || pfirst + 3 * pcount > room)
                         return bad("point tree: points out of range");
+                    if (op == SDFK_OP_CURVEINSTT) {
+                        // the instance row of every point the kernel can pick lies inside the table
+                        const long long base = (long long)P[4], rows = (long long)P[3], stride = (P[2] != 0.0f) ? 12 : 3;
+                        if (!(P[3] >= 0.0f) || !(P[4] >= 0.0f) || (float)base != P[4] || (float)rows != P[3] || pfirst < base ||
+                            (pfirst - base) % 3 != 0 || rows + ((pfirst - base) / 3 + pcount) * stride > nt)
+                            return bad("instancing tree: instance rows out of range");
+                    }
                 }
             }
             return 1;
@@ -255,6 +263,7 @@ static int table_rows_ok(const sdfk_program* p, int op, const float* P, std::str
 static bool is_table_op(int op) {
     return op == SDFK_OP_P_SEGLINE3 || op == SDFK_OP_P_NEAREST3 || op == SDFK_OP_P_SEGLINE2 ||
            op == SDFK_OP_P_NEAREST2 || op == SDFK_OP_CURVEINST || op == SDFK_OP_P_POLYSIGN || op == SDFK_OP_P_NEARTREE ||
+           op == SDFK_OP_CURVEINSTT ||
            op == SDFK_OP_P_SHAPESIGN;
 }
 

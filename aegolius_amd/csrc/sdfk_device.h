@@ -563,6 +563,65 @@ SDFK_DEV float prim_neartree(V3 p, const float* __restrict__ P, const float* __r
     return sd_sqrt(best);
 }
 
+// Nearest INSTANCE through the same tree (curve_instancing with more centres than a scan should visit): the tree's
+// points are the centres in leaf order, P[3] points at the instance rows (centre(3) [+ frame rows (9)]) in the same
+// order, P[4] is the index of the tree's first point, so (point index - P[4]) / 3 is the row. Ties go to the centre
+// visited first (the scan takes the lowest index; the reference's KD-tree query is as arbitrary on exact ties).
+SDFK_DEV void sd_scan_leaf_idx(V3 p, const float* __restrict__ tab, const float* __restrict__ leaf, float* best, int* at) {
+    const int first = (int)leaf[6];
+    const float* __restrict__ pt = tab + first;
+    const int n = (int)leaf[7];
+    for (int i = 0; i < n; ++i) {
+        float dx = p.x - pt[3 * i], dy = p.y - pt[3 * i + 1], dz = p.z - pt[3 * i + 2];
+        const float d2 = sd_fma(dx, dx, sd_fma(dy, dy, dz * dz));
+        if (d2 < *best) {
+            *best = d2;
+            *at = first + 3 * i;
+        }
+    }
+}
+SDFK_DEV V3 op_curveinstt(V3 p, const float* __restrict__ P, const float* __restrict__ T, int) {
+    const int n_top = (int)P[0];
+    const float* __restrict__ tab = T + (int)P[1];
+    int bt = 0;
+    float bd = 3.0e38f;
+    for (int t = 0; t < n_top; ++t) {
+        const float d = sd_boxdist2(p, tab + 8 * t);
+        if (d < bd) { bd = d; bt = t; }
+    }
+    const float* __restrict__ leaves0 = tab + (int)tab[8 * bt + 6];
+    int bl = 0;
+    bd = 3.0e38f;
+    for (int l = 0; l < (int)tab[8 * bt + 7]; ++l) {
+        const float d = sd_boxdist2(p, leaves0 + 8 * l);
+        if (d < bd) { bd = d; bl = l; }
+    }
+    float best = 3.0e38f;
+    int at = (int)P[4];
+    sd_scan_leaf_idx(p, tab, leaves0 + 8 * bl, &best, &at);
+    for (int t = 0; t < n_top; ++t) {
+        const float* __restrict__ tb = tab + 8 * t;
+        if (sd_boxdist2(p, tb) > best) continue;
+        const float* __restrict__ leaves = tab + (int)tb[6];
+        const int nl = (int)tb[7];
+        for (int l = 0; l < nl; ++l) {
+            const float* __restrict__ lf = leaves + 8 * l;
+            if ((t == bt && l == bl) || sd_boxdist2(p, lf) > best) continue;
+            sd_scan_leaf_idx(p, tab, lf, &best, &at);
+        }
+    }
+    const int row = (at - (int)P[4]) / 3;
+    const int stride = (P[2] != 0.0f) ? 12 : 3;
+    const float* __restrict__ c = T + (int)P[3] + row * stride;
+    V3 v = {p.x - c[0], p.y - c[1], p.z - c[2]};
+    if (P[2] != 0.0f) {
+        V3 w = {sd_dot3(c[3], c[4], c[5], v.x, v.y, v.z), sd_dot3(c[6], c[7], c[8], v.x, v.y, v.z),
+                sd_dot3(c[9], c[10], c[11], v.x, v.y, v.z)};
+        return w;
+    }
+    return v;
+}
+
 // ---- 2-D primitives (z ignored) -------------------------------------------------------------
 // sdf_circle C/sdf_2D.py:12-14
 template <typename T> SDFK_DEV T prim_circle(V3T<T> p, const float* __restrict__ P, const float* __restrict__) {
@@ -838,7 +897,7 @@ template <> SDFK_DEV f2 sdfk_aux<f2>(const float* __restrict__ AUX, long long AU
         return r;                                                                                          \
     }
 SDFK_PAIR_C_C(op_twist) SDFK_PAIR_C_C(op_bend) SDFK_PAIR_C_C(op_infrep) SDFK_PAIR_C_C(op_finrep)
-SDFK_PAIR_C_C(op_rotsym) SDFK_PAIR_C_C(op_lininst) SDFK_PAIR_C_C(op_curveinst)
+SDFK_PAIR_C_C(op_rotsym) SDFK_PAIR_C_C(op_lininst) SDFK_PAIR_C_C(op_curveinst) SDFK_PAIR_C_C(op_curveinstt)
 SDFK_PAIR_V_C(prim_braid) SDFK_PAIR_V_C(prim_arc3d) SDFK_PAIR_V_C(prim_segment3) SDFK_PAIR_V_C(prim_infcone)
 SDFK_PAIR_V_C(prim_solidangle) SDFK_PAIR_V_C(prim_triangle3) SDFK_PAIR_V_C(prim_quad3) SDFK_PAIR_V_C(prim_segline3)
 SDFK_PAIR_V_C(prim_nearest3) SDFK_PAIR_V_C(prim_neucircle) SDFK_PAIR_V_C(prim_segment2) SDFK_PAIR_V_C(prim_rbox2)

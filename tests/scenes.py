@@ -216,6 +216,11 @@ _mod_scene("aligned_curve_instancing", lambda ns: ns.Box(0.3, 0.1, 0.05),
            lambda o, ns: o.aligned_curve_instancing(ellipse3, (0.8, 0.5), (0.1, 6.0, 7)), True)
 _mod_scene("fully_aligned_curve_instancing", lambda ns: ns.Box(0.3, 0.1, 0.05),
            lambda o, ns: o.fully_aligned_curve_instancing(helix, (0.6, 0.15), (0.1, 6.0, 7)), True)
+# more instances than the scan threshold (256): nearest centre through the box tree
+_mod_scene("curve_instancing_many", lambda ns: ns.Sphere(0.02),
+           lambda o, ns: o.curve_instancing(helix, (0.7, 0.05), (0, 6 * np.pi, 333)), True)
+_mod_scene("fully_aligned_curve_instancing_many", lambda ns: ns.Box(0.05, 0.02, 0.01),
+           lambda o, ns: o.fully_aligned_curve_instancing(helix, (0.6, 0.08), (0.1, 18.0, 400)), True)
 _mod_scene("move_sdf", _box, lambda o, ns: o.move_sdf((0.2, -0.3, 0.1)))
 _mod_scene("scale_sdf", _box, lambda o, ns: o.scale_sdf(1.6))
 _mod_scene("rotate_sdf", _box, lambda o, ns: o.rotate_sdf(

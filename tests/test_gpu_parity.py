@@ -804,3 +804,25 @@ def test_apply_and_generic_geometry_variants(engine, golden_inputs):
     np.testing.assert_array_equal(g3.create(golden_inputs), want)
     g2 = ns.geom_2d.GenericGeometry2D(ns.sdf_circle, 0.5)
     np.testing.assert_array_equal(g2.propagate(golden_inputs, "ignored"), ns.Circle(0.5).create(golden_inputs))
+
+
+def test_instancing_tree_picks_the_same_instance_as_the_scan(engine, golden_inputs, monkeypatch):
+    """curve_instancing with more than 256 instances goes through the box tree; except on exact ties between two
+    centres it must land on the instance the scan finds, so the fields agree bit for bit almost everywhere."""
+    from aegolius_amd import _prims
+    for name in ("mod_curve_instancing_many", "mod_fully_aligned_curve_instancing_many"):
+        name = [k for k in scenes.SCENES if k.endswith(name[4:])][0]
+        low = lower_geometry(scenes.SCENES[name](ns))
+        assert any(_ops_name(w) == "CURVEINSTT" for w in low.code[:, 0])
+        tree = scenes.SCENES[name](ns).create(golden_inputs.copy())
+        monkeypatch.setattr(_prims, "TREE_THRESHOLD", 10 ** 9)
+        low_scan = lower_geometry(scenes.SCENES[name](ns))
+        assert any(_ops_name(w) == "CURVEINST" for w in low_scan.code[:, 0])
+        scan = scenes.SCENES[name](ns).create(golden_inputs.copy())
+        monkeypatch.undo()
+        assert np.count_nonzero(tree != scan) <= 2          # ties only (none expected on random points)
+
+
+def _ops_name(word):
+    from aegolius_amd import _ops
+    return _ops.OPS[int(word) & 255].name if hasattr(_ops, "OPS") else str(int(word) & 255)

@@ -38,6 +38,27 @@ def main(res=256, m=16384):
         out[label] = {"ms": ms, "mpoints_per_s": n / ms / 1e3}
     out["bit_identical"] = bool(np.array_equal(fields["box_tree"], fields["full_scan"]))
     out["speedup"] = out["full_scan"]["ms"] / out["box_tree"]["ms"]
+
+    # curve_instancing with 4,096 instances along a helix: nearest INSTANCE through the same tree
+    def helix(t, r, p):
+        return np.asarray((r * np.cos(t), r * np.sin(t), p * t))
+    inst = {}
+    for label, thr in (("box_tree", 256), ("full_scan", 1 << 30)):
+        _prims.TREE_THRESHOLD = thr
+        s = ns.Sphere(0.004)
+        s.fully_aligned_curve_instancing(helix, (0.7, 0.004), (-200.0, 200.0, 4096))
+        prog = _engine.Program.from_lowered(lower_geometry(s))
+        prog.eval_grid(axes, 0, n, d_out)
+        t0 = time.perf_counter()
+        prog.eval_grid(axes, 0, n, d_out)
+        ms = (time.perf_counter() - t0) * 1e3
+        host = np.empty(n, dtype=np.float32)
+        _engine.check(lib.sdfk_memcpy_d2h(_engine._ptr(host), _engine._vp(d_out), n * 4), "d2h")
+        inst[label] = host
+        out["instancing_4096_" + label] = {"ms": ms, "mpoints_per_s": n / ms / 1e3}
+    out["instancing_points_that_differ"] = int(np.count_nonzero(inst["box_tree"] != inst["full_scan"]))
+    out["instancing_speedup"] = out["instancing_4096_full_scan"]["ms"] / out["instancing_4096_box_tree"]["ms"]
+    _prims.TREE_THRESHOLD = 256
     lib.sdfk_free(_engine._vp(d_out))
     print(json.dumps(out, indent=1))
 
