@@ -231,11 +231,19 @@ static int table_rows_ok(const sdfk_program* p, int op, const float* P, std::str
                     if (!(pf >= 0.0f) || !(pn >= 1.0f) || (float)pfirst != pf || (float)pcount != pn || pfirst + 3 * pcount > room)
                         return bad("point tree: points out of range");
                     if (op == SDFK_OP_CURVEINSTT) {
-                        // the instance row of every point the kernel can pick lies inside the table
-                        const long long base = (long long)P[4], rows = (long long)P[3], stride = (P[2] != 0.0f) ? 12 : 3;
-                        if (!(P[3] >= 0.0f) || !(P[4] >= 0.0f) || (float)base != P[4] || (float)rows != P[3] || pfirst < base ||
-                            (pfirst - base) % 3 != 0 || rows + ((pfirst - base) / 3 + pcount) * stride > nt)
-                            return bad("instancing tree: instance rows out of range");
+                        // the original index of every point the kernel can pick is readable and names a row inside the table
+                        const long long base = (long long)P[4], rows = (long long)P[3], ids = (long long)P[5];
+                        const long long stride = (P[2] != 0.0f) ? 12 : 3;
+                        if (!(P[3] >= 0.0f) || !(P[4] >= 0.0f) || !(P[5] >= 0.0f) || (float)base != P[4] || (float)rows != P[3] ||
+                            (float)ids != P[5] || pfirst < base || (pfirst - base) % 3 != 0 ||
+                            ids + (pfirst - base) / 3 + pcount > nt)
+                            return bad("instancing tree: original indices out of range");
+                        for (long long q = 0; q < pcount; ++q) {
+                            const float of = p->tables[(size_t)(ids + (pfirst - base) / 3 + q)];
+                            const long long o = (long long)of;
+                            if (!(of >= 0.0f) || (float)o != of || rows + (o + 1) * stride > nt)
+                                return bad("instancing tree: instance row out of range");
+                        }
                     }
                 }
             }

@@ -564,25 +564,32 @@ SDFK_DEV float prim_neartree(V3 p, const float* __restrict__ P, const float* __r
 }
 
 // Nearest INSTANCE through the same tree (curve_instancing with more centres than a scan should visit): the tree's
-// points are the centres in leaf order, P[3] points at the instance rows (centre(3) [+ frame rows (9)]) in the same
-// order, P[4] is the index of the tree's first point, so (point index - P[4]) / 3 is the row. Ties go to the centre
-// visited first (the scan takes the lowest index; the reference's KD-tree query is as arbitrary on exact ties).
-SDFK_DEV void sd_scan_leaf_idx(V3 p, const float* __restrict__ tab, const float* __restrict__ leaf, float* best, int* at) {
+// points are the centres in leaf order; P[5] points at the ORIGINAL index of each of them (same order), P[4] is the
+// index of the tree's first point, P[3] the instance rows (centre(3) [+ frame rows (9)], original order). Among
+// centres at exactly the same fp32 distance the lowest original index wins — what the scan's strict `<` does — so the
+// chosen instance, and with it the field, is bit-identical to the scan's whatever the visiting order (with thousands
+// of centres along a curve such ties are common: neighbours differ by less than an ulp of d^2 near the foot point).
+SDFK_DEV void sd_scan_leaf_idx(V3 p, const float* __restrict__ tab, const float* __restrict__ leaf,
+                               const float* __restrict__ orig, int point_base, float* best, int* who) {
     const int first = (int)leaf[6];
     const float* __restrict__ pt = tab + first;
+    const float* __restrict__ id = orig + (first - point_base) / 3;
     const int n = (int)leaf[7];
     for (int i = 0; i < n; ++i) {
         float dx = p.x - pt[3 * i], dy = p.y - pt[3 * i + 1], dz = p.z - pt[3 * i + 2];
         const float d2 = sd_fma(dx, dx, sd_fma(dy, dy, dz * dz));
-        if (d2 < *best) {
+        const int o = (int)id[i];
+        if (d2 < *best || (d2 == *best && o < *who)) {
             *best = d2;
-            *at = first + 3 * i;
+            *who = o;
         }
     }
 }
 SDFK_DEV V3 op_curveinstt(V3 p, const float* __restrict__ P, const float* __restrict__ T, int) {
     const int n_top = (int)P[0];
     const float* __restrict__ tab = T + (int)P[1];
+    const float* __restrict__ orig = T + (int)P[5];
+    const int point_base = (int)P[4];
     int bt = 0;
     float bd = 3.0e38f;
     for (int t = 0; t < n_top; ++t) {
@@ -597,22 +604,21 @@ SDFK_DEV V3 op_curveinstt(V3 p, const float* __restrict__ P, const float* __rest
         if (d < bd) { bd = d; bl = l; }
     }
     float best = 3.0e38f;
-    int at = (int)P[4];
-    sd_scan_leaf_idx(p, tab, leaves0 + 8 * bl, &best, &at);
+    int who = 0x7fffffff;
+    sd_scan_leaf_idx(p, tab, leaves0 + 8 * bl, orig, point_base, &best, &who);
     for (int t = 0; t < n_top; ++t) {
         const float* __restrict__ tb = tab + 8 * t;
-        if (sd_boxdist2(p, tb) > best) continue;
+        if (sd_boxdist2(p, tb) > best) continue;              // a box AT the best distance is still visited (ties)
         const float* __restrict__ leaves = tab + (int)tb[6];
         const int nl = (int)tb[7];
         for (int l = 0; l < nl; ++l) {
             const float* __restrict__ lf = leaves + 8 * l;
             if ((t == bt && l == bl) || sd_boxdist2(p, lf) > best) continue;
-            sd_scan_leaf_idx(p, tab, lf, &best, &at);
+            sd_scan_leaf_idx(p, tab, lf, orig, point_base, &best, &who);
         }
     }
-    const int row = (at - (int)P[4]) / 3;
     const int stride = (P[2] != 0.0f) ? 12 : 3;
-    const float* __restrict__ c = T + (int)P[3] + row * stride;
+    const float* __restrict__ c = T + (int)P[3] + who * stride;
     V3 v = {p.x - c[0], p.y - c[1], p.z - c[2]};
     if (P[2] != 0.0f) {
         V3 w = {sd_dot3(c[3], c[4], c[5], v.x, v.y, v.z), sd_dot3(c[6], c[7], c[8], v.x, v.y, v.z),
