@@ -270,7 +270,23 @@ def main():
             def gradient():
                 _engine.check(lib.sdfk_field_gradient(vp(out.data_ptr()), dims[0], dims[1], dims[2], 2 if flat else 3, 1,
                                                       vp(vec.data_ptr()), stride, vp(stream)), "sdfk_field_gradient")
-            sel_ms, grad_ms = best_ms(select), best_ms(gradient)
+            # a vector-field chain (§8(f).4) on the run's coordinates with the run's field as the per-point angle:
+            # radial-cylindrical field, turned about z by the SDF value, revolved about x, normalised (28 B/point)
+            import aegolius_amd.cores as ns_cores
+            from aegolius_amd import _vector
+            tiny = np.zeros((3, 8))
+            vf = ns_cores.RadialCylindricalVectorField()
+            vf.rotate_phi(np.zeros(8))
+            vf.revolution_x(tiny)
+            vf.normalize()
+            vprog = _vector.program_array(_vector.lower_only(vf.vf, tiny, ())[0])
+
+            def chain():
+                _engine.check(lib.sdfk_vec_eval_device(vprog, len(vprog), vp(co.data_ptr()), count, stride, vp(out.data_ptr()), 1,
+                                                       stride, 0, vp(vec.data_ptr()), stride, vp(stream)), "sdfk_vec_eval_device")
+            chain()                                               # builds the kernel of this chain shape: not timed
+            torch.cuda.synchronize()
+            sel_ms, grad_ms, chain_ms = best_ms(select), best_ms(gradient), best_ms(chain)
             sel_bytes = 4.0 * count + 8.0 * selected.value
             next_rows = {
                 "interior_selection": {"ms": sel_ms, "selected": selected.value, "bytes": sel_bytes,
@@ -278,7 +294,10 @@ def main():
                 "gradient_direction": {"ms": grad_ms, "bytes": (12.0 if flat else 16.0) * count,
                                        "frac_of_hbm_peak": (12.0 if flat else 16.0) * count / (grad_ms * 1e-3) / 1e9
                                        / HBM_PEAK_GBPS},
-                "note": "sdfk_field_select (+ _finish) and sdfk_field_gradient on the resident field of this run"}
+                "vector_chain": {"ms": chain_ms, "bytes": 28.0 * count,
+                                 "frac_of_hbm_peak": 28.0 * count / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                "note": "sdfk_field_select (+ _finish), sdfk_field_gradient and a 4-instruction vector-field chain "
+                        "(sdfk_vec_eval_device) on the resident coordinates / field of this run"}
             del scratch, index, vec
         except Exception as exc:  # noqa: BLE001
             next_rows = {"error": repr(exc)}
