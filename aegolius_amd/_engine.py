@@ -3,6 +3,7 @@
 This is the only place the Python layer touches native code. There is no CPU fallback: if the
 shared library is missing or no MI355X is visible, evaluation raises.
 """
+import atexit
 import ctypes
 import importlib.util
 import os
@@ -15,6 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsdfk.so")
 
 MODE_AUTO, MODE_INTERPRET, MODE_SPECIALIZED, MODE_NOCULL = 0, 1, 2, 3
+(FLAVOUR_PLAIN_ARRAY, FLAVOUR_PLAIN_GRID, FLAVOUR_TILE_ARRAY, FLAVOUR_TILE_GRID, FLAVOUR_TILE_MASK, FLAVOUR_ROWS_ARRAY,
+ FLAVOUR_ROWS_GRID, FLAVOUR_ROWS_MASK) = range(8)
 
 _c = ctypes
 _vp, _i64, _int, _sz = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t
@@ -31,6 +34,10 @@ SIGNATURES = {
     "sdfk_program_set_cull": (_int, [_vp, _vp, _sz, _vp]),
     "sdfk_program_source": (_c.c_char_p, [_vp]),
     "sdfk_program_compile_check": (_int, [_vp, _c.POINTER(_sz)]),
+    "sdfk_program_compile_flavour": (_int, [_vp, _int, _c.POINTER(_sz), _c.POINTER(_c.c_double)]),
+    "sdfk_debug_jit_stats": (None, [_c.POINTER(_i64), _c.POINTER(_c.c_double)]),
+    "sdfk_jit_drain": (None, []),
+    "sdfk_debug_set_rtc_defs": (None, [_c.c_char_p]),
     "sdfk_eval_device": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _int]),
     "sdfk_eval_device_rows": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int]),
     "sdfk_debug_row_masks": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _c.POINTER(_i64), _c.POINTER(_int), _vp]),
@@ -122,6 +129,8 @@ def lib():
                     fn.restype, fn.argtypes = res, args
                 if handle.sdfk_abi_version() != 1:
                     raise SdfkError("libsdfk.so ABI version mismatch")
+                # background kernel builds finish before the interpreter (and with it torch's HIP runtime) shuts down
+                atexit.register(handle.sdfk_jit_drain)
                 _lib = handle
     return _lib
 
@@ -144,6 +153,13 @@ def require_gpu():
     if device_count() < 1:
         raise SdfkError("aegolius_amd: no HIP device visible - SDF evaluation runs on an MI355X only "
                         "(there is no CPU path)")
+
+
+def jit_stats():
+    """(hiprtc builds this process has run — cache hits excluded —, seconds they took)."""
+    n, t = _i64(0), _c.c_double(0.0)
+    lib().sdfk_debug_jit_stats(ctypes.byref(n), ctypes.byref(t))
+    return n.value, t.value
 
 
 def _ptr(a):
@@ -191,6 +207,13 @@ class Program:
         n = _sz(0)
         check(lib().sdfk_program_compile_check(self._h, ctypes.byref(n)), "sdfk_program_compile_check")
         return n.value
+
+    def compile_flavour(self, flavour):
+        """Build (or fetch) one kernel flavour (FLAVOUR_*), GPU or not -> (code-object bytes, seconds)."""
+        n, t = _sz(0), _c.c_double(0.0)
+        check(lib().sdfk_program_compile_flavour(self._h, int(flavour), ctypes.byref(n), ctypes.byref(t)),
+              "sdfk_program_compile_flavour")
+        return n.value, t.value
 
     def eval_host(self, co, device=0, mode=MODE_AUTO):
         """co: (3, N) float32/float64 host array -> (N,) float32 field."""

@@ -97,6 +97,111 @@ def _evaluate(lower, co, root=None, resident=False):
 
 
 # ---------------------------------------------------------------------------------------------------
+# pointwise operations on given fields (no tree): the array-level functions of cores/post_processing.py, cores/combine.py
+# ---------------------------------------------------------------------------------------------------
+def apply_fields(fields, emit):
+    """`fields`: 1..32 scalar fields of the same size (ndarrays of any shape, or _engine.DeviceField); `emit(L, regs)`
+    emits value instructions on a fresh Lowerer (regs[k] holds field k) and returns the result register. The fields
+    enter as auxiliary rows read by V_FIELD instructions, so the arithmetic is that of the same device functions
+    (csrc/sdfk_device.h val_* / cmb_*) a tree would run. Returns an ndarray shaped like the first ndarray field, or a
+    DeviceField when every field is one."""
+    from ._lower import Lowerer
+    _engine.require_gpu()
+    lib = _engine.lib()
+    resident = all(isinstance(f, _engine.DeviceField) for f in fields)
+    shape, host, n = None, [], None
+    for f in fields:
+        if isinstance(f, _engine.DeviceField):
+            host.append(None)
+            n_f = f.n
+        else:
+            arr = np.asarray(f)
+            if shape is None:
+                shape = arr.shape
+            host.append(np.ascontiguousarray(arr, dtype=np.float32).ravel())
+            n_f = host[-1].size
+        if n is not None and n_f != n:
+            raise ValueError("operands could not be broadcast together: %d and %d values" % (n, n_f))
+        n = n_f
+    L = Lowerer()
+    regs = []
+    for k in range(len(fields)):
+        v = L.new_v()
+        L.emit("V_FIELD", v, 0, k)
+        regs.append(v)
+    lowered = L.finish(emit(L, regs))
+    if n == 0:
+        return np.empty(shape or (0,), dtype=config.output_dtype)
+    device = fields[0].device if resident else config.device
+    _engine.check(lib.sdfk_set_device(device), "sdfk_set_device")
+    vp = _engine._vp
+    stride = (n + 63) // 64 * 64
+    rows = max(len(fields), 3)                       # the rows double as the (never read) coordinate array
+    d_aux = lib.sdfk_malloc(rows * stride * 4)
+    out = _engine.DeviceField(n, device)
+    if not d_aux:
+        raise _engine.SdfkError("apply_fields: out of device memory")
+    try:
+        for k, f in enumerate(fields):
+            row = d_aux + 4 * k * stride
+            if host[k] is None:
+                f._live()
+                _engine.check(lib.sdfk_memcpy_d2d(vp(row), vp(f.ptr), n * 4), "d2d")
+            else:
+                _engine.check(lib.sdfk_memcpy_h2d(vp(row), _engine._ptr(host[k]), n * 4), "h2d")
+        _engine.check(lib.sdfk_eval_device_aux(program_for(lowered).handle, vp(d_aux), n, stride, vp(d_aux), len(fields), stride,
+                                               vp(out.ptr), None, config.mode), "sdfk_eval_device_aux")
+        _engine.check(lib.sdfk_sync(None), "sdfk_sync")
+    finally:
+        lib.sdfk_free(vp(d_aux))
+    if resident:
+        return out
+    res = out.numpy()
+    out.free()
+    if config.output_dtype is not np.float32:
+        res = res.astype(config.output_dtype)
+    return res.reshape(shape)
+
+
+def apply_value_op(name, u, args):
+    """One of the value operations of _mods.VALUE_OPS (the post-processing wrappers of the reference) on a field."""
+    from ._mods import VALUE_OPS
+    opname, prm = VALUE_OPS[name]
+
+    def emit(L, regs):
+        L.emit(opname, regs[0], regs[0], params=prm(args))
+        return regs[0]
+    return apply_fields([u], emit)
+
+
+def apply_grid_op(name, u, args):
+    """conv_averaging / conv_edge_detection on a GRID-shaped field (2-D or 3-D array), on the device."""
+    from ._ir import ModSDF
+    _engine.require_gpu()
+    lib = _engine.lib()
+    arr = np.asarray(u)
+    if arr.ndim not in (2, 3):
+        raise ValueError("the field must be a 2-D or 3-D grid; got shape %r" % (arr.shape,))
+    n = arr.size
+    field = _engine.DeviceField.from_host(arr, config.device)
+    d_scratch = lib.sdfk_malloc(max(n, 1) * 4)
+    try:
+        if not d_scratch:
+            raise _engine.SdfkError("out of device memory")
+        node = ModSDF(name, dict(args, co_resolution=arr.shape), None)
+        _apply_grid_op(lib, node, None, field.ptr, n, None, None, None, d_scratch, shape=arr.shape)
+        _engine.check(lib.sdfk_sync(None), "sdfk_sync")
+        out = field.numpy()
+    finally:
+        if d_scratch:
+            lib.sdfk_free(_engine._vp(d_scratch))
+        field.free()
+    if config.output_dtype is not np.float32:
+        out = out.astype(config.output_dtype)
+    return out.reshape(arr.shape)
+
+
+# ---------------------------------------------------------------------------------------------------
 # staged evaluation: trees with grid-neighbourhood operators (signed, conv_averaging, conv_edge_detection)
 # ---------------------------------------------------------------------------------------------------
 def _grid_shape(n, resolution):

@@ -9,6 +9,9 @@ these objects around as functions (e.g. `obj.sign(direct=True)` into `recover_vo
 """
 
 
+import inspect
+
+
 class SDFExpr:
     """Callable stand-in for one reference closure."""
 
@@ -18,13 +21,33 @@ class SDFExpr:
 
 
 class PrimSDF(SDFExpr):
-    """One of the reference's `sdf_*` functions (cores/sdf_3D.py, cores/sdf_2D.py)."""
+    """One of the reference's `sdf_*` functions (cores/sdf_3D.py, cores/sdf_2D.py). `arg_names` are the reference's
+    parameter names after `co` (sdf_sphere(co, radius), sdf_box(co, size) ...): the object reports that signature
+    (inspect.signature) and takes the arguments by position or by keyword, like the reference's function."""
 
-    def __init__(self, name, lower, doc=""):
+    def __init__(self, name, lower, doc="", arg_names=None):
         self.name = name
         self.lower = lower  # lower(L, vdst, creg, args)
-        self.__name__ = name
+        self.__name__ = self.__qualname__ = name
         self.__doc__ = doc
+        if arg_names is not None:
+            kind = inspect.Parameter.POSITIONAL_OR_KEYWORD
+            self.__signature__ = inspect.Signature([inspect.Parameter(n, kind) for n in ("co",) + tuple(arg_names)])
+
+    def __call__(self, *args, **kwargs):
+        sig = getattr(self, "__signature__", None)
+        if sig is None:
+            if kwargs:
+                raise TypeError("%s() takes no keyword arguments" % self.name)
+            co, params = args[0], args[1:]
+        else:
+            try:
+                bound = sig.bind(*args, **kwargs)
+            except TypeError as exc:
+                raise TypeError("%s() %s" % (self.name, exc)) from None
+            co, params = bound.args[0], bound.args[1:]
+        from ._eval import evaluate_expr
+        return evaluate_expr(self, co, params)
 
     def __repr__(self):
         return "<sdf primitive %s>" % self.name

@@ -356,28 +356,33 @@ def _(L, e, creg, mode, params):
 # ------------------------------------------------------------------------------------------------
 # value-only
 # ------------------------------------------------------------------------------------------------
-def _simple_value(opname, prm_fn):
+VALUE_OPS = {}      # modification name -> (opcode, arguments -> parameter block): also the array-level functions of
+                    # cores/post_processing.py run through these (aegolius_amd._eval.apply_fields)
+
+
+def _simple_value(opname, prm_fn, name=None):
+    if name is not None:
+        VALUE_OPS[name] = (opname, prm_fn)
+
     def fn(L, e, creg, mode, params):
         return _value_mod(L, e, creg, mode, params, opname, prm_fn(e.args))
     return fn
 
 
-MOD_LOWER["rounding"] = _simple_value("VSUBC", lambda a: [a["rounding_radius"]])            # :100-118
-MOD_LOWER["boundary"] = _simple_value("VABS", lambda a: [])                                  # :146-161
-MOD_LOWER["invert"] = _simple_value("VNEG", lambda a: [])                                    # :277-299
-MOD_LOWER["sign"] = _simple_value("VSIGN", lambda a: [])                                     # :301-323
-MOD_LOWER["onion"] = _simple_value("VONION", lambda a: [a["thickness"]])                     # :371-388
-MOD_LOWER["concentric"] = _simple_value("VCONCENTRIC", lambda a: [a["width"] / 2])           # :390-409
+MOD_LOWER["rounding"] = _simple_value("VSUBC", lambda a: [a["rounding_radius"]], name="rounding")            # :100-118
+MOD_LOWER["boundary"] = _simple_value("VABS", lambda a: [], name="boundary")                                  # :146-161
+MOD_LOWER["invert"] = _simple_value("VNEG", lambda a: [], name="invert")                                    # :277-299
+MOD_LOWER["sign"] = _simple_value("VSIGN", lambda a: [], name="sign")                                     # :301-323
+MOD_LOWER["onion"] = _simple_value("VONION", lambda a: [a["thickness"]], name="onion")                     # :371-388
+MOD_LOWER["concentric"] = _simple_value("VCONCENTRIC", lambda a: [a["width"] / 2], name="concentric")           # :390-409
 # post-processing wrappers :1361-1587 -> reference cores/post_processing.py:380-558
-MOD_LOWER["sigmoid_falloff"] = _simple_value("VSIGMOID", lambda a: [a["amplitude"], 4 * _inv(a["width"]), 0.0])
-MOD_LOWER["positive_sigmoid_falloff"] = _simple_value(
-    "VSIGMOID", lambda a: [a["amplitude"], 4 * _inv(a["width"]), a["width"]])
-MOD_LOWER["capped_exponential"] = _simple_value("VCAPEXP", lambda a: [a["amplitude"], -4 * _inv(a["width"])])
-MOD_LOWER["hard_binarization"] = _simple_value("VHARDBIN", lambda a: [a["threshold"]])
-MOD_LOWER["linear_falloff"] = _simple_value("VLINFALL", lambda a: [a["amplitude"], _inv(a["width"])])
-MOD_LOWER["relu"] = _simple_value("VRELU", lambda a: [_inv(a["width"])])
-MOD_LOWER["smooth_relu"] = _simple_value(
-    "VSMOOTHRELU", lambda a: [_inv(a["width"]), (a["smooth_width"] + a["threshold"]) * 4 * a["threshold"]])
+MOD_LOWER["sigmoid_falloff"] = _simple_value("VSIGMOID", lambda a: [a["amplitude"], 4 * _inv(a["width"]), 0.0], name="sigmoid_falloff")
+MOD_LOWER["positive_sigmoid_falloff"] = _simple_value("VSIGMOID", lambda a: [a["amplitude"], 4 * _inv(a["width"]), a["width"]], name="positive_sigmoid_falloff")
+MOD_LOWER["capped_exponential"] = _simple_value("VCAPEXP", lambda a: [a["amplitude"], -4 * _inv(a["width"])], name="capped_exponential")
+MOD_LOWER["hard_binarization"] = _simple_value("VHARDBIN", lambda a: [a["threshold"]], name="hard_binarization")
+MOD_LOWER["linear_falloff"] = _simple_value("VLINFALL", lambda a: [a["amplitude"], _inv(a["width"])], name="linear_falloff")
+MOD_LOWER["relu"] = _simple_value("VRELU", lambda a: [_inv(a["width"])], name="relu")
+MOD_LOWER["smooth_relu"] = _simple_value("VSMOOTHRELU", lambda a: [_inv(a["width"]), (a["smooth_width"] + a["threshold"]) * 4 * a["threshold"]], name="smooth_relu")
 
 
 def _slowstart_params(a):
@@ -386,9 +391,9 @@ def _slowstart_params(a):
     return [_inv(a["width"]), bw, np.sqrt(bw) * a["ground"]]
 
 
-MOD_LOWER["slowstart"] = _simple_value("VSLOWSTART", _slowstart_params)
-MOD_LOWER["gaussian_boundary"] = _simple_value("VGAUSS", lambda a: [a["amplitude"], _inv(a["width"]), 0.0])
-MOD_LOWER["gaussian_falloff"] = _simple_value("VGAUSS", lambda a: [a["amplitude"], _inv(a["width"]), 1.0])
+MOD_LOWER["slowstart"] = _simple_value("VSLOWSTART", _slowstart_params, name="slowstart")
+MOD_LOWER["gaussian_boundary"] = _simple_value("VGAUSS", lambda a: [a["amplitude"], _inv(a["width"]), 0.0], name="gaussian_boundary")
+MOD_LOWER["gaussian_falloff"] = _simple_value("VGAUSS", lambda a: [a["amplitude"], _inv(a["width"]), 1.0], name="gaussian_falloff")
 
 
 # ------------------------------------------------------------------------------------------------

@@ -11,10 +11,53 @@ from ._ir import PrimSDF
 
 _REG = {}
 
+# parameter names after `co`, as the reference spells them (cores/sdf_3D.py:13-286, cores/sdf_2D.py:12-224): the
+# primitives report these signatures and take keyword arguments like the reference's functions
+ARG_NAMES = {
+    "sdf_x": ('offset',),
+    "sdf_y": ('offset',),
+    "sdf_z": ('offset',),
+    "sdf_sphere": ('radius',),
+    "sdf_cylinder": ('radius', 'height'),
+    "sdf_box": ('size',),
+    "sdf_torus": ('R', 'r'),
+    "sdf_chainlink": ('R', 'r', 'length'),
+    "sdf_braid": ('length', 'R', 'r', 'pitch'),
+    "sdf_arc_3d": ('R', 'r', 'start_angle', 'end_angle'),
+    "sdf_plane": ('normal', 'offset'),
+    "sudf_plane": ('normal', 'thickness'),
+    "sdf_segment_3d": ('a', 'b'),
+    "sdf_cone": ('height', 'angle'),
+    "sdf_oriented_infinite_cone": ('angle',),
+    "sdf_infinite_cone": ('angle',),
+    "sdf_solid_angle": ('radius', 'angle_1', 'angle_2'),
+    "sdf_triangle_3d": ('a', 'b', 'c'),
+    "sdf_quad_3d": ('a', 'b', 'c', 'd'),
+    "sdf_segmented_curve_3d": ('points', 't'),
+    "sdf_segmented_line_3d": ('points',),
+    "sdf_parametric_curve_3d": ('f', 'f_parameters', 't'),
+    "sdf_point_cloud_3d": ('points',),
+    "sdf_circle": ('radius',),
+    "sdf_neu_circle": ('radius', 'norm'),
+    "sdf_box_2d": ('size',),
+    "sdf_segment_2d": ('a', 'b'),
+    "sdf_rounded_box_2d": ('size', 'rounding'),
+    "sdf_triangle_2d": ('p0', 'p1', 'p2'),
+    "sdf_arc": ('radius', 'start_angle', 'end_angle'),
+    "sdf_sector": ('radius', 'angle_1', 'angle_2'),
+    "sdf_inf_sector": ('angle_1', 'angle_2'),
+    "sdf_ngon": ('radius', 'n'),
+    "sdf_segmented_curve_2d": ('points', 't'),
+    "sdf_segmented_line_2d": ('points',),
+    "sdf_polygon_2d": ('points',),
+    "sdf_parametric_curve_2d": ('f', 'f_parameters', 't'),
+    "sdf_point_cloud_2d": ('points',),
+}
+
 
 def _prim(name, doc=""):
     def deco(fn):
-        _REG[name] = PrimSDF(name, fn, doc)
+        _REG[name] = PrimSDF(name, fn, doc, ARG_NAMES.get(name))
         return fn
     return deco
 

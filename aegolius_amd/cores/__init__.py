@@ -1,10 +1,23 @@
 """Same flat namespace as the reference's `spomso.cores` (reference cores/__init__.py:7-48) for the
 scalar-field path: `from aegolius_amd.cores import Sphere, CombineGeometry, generate_grid ...`."""
+from . import post_processing
+from . import triangulation_functions
 from .combine import CombineGeometry
+from .combine import smoothmin_poly2, smoothmin_poly3, smoothmax_boltz
 from .transformations import EuclideanTransform
 from .modifications import ModifyObject
 from .geom import GenericGeometry, VectorField
 from .modifications import ModifyVectorObject
+
+from .post_processing import sigmoid_falloff, positive_sigmoid_falloff, capped_exponential
+from .post_processing import hard_binarization, linear_falloff
+from .post_processing import relu, smooth_relu, slowstart
+from .post_processing import gaussian_boundary, gaussian_falloff
+from .post_processing import conv_averaging, conv_edge_detection
+from .post_processing import custom_post_process
+
+from .triangulation_functions import check_convex, check_convex_all, is_inside_triangle, is_ear, triangulate
+from .triangulation_functions import interior_triangle, interior_convex, interior_polygon
 
 from .helper_functions import resolution_conversion, generate_grid, smarter_reshape
 from .helper_functions import vector_smarter_reshape, nd_vector_smarter_reshape

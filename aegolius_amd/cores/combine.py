@@ -7,6 +7,35 @@ The arithmetic is in csrc/sdfk_device.h (cmb_*).
 from .._ir import CombineSDF
 from .geom import GenericGeometry
 
+
+# ---- the smooth kernels on plain arrays (reference cores/combine.py:12-34) -----------------------------------------
+def _pair(opname, x, y, prm):
+    from .. import _eval
+
+    def emit(L, regs):
+        L.emit(opname, regs[0], regs[0], regs[1], params=prm)
+        return regs[0]
+    return _eval.apply_fields([x, y], emit)
+
+
+def smoothmin_poly2(x, y, a):
+    """min(x, y) - h^2 a / 4 with h = max(a - |x - y|, 0) / a; a == 0: min(x, y) (:12-18). On the GPU (cmb_smin2)."""
+    a = float(a)
+    return _pair("VMIN", x, y, []) if a == 0 else _pair("SMIN2", x, y, [a, 1.0 / (4.0 * a)])
+
+
+def smoothmin_poly3(x, y, a):
+    """min(x, y) - h^3 a / 6; a == 0: min(x, y) (:20-26). On the GPU (cmb_smin3)."""
+    a = float(a)
+    return _pair("VMIN", x, y, []) if a == 0 else _pair("SMIN3", x, y, [a, 1.0 / (6.0 * a * a)])
+
+
+def smoothmax_boltz(x, y, a):
+    """Boltzmann-weighted mean (x e^{x/a} + y e^{y/a}) / (e^{x/a} + e^{y/a}) (:29-34), evaluated in the overflow-free
+    form. On the GPU (cmb_boltz)."""
+    a = float(a)
+    return _pair("BOLTZ", x, y, [1.0 / a if a != 0 else float("inf")])
+
 # operation name -> opcode of the folding instruction
 NARY_OPS = {"UNION": "VMIN", "INTERSECT": "VMAX"}                                  # np.amin / np.amax over all
 BINARY_OPS = {"UNION2": "VMIN", "SUBTRACT2": "VSUBTRACT", "INTERSECT2": "VMAX", "SUM": "VADD",

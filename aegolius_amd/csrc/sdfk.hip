@@ -14,16 +14,22 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <chrono>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <thread>
 #include <string>
 #include <vector>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include "../../include/sdfk.h"
@@ -156,11 +162,23 @@ struct DevState {
     unsigned long long params_version = 0;
 };
 
-struct SpecKernel {
+// One hiprtc translation unit = (program topology, kernel flavour, build options). The code object is built once
+// per PROCESS — by whichever thread asks first, outside every global lock — and shared by all devices; a device
+// only loads it (hipModuleLoadData). state: 0 idle, 1 building, 2 ready, 3 failed.
+struct CodeObject {
+    std::mutex mu;
+    std::condition_variable cv;
+    int state = 0;
+    std::vector<char> co;
+    std::string error;
+    double build_seconds = 0.0;
+    std::chrono::steady_clock::time_point failed_at;
+};
+struct SpecModule {                   // a code object loaded on one device
+    std::mutex mu;
+    bool loaded = false, failed = false;
     hipModule_t mod = nullptr;
-    hipFunction_t v4 = nullptr, v1 = nullptr, g4 = nullptr, g1 = nullptr, tile = nullptr, tile_grid = nullptr, tmask = nullptr, rows = nullptr,
-                  rows_grid = nullptr, rmask = nullptr;
-    bool failed = false;
+    hipFunction_t fn[2] = {nullptr, nullptr};
     std::string error;
 };
 
@@ -178,8 +196,9 @@ struct sdfk_program {
     std::map<int, DevState> dev;
 };
 
-static std::mutex g_spec_mu;
-static std::map<std::pair<int, std::string>, std::shared_ptr<SpecKernel>> g_spec;
+static std::mutex g_code_mu;                                    // guards the two maps only, never a build
+static std::map<std::string, std::shared_ptr<CodeObject>> g_code;
+static std::map<std::pair<int, std::string>, std::shared_ptr<SpecModule>> g_mods;
 
 extern "C" int sdfk_abi_version(void) { return SDFK_ABI_VERSION; }
 
@@ -202,7 +221,9 @@ static int table_rows_ok(const sdfk_program* p, int op, const float* P, std::str
         return 0;
     };
     long long cnt = (long long)P[0], off = (long long)P[1];
-    if (!(P[0] >= 0.0f) || !(P[1] >= 0.0f) || (float)cnt != P[0] || (float)off != P[1]) return bad("table count/offset not integral");
+    if (op == SDFK_OP_P_POLYSIGN && P[0] == -1.0f) cnt = 1;      // one piece, raw side value (interior_convex)
+    else if (!(P[0] >= 0.0f) || (float)cnt != P[0]) return bad("table count/offset not integral");
+    if (!(P[1] >= 0.0f) || (float)off != P[1]) return bad("table count/offset not integral");
     long long nt = (long long)p->tables.size();
     long long row = 0;
     switch (op) {
@@ -477,40 +498,34 @@ extern "C" const char* sdfk_program_source(sdfk_program* p) {
     std::lock_guard<std::mutex> lk(p->mu);
     if (p->source.empty())
         p->source = sdfk_generate_source(g_ops, SDFK_OP_COUNT, p->code.data(), p->code.size() / 2, p->result_reg,
-                                         p->sites);
+                                         p->sites, SDFK_FL_ALL);
     return p->source.c_str();
 }
 
 // tile geometry of the brick-culling kernel: SDFK_TWAVES waves x SDFK_WBRICKS bricks of 128 points per
 // workgroup (overridable through the environment for experiments)
+// (experiments: "-DSDFK_TWAVES=n" / "-DSDFK_RWBRICKS=n" inside the extra build switches override the launch geometry)
+static std::atomic<int> g_twaves_override{0}, g_rwbricks_override{0};
 static int tile_waves() {
     static int v = [] { const char* e = getenv("SDFK_TWAVES"); int t = e ? atoi(e) : 4; return (t >= 1 && t <= 16) ? t : 4; }();
-    return v;
+    const int o = g_twaves_override.load();
+    return o ? o : v;
 }
 static int tile_wbricks() {
     static int v = [] {
         const char* e = getenv("SDFK_WBRICKS");
         int t = e ? atoi(e) : 4;
         if (t < 1 || t > 32) t = 4;
-        if (t > 32) t = 32;   // one probe lane per run: 2 * waves * bricks <= 64 * waves
         return t;
     }();
     return v;
 }
 static int tile_points() { return tile_waves() * tile_wbricks() * 128; }
-// row-block kernel: SDFK_NP packed pairs per lane (brick = 32 points x 4*NP rows), SDFK_RWBRICKS bricks per wave
-static int rows_np() {
-    static int v = [] { const char* e = getenv("SDFK_NP"); int t = e ? atoi(e) : 4; return (t == 2 || t == 4) ? t : 4; }();
-    return v;
-}
-static int rows_tiles() {   // tiles per workgroup of the row-block kernel
-    static int v = [] { const char* e = getenv("SDFK_RTILES"); int t = e ? atoi(e) : 1; return (t >= 1 && t <= 64) ? t : 1; }();
-    return v;
-}
 // bricks per wave of the row-block kernel: 2 — except for big trees (> 150 instructions, e.g. the 50-primitive 2-D
 // union), whose whole-tree probe is better shared by 16 bricks per workgroup than by 8 (measured -11 %)
 static int rows_wbricks(const sdfk_program* p) {
     static int forced = [] { const char* e = getenv("SDFK_RWBRICKS"); int t = e ? atoi(e) : 0; return (t >= 1 && t <= 16) ? t : 0; }();
+    if (const int o = g_rwbricks_override.load()) return o;
     if (forced) return forced;
     return (p && p->code.size() / 2 > 150) ? 4 : 2;
 }
@@ -523,7 +538,7 @@ struct RowGeom {           // mirrors sdfk_rowgeom of the generated source
 // can the row-block kernel take n points in rows of row_len? (brick ids are 32-bit)
 static bool rows_geometry(long long n, long long row_len, RowGeom* g) {
     if (row_len < 32 || row_len > 0x7fffffffLL || n <= 0 || n % row_len != 0) return false;
-    const long long R = n / row_len, brows = 4 * rows_np();
+    const long long R = n / row_len, brows = 16;
     // windows of 32 points aligned in the flat array: one more than ceil(L / 32) can overlap a row
     const long long nchunk = (row_len % 32 == 0) ? row_len / 32 : (row_len + 62) / 32;
     const long long nb = nchunk * ((R + brows - 1) / brows);
@@ -537,12 +552,32 @@ static bool rows_geometry(long long n, long long row_len, RowGeom* g) {
     return true;
 }
 static int tile_threads() { return 64 * tile_waves(); }
-// Optional on-disk cache of hiprtc code objects (opt-in: SDFK_CACHE_DIR=<directory>): a new process then loads the
-// kernels of tree / chain shapes it has seen before instead of compiling them (≈ 0.3 s per primitive). The file name
-// is a 64-bit FNV-1a hash of the source, the options and the hiprtc version, plus the source length.
+// On-disk cache of hiprtc code objects, ON by default: a new process loads the kernels of tree / chain shapes it has
+// seen before instead of compiling them. Directory: $SDFK_CACHE_DIR, else $XDG_CACHE_HOME/sdfk, else $HOME/.cache/sdfk;
+// SDFK_CACHE_DIR= (empty), "off" or "0" disables it. The file name is a 64-bit FNV-1a hash of the source, the options
+// and the hiprtc version, plus the source length. A cache that cannot be created, read or written is never an error.
+static std::string rtc_cache_dir() {
+    static const std::string dir = [] {
+        std::string d;
+        if (const char* e = getenv("SDFK_CACHE_DIR")) {
+            d = e;
+            if (d.empty() || d == "off" || d == "0") return std::string();
+        } else if (const char* x = getenv("XDG_CACHE_HOME"); x && *x) {
+            d = std::string(x) + "/sdfk";
+        } else if (const char* h = getenv("HOME"); h && *h) {
+            (void)mkdir((std::string(h) + "/.cache").c_str(), 0700);
+            d = std::string(h) + "/.cache/sdfk";
+        } else {
+            return std::string();
+        }
+        (void)mkdir(d.c_str(), 0700);
+        return d;
+    }();
+    return dir;
+}
 static std::string rtc_cache_path(const std::string& src, const std::string& opts) {
-    const char* dir = getenv("SDFK_CACHE_DIR");
-    if (!dir || !*dir) return std::string();
+    const std::string dir = rtc_cache_dir();
+    if (dir.empty()) return std::string();
     int major = 0, minor = 0;
     (void)hiprtcVersion(&major, &minor);
     unsigned long long h = 1469598103934665603ull;
@@ -557,7 +592,7 @@ static std::string rtc_cache_path(const std::string& src, const std::string& opt
     mix(std::to_string(major) + "." + std::to_string(minor) + "/abi" + std::to_string(SDFK_ABI_VERSION));
     char name[96];
     snprintf(name, sizeof name, "/sdfk-%016llx-%zu.co", h, src.size());
-    return std::string(dir) + name;
+    return dir + name;
 }
 static bool rtc_cache_read(const std::string& path, std::vector<char>* out) {
     if (path.empty()) return false;
@@ -584,52 +619,64 @@ static void rtc_cache_write(const std::string& path, const std::vector<char>& co
     if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());   // atomic: readers never see a partial file
 }
 
-static int rtc_compile_uncached(const std::string& src, std::vector<char>* out, std::string* log, int rwb, std::string* optkey);
-static int rtc_compile(const std::string& src, std::vector<char>* out, std::string* log, int rwb) {
-    std::string optkey;
-    if (getenv("SDFK_CACHE_DIR")) {
-        (void)rtc_compile_uncached(std::string(), nullptr, nullptr, rwb, &optkey);      // options only
-        const std::string path = rtc_cache_path(src, optkey);
-        if (rtc_cache_read(path, out)) return 0;
-        const int rc = rtc_compile_uncached(src, out, log, rwb, nullptr);
-        if (rc == 0) rtc_cache_write(path, *out);
-        return rc;
+static std::mutex g_rtc_mu;   // hiprtc and hipModuleLoadData: one thread at a time (see BuildWorker)
+// extra -D switches for the generated source (experiments): SDFK_RTC_DEFS="-DSDFK_TWAVES=2 ..." or sdfk_debug_set_rtc_defs
+static std::mutex g_defs_mu;
+static std::string g_rtc_defs = [] { const char* e = getenv("SDFK_RTC_DEFS"); return std::string(e ? e : ""); }();
+extern "C" void sdfk_debug_set_rtc_defs(const char* defs) {
+    std::lock_guard<std::mutex> lk(g_defs_mu);
+    std::string rest;
+    int tw = 0, rwb = 0;
+    const std::string all = defs ? defs : "";
+    size_t pos = 0;
+    while (pos < all.size()) {
+        size_t sp = all.find(' ', pos);
+        if (sp == std::string::npos) sp = all.size();
+        const std::string tok = all.substr(pos, sp - pos);
+        if (tok.compare(0, 14, "-DSDFK_TWAVES=") == 0) tw = atoi(tok.c_str() + 14);
+        else if (tok.compare(0, 16, "-DSDFK_RWBRICKS=") == 0) rwb = atoi(tok.c_str() + 16);
+        else if (!tok.empty()) rest += tok + " ";
+        pos = sp + 1;
     }
-    return rtc_compile_uncached(src, out, log, rwb, nullptr);
+    g_twaves_override = (tw >= 1 && tw <= 16) ? tw : 0;
+    g_rwbricks_override = (rwb >= 1 && rwb <= 16) ? rwb : 0;
+    g_rtc_defs = rest;
 }
-static int rtc_compile_uncached(const std::string& src, std::vector<char>* out, std::string* log, int rwb, std::string* optkey) {
-    hiprtcProgram prog = nullptr;                              // optkey != NULL: only the option string is wanted
-    if (!optkey && hiprtcCreateProgram(&prog, src.c_str(), "sdfk_spec.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+static std::vector<std::string> rtc_options(int rwb) {
+    std::vector<std::string> o = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17",
+                                  // -fno-honor-nans -mno-amdgpu-ieee: v_min/v_max without the canonicalising pre-op (same
+                                  // flags as the hipcc build of the interpreter kernel: both flavours stay bit-identical)
+                                  "-fno-honor-nans", "-mno-amdgpu-ieee",
+                                  "-DSDFK_TWAVES=" + std::to_string(tile_waves()), "-DSDFK_WBRICKS=" + std::to_string(tile_wbricks()),
+                                  "-DSDFK_RWBRICKS=" + std::to_string(rwb)};
+    std::string all;
+    {
+        std::lock_guard<std::mutex> lk(g_defs_mu);
+        all = g_rtc_defs;
+    }
+    size_t pos = 0;
+    while (pos < all.size()) {
+        size_t sp = all.find(' ', pos);
+        if (sp == std::string::npos) sp = all.size();
+        if (sp > pos && all.compare(pos, 2, "-D") == 0) o.push_back(all.substr(pos, sp - pos));
+        pos = sp + 1;
+    }
+    return o;
+}
+static std::string rtc_option_key(int rwb) {
+    std::string k;
+    for (const std::string& o : rtc_options(rwb)) k += o + " ";
+    return k;
+}
+static int rtc_compile_uncached(const std::string& src, std::vector<char>* out, std::string* log, int rwb) {
+    hiprtcProgram prog = nullptr;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "sdfk_spec.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
         *log = "hiprtcCreateProgram failed";
         return -1;
     }
-    char d_tile[48], d_thr[48], d_np[48], d_rwb[48], d_rt[48];
-    snprintf(d_rt, sizeof d_rt, "-DSDFK_RTILES=%d", rows_tiles());
-    snprintf(d_tile, sizeof d_tile, "-DSDFK_TWAVES=%d", tile_waves());
-    snprintf(d_thr, sizeof d_thr, "-DSDFK_WBRICKS=%d", tile_wbricks());
-    snprintf(d_np, sizeof d_np, "-DSDFK_NP=%d", rows_np());
-    snprintf(d_rwb, sizeof d_rwb, "-DSDFK_RWBRICKS=%d", rwb);
-    // -fno-honor-nans -mno-amdgpu-ieee: v_min/v_max without the canonicalising pre-op (same flags as the
-    // hipcc build of the interpreter kernel, so both flavours stay bit-identical)
-    std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17",
-                                     "-fno-honor-nans", "-mno-amdgpu-ieee", d_tile, d_thr, d_np, d_rwb, d_rt};
-    // experiment hook: extra -D switches for the generated source (space separated), e.g. SDFK_RTC_DEFS="-DSDFK_TWAVES=2"
-    std::vector<std::string> extra;
-    if (const char* e = getenv("SDFK_RTC_DEFS")) {
-        std::string all(e);
-        size_t pos = 0;
-        while (pos < all.size()) {
-            size_t sp = all.find(' ', pos);
-            if (sp == std::string::npos) sp = all.size();
-            if (sp > pos && all.compare(pos, 2, "-D") == 0) extra.push_back(all.substr(pos, sp - pos));
-            pos = sp + 1;
-        }
-    }
-    for (const std::string& x : extra) opts.push_back(x.c_str());
-    if (optkey) {                                              // the caller only wants the option string (cache key)
-        for (const char* o : opts) *optkey += std::string(o) + " ";
-        return 0;
-    }
+    const std::vector<std::string> o = rtc_options(rwb);
+    std::vector<const char*> opts;
+    for (const std::string& x : o) opts.push_back(x.c_str());
     hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
     size_t ls = 0;
     hiprtcGetProgramLogSize(prog, &ls);
@@ -649,48 +696,221 @@ static int rtc_compile_uncached(const std::string& src, std::vector<char>* out, 
     hiprtcDestroyProgram(&prog);
     return 0;
 }
+// *from_disk (optional): the code object came from the on-disk cache
+static int rtc_compile(const std::string& src, std::vector<char>* out, std::string* log, int rwb, bool* from_disk = nullptr) {
+    if (from_disk) *from_disk = false;
+    const std::string path = rtc_cache_path(src, rtc_option_key(rwb));
+    if (rtc_cache_read(path, out)) {
+        if (from_disk) *from_disk = true;
+        return 0;
+    }
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(g_rtc_mu);
+        rc = rtc_compile_uncached(src, out, log, rwb);
+    }
+    if (rc == 0) rtc_cache_write(path, *out);
+    return rc;
+}
 
-extern "C" int sdfk_program_compile_check(sdfk_program* p, size_t* code_size) {
-    const char* src = sdfk_program_source(p);
-    if (!src) return fail(-1, "null program");
+// ---- code objects (per process) and modules (per device) -----------------------------------------
+static const char* const kFlavourFn[SDFK_FL_COUNT][2] = {
+    {"sdfk_spec_v4", "sdfk_spec_v1"}, {"sdfk_spec_g4", "sdfk_spec_g1"}, {"sdfk_spec_t", nullptr}, {"sdfk_spec_tg", nullptr},
+    {"sdfk_spec_tmask", nullptr},     {"sdfk_spec_r", nullptr},         {"sdfk_spec_rg", nullptr}, {"sdfk_spec_rmask", nullptr}};
+
+// hiprtc is entered by ONE thread at a time, and never while a code object is being loaded (hipModuleLoadData):
+// g_rtc_mu. Background builds are queued to one worker thread, which is drained before the interpreter / the
+// library's statics (and with them hiprtc) go away: sdfk_jit_drain (Python: atexit) and the destructor below.
+struct BuildWorker {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> jobs;
+    std::thread thread;
+    bool stop = false, busy = false;
+    void post(std::function<void()> job) {
+        std::lock_guard<std::mutex> lk(mu);
+        jobs.push_back(std::move(job));
+        if (!thread.joinable()) thread = std::thread([this] { loop(); });
+        cv.notify_all();
+    }
+    void loop() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [this] { return stop || !jobs.empty(); });
+            if (jobs.empty()) return;                        // (stop: the queue is finished first)
+            std::function<void()> job = std::move(jobs.front());
+            jobs.pop_front();
+            busy = true;
+            lk.unlock();
+            job();
+            lk.lock();
+            busy = false;
+            cv.notify_all();
+        }
+    }
+    void drain() {                                           // wait until nothing is queued or running
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [this] { return jobs.empty() && !busy; });
+    }
+    ~BuildWorker() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+            cv.notify_all();
+        }
+        if (thread.joinable()) thread.join();
+    }
+};
+static BuildWorker g_builds;
+extern "C" void sdfk_jit_drain(void) { g_builds.drain(); }
+static std::atomic<long long> g_compile_count{0};             // hiprtc builds this process has actually run
+static std::atomic<long long> g_compile_micros{0};
+extern "C" void sdfk_debug_jit_stats(int64_t* builds, double* seconds) {
+    if (builds) *builds = g_compile_count.load();
+    if (seconds) *seconds = (double)g_compile_micros.load() * 1e-6;
+}
+
+static std::shared_ptr<CodeObject> code_entry(const std::string& key) {
+    std::lock_guard<std::mutex> lk(g_code_mu);
+    std::shared_ptr<CodeObject>& e = g_code[key];
+    if (!e) e = std::make_shared<CodeObject>();
+    return e;
+}
+// run one build; the caller has moved the entry to state 1
+static void code_build(const std::shared_ptr<CodeObject>& e, const std::string& src, int rwb) {
+    const auto t0 = std::chrono::steady_clock::now();
     std::vector<char> co;
     std::string log;
-    if (rtc_compile(src, &co, &log, rows_wbricks(p)) != 0) return fail(-3, log);
-    if (code_size) *code_size = co.size();
+    bool from_disk = false;
+    const int rc = rtc_compile(src, &co, &log, rwb, &from_disk);
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (!from_disk) {
+        g_compile_count++;
+        g_compile_micros += (long long)(dt * 1e6);
+    }
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->build_seconds = dt;
+    if (rc == 0) {
+        e->co.swap(co);
+        e->state = 2;
+    } else {
+        e->error = log;
+        e->state = 3;
+        e->failed_at = std::chrono::steady_clock::now();
+    }
+    e->cv.notify_all();
+}
+// The code object of (source, options): wait = build here (or wait for the thread that is building); !wait = make sure
+// a build is under way (background thread) and return at once. A failed build is retried after 30 s at the earliest.
+template <typename MakeSource>
+static std::shared_ptr<CodeObject> code_get(const std::string& key, MakeSource make_source, int rwb, bool wait) {
+    std::shared_ptr<CodeObject> e = code_entry(key);
+    std::unique_lock<std::mutex> lk(e->mu);
+    if (e->state == 3 && std::chrono::steady_clock::now() - e->failed_at > std::chrono::seconds(30)) e->state = 0;
+    if (e->state == 0) {
+        e->state = 1;
+        lk.unlock();
+        const std::string src = make_source();                 // (the program may be gone before a background build ends)
+        if (wait) {
+            code_build(e, src, rwb);
+        } else {
+            g_builds.post([e, src, rwb] { code_build(e, src, rwb); });
+        }
+        return e;
+    }
+    if (wait) e->cv.wait(lk, [&] { return e->state != 1; });
+    return e;
+}
+static std::string flavour_key(const sdfk_program* p, int flavour, int rwb) {
+    return p->key + "|f" + std::to_string(flavour) + "|" + rtc_option_key(rwb);
+}
+static std::string flavour_source(const sdfk_program* p, int flavour) {
+    return sdfk_generate_source(g_ops, SDFK_OP_COUNT, p->code.data(), p->code.size() / 2, p->result_reg, p->sites, flavour);
+}
+
+extern "C" int sdfk_program_compile_check(sdfk_program* p, size_t* code_size) {
+    // every flavour this program can be launched with, each as its own translation unit (what a run would build)
+    if (!p) return fail(-1, "null program");
+    size_t total = 0;
+    const int rwb = rows_wbricks(p);
+    for (int f = 0; f < SDFK_FL_COUNT; ++f) {
+        if (p->sites.empty() && f != SDFK_FL_PLAIN_ARRAY && f != SDFK_FL_PLAIN_GRID) continue;
+        std::shared_ptr<CodeObject> e = code_get(flavour_key(p, f, rwb), [&] { return flavour_source(p, f); }, rwb, true);
+        if (e->state != 2) return fail(-3, e->error);
+        total += e->co.size();
+    }
+    if (code_size) *code_size = total;
+    return 0;
+}
+/* Build (or fetch) ONE flavour without a GPU: 0 + seconds the build took (0 when it was already there). */
+extern "C" int sdfk_program_compile_flavour(sdfk_program* p, int flavour, size_t* code_size, double* seconds) {
+    if (!p) return fail(-1, "null program");
+    if (flavour < 0 || flavour >= SDFK_FL_COUNT) return fail(-1, "sdfk_program_compile_flavour: unknown flavour");
+    if (p->sites.empty() && flavour != SDFK_FL_PLAIN_ARRAY && flavour != SDFK_FL_PLAIN_GRID)
+        return fail(-2, "sdfk_program_compile_flavour: the program has no cull sites");
+    const int rwb = rows_wbricks(p);
+    const auto t0 = std::chrono::steady_clock::now();
+    std::shared_ptr<CodeObject> e = code_get(flavour_key(p, flavour, rwb), [&] { return flavour_source(p, flavour); }, rwb, true);
+    if (e->state != 2) return fail(-3, e->error);
+    if (code_size) *code_size = e->co.size();
+    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return 0;
 }
 
-static std::shared_ptr<SpecKernel> get_spec(sdfk_program* p, int device) {
-    std::lock_guard<std::mutex> lk(g_spec_mu);
-    auto k = std::make_pair(device, p->key);
-    auto it = g_spec.find(k);
-    if (it != g_spec.end()) return it->second;
-    auto sk = std::make_shared<SpecKernel>();
-    g_spec[k] = sk;
-    const char* src = sdfk_program_source(p);
-    std::vector<char> co;
-    std::string log;
-    if (rtc_compile(src, &co, &log, rows_wbricks(p)) != 0) {
-        sk->failed = true;
-        sk->error = log;
-        return sk;
+// The module of one flavour on one device. wait = false: nullptr while the code object is still being built in the
+// background (the caller serves this call from the interpreter kernel — same bits). *err is set on failure.
+static std::shared_ptr<SpecModule> get_module(sdfk_program* p, int device, int flavour, bool wait, std::string* err) {
+    const int rwb = rows_wbricks(p);
+    const std::string key = flavour_key(p, flavour, rwb);
+    std::shared_ptr<SpecModule> m;
+    {
+        std::lock_guard<std::mutex> lk(g_code_mu);
+        std::shared_ptr<SpecModule>& slot = g_mods[std::make_pair(device, key)];
+        if (!slot) slot = std::make_shared<SpecModule>();
+        m = slot;
     }
-    hipError_t e = hipModuleLoadData(&sk->mod, co.data());
-    if (e == hipSuccess) e = hipModuleGetFunction(&sk->v4, sk->mod, "sdfk_spec_v4");
-    if (e == hipSuccess) e = hipModuleGetFunction(&sk->v1, sk->mod, "sdfk_spec_v1");
-    if (e == hipSuccess) e = hipModuleGetFunction(&sk->g4, sk->mod, "sdfk_spec_g4");
-    if (e == hipSuccess) e = hipModuleGetFunction(&sk->g1, sk->mod, "sdfk_spec_g1");
-    if (e == hipSuccess && !p->sites.empty()) e = hipModuleGetFunction(&sk->tile, sk->mod, "sdfk_spec_t");
-    if (e == hipSuccess && !p->sites.empty()) e = hipModuleGetFunction(&sk->tmask, sk->mod, "sdfk_spec_tmask");
-    if (e == hipSuccess && !p->sites.empty()) e = hipModuleGetFunction(&sk->tile_grid, sk->mod, "sdfk_spec_tg");
-    if (e == hipSuccess && !p->sites.empty()) e = hipModuleGetFunction(&sk->rows, sk->mod, "sdfk_spec_r");
-    if (e == hipSuccess && !p->sites.empty()) e = hipModuleGetFunction(&sk->rows_grid, sk->mod, "sdfk_spec_rg");
-    if (e == hipSuccess && !p->sites.empty()) e = hipModuleGetFunction(&sk->rmask, sk->mod, "sdfk_spec_rmask");
-    if (e != hipSuccess) {
-        sk->failed = true;
-        sk->error = std::string("hipModuleLoadData/GetFunction: ") + hipGetErrorString(e);
+    std::lock_guard<std::mutex> lk(m->mu);                     // per (device, flavour): loads never block other devices
+    if (m->loaded) return m;
+    std::shared_ptr<CodeObject> e;
+    {
+        std::lock_guard<std::mutex> ce(g_code_mu);
+        auto it = g_code.find(key);
+        if (it != g_code.end()) e = it->second;
     }
-    return sk;
+    int state = 0;
+    if (e) {
+        std::lock_guard<std::mutex> el(e->mu);
+        state = e->state;
+    }
+    if (state != 2) {
+        e = code_get(key, [&] { return flavour_source(p, flavour); }, rwb, wait);
+        std::lock_guard<std::mutex> el(e->mu);
+        state = e->state;
+    }
+    if (state == 1) return nullptr;                            // still building (wait == false)
+    if (state != 2) {
+        std::lock_guard<std::mutex> el(e->mu);
+        *err = e->error;
+        m->failed = true;
+        m->error = e->error;
+        return m;                                              // (not marked loaded: a later call asks code_get again)
+    }
+    hipError_t he;
+    {
+        std::lock_guard<std::mutex> rl(g_rtc_mu);
+        he = hipModuleLoadData(&m->mod, e->co.data());
+    }
+    for (int i = 0; i < 2 && he == hipSuccess; ++i)
+        if (kFlavourFn[flavour][i]) he = hipModuleGetFunction(&m->fn[i], m->mod, kFlavourFn[flavour][i]);
+    if (he != hipSuccess) {
+        m->failed = true;
+        m->error = std::string("hipModuleLoadData/GetFunction: ") + hipGetErrorString(he);
+        *err = m->error;
+        return m;
+    }
+    m->failed = false;
+    m->loaded = true;
+    return m;
 }
 
 // make sure code / params / tables of `p` are resident on the current device
@@ -738,26 +958,41 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
     long long n4 = vec_ok ? (n / 4) * 4 : 0;
     long long tail = n - n4;
 
-    // Very large trees: hiprtc needs ~0.3 s per primitive for the specialised kernels (minutes beyond a few hundred
-    // primitives); in AUTO mode they run on the interpreter kernel, which needs no compilation
-    // (SDFK_SPECIALIZE_LIMIT instructions, default 600 ~ 200 primitives; MODE_SPECIALIZED always specialises).
+    // Very large trees: hiprtc needs ~0.1-0.3 s per primitive and flavour (minutes beyond several hundred
+    // primitives); in AUTO mode they stay on the interpreter kernel, which needs no compilation
+    // (SDFK_SPECIALIZE_LIMIT instructions, default 1200 ~ 400 primitives; MODE_SPECIALIZED always specialises).
     static const long long spec_limit = [] {
         const char* e = getenv("SDFK_SPECIALIZE_LIMIT");
-        const long long v = e ? atoll(e) : 600;
-        return v > 0 ? v : 600;
+        const long long v = e ? atoll(e) : 1200;
+        return v > 0 ? v : 1200;
     }();
     if (mode == SDFK_MODE_AUTO && (long long)(p->code.size() / 2) > spec_limit && p->interp_ok) mode = SDFK_MODE_INTERPRET;
 
-    std::shared_ptr<SpecKernel> sk;
+    // Which flavour does this call launch? (row blocks > line bricks > plain; NOCULL and programs without sites: plain)
+    RowGeom rg;
+    int flavour = arr ? SDFK_FL_PLAIN_ARRAY : SDFK_FL_PLAIN_GRID;
+    const long long grow = grid ? (grid->n2 > 1 ? (long long)grid->n2 : (long long)grid->n1) : 0;
+    if (!p->sites.empty() && mode != SDFK_MODE_NOCULL && mode != SDFK_MODE_INTERPRET) {
+        if (arr && rows_geometry(n, row_len, &rg)) flavour = SDFK_FL_ROWS_ARRAY;          // rows need no alignment beyond 4 bytes
+        else if (arr && vec_ok) flavour = SDFK_FL_TILE_ARRAY;
+        else if (grid && grid->start % grow == 0 && rows_geometry(n, grow, &rg)) flavour = SDFK_FL_ROWS_GRID;
+        else if (grid && vec_ok) flavour = SDFK_FL_TILE_GRID;
+    }
+    std::shared_ptr<SpecModule> sk;
     if (mode != SDFK_MODE_INTERPRET) {
-        sk = get_spec(p, device);
-        if (sk->failed) {
+        // AUTO: while hiprtc is still building this flavour (background thread, SDFK_ASYNC_JIT=0 turns that off) the
+        // call is served by the interpreter kernel — the same device functions, the same bits — and later calls
+        // switch over. SPECIALIZED / NOCULL always wait for the build.
+        static const bool async_jit = [] { const char* e = getenv("SDFK_ASYNC_JIT"); return !(e && e[0] == '0'); }();
+        const bool wait = mode != SDFK_MODE_AUTO || !p->interp_ok || !async_jit;
+        std::string err;
+        sk = get_module(p, device, flavour, wait, &err);
+        if (sk && sk->failed) {
             if (mode == SDFK_MODE_SPECIALIZED || !p->interp_ok)
-                return fail(-3, "specialised kernel unavailable: " + sk->error);
+                return fail(-3, "specialised kernel unavailable: " + err);
             static bool warned = false;
             if (!warned) {
-                fprintf(stderr, "[sdfk] hiprtc specialisation failed, using the interpreter kernel: %s\n",
-                        sk->error.c_str());
+                fprintf(stderr, "[sdfk] hiprtc specialisation failed, using the interpreter kernel: %s\n", err.c_str());
                 warned = true;
             }
             sk.reset();
@@ -769,44 +1004,38 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
     const float* prm = d->d_params;
     const float* tab = d->d_tables;
     if (sk) {
-        RowGeom rg;
-        if (arr && sk->rows && mode != SDFK_MODE_NOCULL && rows_geometry(n, row_len, &rg)) {
-            // row-block culling kernel: rows need no alignment beyond 4 bytes
-            const float* co = arr->co;
-            long long stride = arr->stride;
-            void* args[] = {&prm, &tab, &co, &stride, &rg, &d_out};
-            const unsigned per_tile = (unsigned)(tile_waves() * rows_wbricks(p) * rows_tiles());
-            const unsigned tiles = (rg.nbricks + per_tile - 1) / per_tile;
-            HIPCHK(hipModuleLaunchKernel(sk->rows, tiles, 1, 1, tile_threads(), 1, 1, 0, stream, args, nullptr));
+        if (flavour == SDFK_FL_ROWS_ARRAY || flavour == SDFK_FL_ROWS_GRID) {
+            const unsigned per_tile = (unsigned)(tile_waves() * rows_wbricks(p));
+            const unsigned tiles = ((rg.nbricks + per_tile - 1) / per_tile + 7u) & ~7u;   // whole rounds over the 8 XCDs
+            if (arr) {
+                const float* co = arr->co;
+                long long stride = arr->stride;
+                void* args[] = {&prm, &tab, &co, &stride, &rg, &d_out};
+                HIPCHK(hipModuleLaunchKernel(sk->fn[0], tiles, 1, 1, tile_threads(), 1, 1, 0, stream, args, nullptr));
+            } else {
+                // whole grid rows (x-slabs of a sharded evaluation always are); rows along the third axis, or along
+                // the second one when the grid is flat (n2 == 1)
+                SrcGrid g = *grid;
+                rg.row0 = grid->start / grow;
+                rg.yrows = grid->n2 > 1 ? 0 : 1;
+                void* args[] = {&prm, &tab, &g, &rg, &d_out};
+                HIPCHK(hipModuleLaunchKernel(sk->fn[0], tiles, 1, 1, tile_threads(), 1, 1, 0, stream, args, nullptr));
+            }
             return 0;
         }
-        if (arr && sk->tile && vec_ok && mode != SDFK_MODE_NOCULL) {
+        if (flavour == SDFK_FL_TILE_ARRAY || flavour == SDFK_FL_TILE_GRID) {
             // brick-culling tile kernel: handles the ragged end itself
-            const float* co = arr->co;
-            long long stride = arr->stride;
-            void* args[] = {&prm, &tab, &co, &stride, &n, &d_out};
             const unsigned tiles = (unsigned)((n + tile_points() - 1) / tile_points());
-            HIPCHK(hipModuleLaunchKernel(sk->tile, tiles, 1, 1, tile_threads(), 1, 1, 0, stream, args, nullptr));
-            return 0;
-        }
-        // rows of the grid: along the third axis, or along the second one when the grid is flat (n2 == 1)
-        const long long grow = grid ? (grid->n2 > 1 ? (long long)grid->n2 : (long long)grid->n1) : 0;
-        if (grid && sk->rows_grid && mode != SDFK_MODE_NOCULL && grid->start % grow == 0 && rows_geometry(n, grow, &rg)) {
-            // whole grid rows (x-slabs of a sharded evaluation always are): row-block culling kernel
-            SrcGrid g = *grid;
-            rg.row0 = grid->start / grow;
-            rg.yrows = grid->n2 > 1 ? 0 : 1;
-            void* args[] = {&prm, &tab, &g, &rg, &d_out};
-            const unsigned per_tile = (unsigned)(tile_waves() * rows_wbricks(p) * rows_tiles());
-            const unsigned tiles = (rg.nbricks + per_tile - 1) / per_tile;
-            HIPCHK(hipModuleLaunchKernel(sk->rows_grid, tiles, 1, 1, tile_threads(), 1, 1, 0, stream, args, nullptr));
-            return 0;
-        }
-        if (grid && sk->tile_grid && vec_ok && mode != SDFK_MODE_NOCULL) {
-            SrcGrid g = *grid;
-            void* args[] = {&prm, &tab, &g, &n, &d_out};
-            const unsigned tiles = (unsigned)((n + tile_points() - 1) / tile_points());
-            HIPCHK(hipModuleLaunchKernel(sk->tile_grid, tiles, 1, 1, tile_threads(), 1, 1, 0, stream, args, nullptr));
+            if (arr) {
+                const float* co = arr->co;
+                long long stride = arr->stride;
+                void* args[] = {&prm, &tab, &co, &stride, &n, &d_out};
+                HIPCHK(hipModuleLaunchKernel(sk->fn[0], tiles, 1, 1, tile_threads(), 1, 1, 0, stream, args, nullptr));
+            } else {
+                SrcGrid g = *grid;
+                void* args[] = {&prm, &tab, &g, &n, &d_out};
+                HIPCHK(hipModuleLaunchKernel(sk->fn[0], tiles, 1, 1, tile_threads(), 1, 1, 0, stream, args, nullptr));
+            }
             return 0;
         }
         if (arr) {
@@ -815,13 +1044,13 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
             if (n4) {
                 long long off = 0;
                 void* args[] = {&prm, &tab, &co, &stride, &off, &n4, &d_out, &aux, &aux_stride};
-                HIPCHK(hipModuleLaunchKernel(sk->v4, blocks_for(n4, 4), 1, 1, SDFK_BLOCK, 1, 1, 0, stream, args,
+                HIPCHK(hipModuleLaunchKernel(sk->fn[0], blocks_for(n4, 4), 1, 1, SDFK_BLOCK, 1, 1, 0, stream, args,
                                              nullptr));
             }
             if (tail) {
                 long long off = n4;
                 void* args[] = {&prm, &tab, &co, &stride, &off, &tail, &d_out, &aux, &aux_stride};
-                HIPCHK(hipModuleLaunchKernel(sk->v1, blocks_for(tail, 1), 1, 1, SDFK_BLOCK, 1, 1, 0, stream, args,
+                HIPCHK(hipModuleLaunchKernel(sk->fn[1], blocks_for(tail, 1), 1, 1, SDFK_BLOCK, 1, 1, 0, stream, args,
                                              nullptr));
             }
         } else {
@@ -829,13 +1058,13 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
             if (n4) {
                 long long off = 0;
                 void* args[] = {&prm, &tab, &g, &off, &n4, &d_out, &aux, &aux_stride};
-                HIPCHK(hipModuleLaunchKernel(sk->g4, blocks_for(n4, 4), 1, 1, SDFK_BLOCK, 1, 1, 0, stream, args,
+                HIPCHK(hipModuleLaunchKernel(sk->fn[0], blocks_for(n4, 4), 1, 1, SDFK_BLOCK, 1, 1, 0, stream, args,
                                              nullptr));
             }
             if (tail) {
                 long long off = n4;
                 void* args[] = {&prm, &tab, &g, &off, &tail, &d_out, &aux, &aux_stride};
-                HIPCHK(hipModuleLaunchKernel(sk->g1, blocks_for(tail, 1), 1, 1, SDFK_BLOCK, 1, 1, 0, stream, args,
+                HIPCHK(hipModuleLaunchKernel(sk->fn[1], blocks_for(tail, 1), 1, 1, SDFK_BLOCK, 1, 1, 0, stream, args,
                                              nullptr));
             }
         }
@@ -903,7 +1132,7 @@ extern "C" int sdfk_debug_row_masks(sdfk_program* p, const float* d_co, int64_t 
     if (row_stride < n || !rows_geometry(n, row_len, &rg))
         return fail(-1, "sdfk_debug_row_masks: the row-block kernel does not take this shape");
     if (n_bricks) *n_bricks = rg.nbricks;
-    if (brick_rows) *brick_rows = 4 * rows_np();
+    if (brick_rows) *brick_rows = 16;
     if (!d_masks) return 0;                      // size query
     hipStream_t stream = (hipStream_t)stream_;
     int device = 0;
@@ -911,14 +1140,15 @@ extern "C" int sdfk_debug_row_masks(sdfk_program* p, const float* d_co, int64_t 
     DevState* d = nullptr;
     int rc = ensure_resident(p, device, stream, &d);
     if (rc) return rc;
-    std::shared_ptr<SpecKernel> sk = get_spec(p, device);
-    if (sk->failed || !sk->rmask) return fail(-3, "specialised kernel unavailable: " + sk->error);
+    std::string err;
+    std::shared_ptr<SpecModule> sk = get_module(p, device, SDFK_FL_ROWS_MASK, true, &err);
+    if (!sk || sk->failed) return fail(-3, "specialised kernel unavailable: " + err);
     const float* prm = d->d_params;
     const float* tab = d->d_tables;
     long long stride = row_stride;
     void* args[] = {&prm, &tab, &d_co, &stride, &rg, &d_masks};
     const unsigned per_tile = (unsigned)(tile_waves() * rows_wbricks(p));
-    HIPCHK(hipModuleLaunchKernel(sk->rmask, (rg.nbricks + per_tile - 1) / per_tile, 1, 1, tile_threads(), 1, 1, 0, stream,
+    HIPCHK(hipModuleLaunchKernel(sk->fn[0], (rg.nbricks + per_tile - 1) / per_tile, 1, 1, tile_threads(), 1, 1, 0, stream,
                                  args, nullptr));
     return 0;
 }
@@ -935,13 +1165,14 @@ extern "C" int sdfk_debug_brick_masks(sdfk_program* p, const float* d_co, int64_
     DevState* d = nullptr;
     int rc = ensure_resident(p, device, stream, &d);
     if (rc) return rc;
-    std::shared_ptr<SpecKernel> sk = get_spec(p, device);
-    if (sk->failed || !sk->tmask) return fail(-3, "specialised kernel unavailable: " + sk->error);
+    std::string err;
+    std::shared_ptr<SpecModule> sk = get_module(p, device, SDFK_FL_TILE_MASK, true, &err);
+    if (!sk || sk->failed) return fail(-3, "specialised kernel unavailable: " + err);
     const float* prm = d->d_params;
     const float* tab = d->d_tables;
     long long stride = row_stride, nn = n;
     void* args[] = {&prm, &tab, &d_co, &stride, &nn, &d_masks};
-    HIPCHK(hipModuleLaunchKernel(sk->tmask, (unsigned)((n + tile_points() - 1) / tile_points()), 1, 1, tile_threads(),
+    HIPCHK(hipModuleLaunchKernel(sk->fn[0], (unsigned)((n + tile_points() - 1) / tile_points()), 1, 1, tile_threads(),
                                  1, 1, 0, stream, args, nullptr));
     return 0;
 }

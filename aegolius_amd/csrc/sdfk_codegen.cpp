@@ -35,6 +35,8 @@ static __device__ __forceinline__ void sdfk_body(const float* __restrict__ PRM, 
     }
     sdfk_store<VEC>(out, off + block_base + lane_off, v);
 }
+)SDFKW";
+static const char kWrappersArray[] = R"SDFKW(
 extern "C" __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_spec_v4(
     const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
     long long off, long long n, float* __restrict__ out, const float* __restrict__ aux, long long aux_stride) {
@@ -47,6 +49,8 @@ extern "C" __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_spec_v1(
     SrcArray s = {co, stride};
     sdfk_body<1>(PRM, TAB, s, off, n, out, aux, aux_stride);
 }
+)SDFKW";
+static const char kWrappersGrid[] = R"SDFKW(
 extern "C" __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_spec_g4(
     const float* __restrict__ PRM, const float* __restrict__ TAB, SrcGrid g, long long off, long long n,
     float* __restrict__ out, const float* __restrict__ aux, long long aux_stride) {
@@ -58,6 +62,28 @@ extern "C" __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_spec_g1(
     sdfk_body<1>(PRM, TAB, g, off, n, out, aux, aux_stride);
 }
 )SDFKW";
+
+// Pieces shared by the two culling kernel families.
+static const char kWaveHelpers[] = R"SDFKH(
+#ifndef SDFK_TWAVES
+#define SDFK_TWAVES 4           // waves per workgroup           (host launch code must agree: sdfk.hip)
+#endif
+#define SDFK_TTHREADS (64 * SDFK_TWAVES)
+// wave-wide max of a non-negative value (DPP: row_shr 1,2,4,8, row_bcast 15 / 31); result valid in every lane
+static __device__ __forceinline__ float sdfk_wave_max(float v) {
+    v = sd_rawmax(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false)));
+    v = sd_rawmax(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, false)));
+    v = sd_rawmax(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, false)));
+    v = sd_rawmax(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, false)));
+    v = sd_rawmax(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false)));
+    v = sd_rawmax(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false)));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+static __device__ __forceinline__ float sdfk_lane(float v, int l) {     // l wave-uniform
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+)SDFKH";
 
 // Brick-culling tile kernel (only emitted when the program has cull sites).
 // A brick = SDFK_BRICK (128) consecutive points = one wave x one packed f2 lane value. A workgroup of
@@ -75,16 +101,12 @@ extern "C" __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_spec_g1(
 //      is skipped only if both runs allow it
 //   0  anything else: one bounding sphere, x / y re-read from global memory in phase C
 static const char kTileKernel[] = R"SDFKT(
-#ifndef SDFK_TWAVES
-#define SDFK_TWAVES 4           // waves per workgroup           (host launch code must agree: sdfk.hip)
-#endif
 #ifndef SDFK_WBRICKS
 #define SDFK_WBRICKS 4          // bricks per wave
 #endif
 #define SDFK_BRICK 128
 #define SDFK_NBRICK (SDFK_TWAVES * SDFK_WBRICKS)
 #define SDFK_TILE (SDFK_NBRICK * SDFK_BRICK)
-#define SDFK_TTHREADS (64 * SDFK_TWAVES)
 static_assert(2 * SDFK_NBRICK <= SDFK_TTHREADS, "one probe lane per run");
 
 struct sdfk_tilemeta {
@@ -95,20 +117,6 @@ struct sdfk_tilemeta {
     float base[SDFK_NBRICK][3 * SDFK_NROOT], base2[SDFK_NBRICK][3 * SDFK_NROOT];
     unsigned kind[SDFK_NBRICK], split[SDFK_NBRICK];   // split = index of the first point of the second run
 };
-
-// wave-wide max of a non-negative value (DPP: row_shr 1,2,4,8, row_bcast 15 / 31); result valid in every lane
-static __device__ __forceinline__ float sdfk_wave_max(float v) {
-    v = sd_rawmax(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false)));
-    v = sd_rawmax(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, false)));
-    v = sd_rawmax(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, false)));
-    v = sd_rawmax(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, false)));
-    v = sd_rawmax(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false)));
-    v = sd_rawmax(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false)));
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-static __device__ __forceinline__ float sdfk_lane(float v, int l) {     // l wave-uniform
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
 
 // phase A for one brick: classify and bound; lane 0 publishes the metadata
 static __device__ __forceinline__ void sdfk_brick_bounds(f2 x, f2 y, f2 z, int lane, sdfk_tilemeta* meta, int b) {
@@ -320,17 +328,23 @@ static __device__ __forceinline__ void sdfk_tile_kernel(const float* __restrict_
     sdfk_tile_evaluate(PRM, TAB, src, n, (long long)blockIdx.x * SDFK_TILE, &meta, out, threadIdx.x & 63,
                        threadIdx.x >> 6);
 }
+)SDFKT";
+static const char kTileArray[] = R"SDFKT(
 extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_t(
     const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
     long long n, float* __restrict__ out) {
     const SrcArray s = {co, stride};
     sdfk_tile_kernel(PRM, TAB, s, n, out);
 }
+)SDFKT";
+static const char kTileGrid[] = R"SDFKT(
 // the same on a regular grid expanded from three per-axis tables: no coordinate array at all (4 B/point)
 extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_tg(
     const float* __restrict__ PRM, const float* __restrict__ TAB, SrcGrid g, long long n, float* __restrict__ out) {
     sdfk_tile_kernel(PRM, TAB, g, n, out);
 }
+)SDFKT";
+static const char kTileMask[] = R"SDFKT(
 // debugging / test aid: the skip masks of every brick (2 bits per site: bit 2k = skip first operand,
 // bit 2k+1 = skip second operand; bit 63 = x/y-constant run, bit 62 = two such runs)
 extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_tmask(
@@ -517,9 +531,20 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
                                                          unsigned tile, unsigned& rb0, unsigned& c0) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned q0 = tile * SDFK_RNBRICK + wave * SDFK_RWBRICKS;            // first brick of this wave
-    rb0 = q0 / g.nchunk;
-    c0 = q0 - rb0 * g.nchunk;
+    rb0 = __builtin_amdgcn_readfirstlane(q0 / g.nchunk);        // (the division runs on the vector unit: back to an SGPR,
+    c0 = q0 - rb0 * g.nchunk;                                    //  so that what is derived from it stays scalar)
     unsigned rb = rb0, c = c0;
+#ifdef SDFK_HOIST
+    sdfk_rowregs hregs[SDFK_RWBRICKS];
+#pragma unroll
+    for (int j = 0; j < SDFK_RWBRICKS; ++j) {
+        if (q0 + j < g.nbricks) sdfk_rows_load(s, g, (long long)rb * SDFK_RROWS, c, lane, hregs[j]);
+        if (++c == g.nchunk) { c = 0; ++rb; }
+    }
+#pragma unroll
+    for (int j = 0; j < SDFK_RWBRICKS; ++j)
+        if (q0 + j < g.nbricks) sdfk_rows_bounds(hregs[j], lane, meta, wave * SDFK_RWBRICKS + j);
+#else
     // (hoisting all loads of the wave ahead of the first use was measured slower: registers, not memory-level
     // parallelism, limit this phase)
 #pragma unroll
@@ -535,6 +560,7 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
         }
         if (++c == g.nchunk) { c = 0; ++rb; }
     }
+#endif
     __syncthreads();
     if (threadIdx.x < SDFK_RNBRICK && tile * SDFK_RNBRICK + threadIdx.x < g.nbricks) {
         const float4 bb = meta->bound[threadIdx.x];
@@ -632,18 +658,24 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
 #else
 #define SDFK_ROWS_ATTR
 #endif
+)SDFKR";
+static const char kRowsArray[] = R"SDFKR(
 extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) SDFK_ROWS_ATTR void sdfk_spec_r(
     const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
     sdfk_rowgeom g, float* __restrict__ out) {
     const SrcArray s = {co, stride};
     sdfk_rows_kernel(PRM, TAB, s, g, out);
 }
+)SDFKR";
+static const char kRowsGrid[] = R"SDFKR(
 // the same on a regular grid expanded from three per-axis tables (no coordinate array: 4 B/point); the slab
 // starts at a row boundary and out[0] is its first point
 extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_rg(
     const float* __restrict__ PRM, const float* __restrict__ TAB, SrcGrid s, sdfk_rowgeom g, float* __restrict__ out) {
     sdfk_rows_kernel(PRM, TAB, s, g, out);
 }
+)SDFKR";
+static const char kRowsMask[] = R"SDFKR(
 // test aid: the skip masks (two 64-bit words per brick: sites 0-31, 32-63; bit 2k = first operand of site k
 // skipped, bit 2k+1 = second) followed by the "uniform rows" flag in a third word
 extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_rmask(
@@ -699,7 +731,7 @@ struct Gen {
             instr(i, indent, rows && mode == 2);
             return;
         }
-        char buf[640];
+        char buf[800];
         const uint32_t w = code[2 * i], poff = code[2 * i + 1];
         const unsigned a = (w >> 8) & 255u;
         if (rows) {
@@ -755,7 +787,10 @@ struct Gen {
     }
 
     // (no initialisers: skipped subtrees never have their registers read — set_cull's liveness check)
-    void declare(const char* ctype, const char* vtype, bool arr) {
+    // init: give every register a value up front. Skipped subtrees never have their registers READ (set_cull's
+    // liveness check), but without it the compiler materialises a zero for each of them on every skip edge —
+    // 8 moves per nesting level of a combiner chain in the row-block kernel; one initialisation costs them once.
+    void declare(const char* ctype, const char* vtype, bool arr, bool init = false) {
         std::set<unsigned> cregs, vregs;
         for (size_t i = 0; i < n_instr; ++i) {
             const uint32_t w = code[2 * i];
@@ -766,13 +801,14 @@ struct Gen {
         }
         char buf[160];
         const char* dim = arr ? "[SDFK_NP]" : "";
+        const char* ini = init ? " = {}" : "";
         for (unsigned c : cregs)
             if (c != 0) {
                 snprintf(buf, sizeof buf, "    %s C_%u%s;\n", ctype, c, dim);
                 s += buf;
             }
         for (unsigned v : vregs) {
-            snprintf(buf, sizeof buf, "    %s V_%u%s;\n", vtype, v, dim);
+            snprintf(buf, sizeof buf, "    %s V_%u%s%s;\n", vtype, v, dim, ini);
             s += buf;
         }
     }
@@ -855,6 +891,39 @@ struct Gen {
         return b;
     }
 
+    // the site (if any) whose whole span [a0, comb] is exactly [lo, hi]
+    int site_spanning(size_t lo, size_t hi) const {
+        for (size_t k = 0; k < sites->size(); ++k)
+            if ((*sites)[k].a0 == lo && (*sites)[k].comb == hi) return (int)k;
+        return -1;
+    }
+
+    // second operand of site k and its combiner; `replace`: expression that is true when the first operand is
+    // irrelevant (the combiner's value is then the second operand alone)
+    void emit_second(int k, const std::string& ind, const std::string& replace, int depth) {
+        const sdfk_cullsite& t = (*sites)[k];
+        const std::string tb = bit_test(2 * k + 1);
+        const uint32_t w = code[2 * t.comb];
+        const unsigned a = (w >> 8) & 255u, b = (w >> 16) & 255u, c = w >> 24;
+        char gB[64], gA[64], wx[32];
+        bool neg;
+        site_ops(t, gB, gA, wx, &neg, sizeof gB);
+        char ra[24], rb_[24], rc[24];
+        snprintf(ra, sizeof ra, "V_%u", a);
+        snprintf(rb_, sizeof rb_, "V_%u", b);
+        snprintf(rc, sizeof rc, "V_%u", c);
+        const std::string e = rows ? "{ SDFK_EACH " : "", x = rows ? "[q]" : "", z = rows ? " }" : "";
+        const std::string in2 = ind + "    ";
+        s += ind + "if (!" + tb + ") {\n";
+        emit_span(t.b0, t.b1, depth + 1);
+        s += in2 + "if (" + replace + ") " + e + ra + x + " = " + (neg ? "-" : "") + rc + x + ";" + z + "\n";
+        s += in2 + "else {\n";
+        instr(t.comb, (in2 + "    ").c_str(), rows);
+        s += in2 + "}\n";
+        s += ind + "}\n";
+        if (a != b) s += ind + "else " + e + ra + x + " = " + rb_ + x + ";" + z + "\n";
+    }
+
     void emit_span(size_t lo, size_t hi, int depth) {
         std::string ind(4 + 4 * std::min(depth, 10), ' ');   // (cosmetic; capped so lines fit the line buffers)
         size_t i = lo;
@@ -865,35 +934,56 @@ struct Gen {
                 ++i;
                 continue;
             }
-            const sdfk_cullsite& t = (*sites)[k];
-            // (inside [a0, a1] this site is out of reach: its combiner lies beyond a1)
-            const std::string ta = bit_test(2 * k), tb = bit_test(2 * k + 1);
-            // first operand (unless irrelevant), then — only if the second one matters — the second operand and the
-            // combiner. Everything the second operand computes lives and dies inside that block, so a skipped
-            // operand costs one scalar branch: no merge copies, no placeholder values.
-            s += ind + "if (!" + ta + ") {\n";
-            emit_span(t.a0, t.a1, depth + 1);
+            // A left-deep chain — fold(fold(fold(p0, p1), p2), p3): what CombineGeometry builds for n operands and what
+            // every chain of pairwise unions is — comes as sites that all open at the same instruction, each one's
+            // first operand being the whole site before it. Nested, every level would merge "operand skipped" with
+            // "operand evaluated", and the compiler fills the skipped side's registers with zeros level after level
+            // (8 moves per level in the row-block kernel). Flat instead: the highest level whose FIRST operand is
+            // irrelevant is where evaluation starts (scalar arithmetic on the mask), levels below it do nothing.
+            std::vector<int> chain = {k};                    // outermost first
+            for (;;) {
+                const sdfk_cullsite& t = (*sites)[chain.back()];
+                const int inner = site_spanning(t.a0, t.a1);
+                if (inner < 0) break;
+                chain.push_back(inner);
+            }
+            const size_t m = chain.size();
+            // (inside [a0, a1] a site is out of reach of itself: its combiner lies beyond a1)
+            if (m == 1) {
+                const sdfk_cullsite& t = (*sites)[k];
+                const std::string ta = bit_test(2 * k);
+                // first operand (unless irrelevant), then — only if the second one matters — the second operand and
+                // the combiner. Everything the second operand computes lives and dies inside that block, so a
+                // skipped operand costs one scalar branch: no merge copies, no placeholder values.
+                s += ind + "if (!" + ta + ") {\n";
+                emit_span(t.a0, t.a1, depth + 1);
+                s += ind + "}\n";
+                emit_second(k, ind, ta, depth);
+                i = t.comb + 1;
+                continue;
+            }
+            char st[32];
+            snprintf(st, sizeof st, "st_%d", k);
+            s += ind + "{ unsigned " + st + " = 0u;\n";
+            for (size_t idx = 1; idx <= m; ++idx) {          // level idx = site chain[m - idx]
+                char buf[96];
+                snprintf(buf, sizeof buf, "if %s %s = %zuu;\n", bit_test(2 * chain[m - idx]).c_str(), st, idx);
+                s += ind + "  " + buf;
+            }
+            const sdfk_cullsite& first = (*sites)[chain[m - 1]];
+            s += ind + "  if (" + st + " == 0u) {\n";
+            emit_span(first.a0, first.a1, depth + 1);
+            s += ind + "  }\n";
+            for (size_t idx = 1; idx <= m; ++idx) {
+                char cond[64], repl[64];
+                snprintf(cond, sizeof cond, "%s <= %zuu", st, idx);
+                snprintf(repl, sizeof repl, "%s == %zuu", st, idx);
+                s += ind + "  if (" + cond + ") {\n";
+                emit_second(chain[m - idx], ind + "    ", repl, depth + 1);
+                s += ind + "  }\n";
+            }
             s += ind + "}\n";
-            const uint32_t w = code[2 * t.comb];
-            const unsigned a = (w >> 8) & 255u, b = (w >> 16) & 255u, c = w >> 24;
-            char gB[64], gA[64], wx[32];
-            bool neg;
-            site_ops(t, gB, gA, wx, &neg, sizeof gB);
-            char ra[24], rb_[24], rc[24];
-            snprintf(ra, sizeof ra, "V_%u", a);
-            snprintf(rb_, sizeof rb_, "V_%u", b);
-            snprintf(rc, sizeof rc, "V_%u", c);
-            const std::string e = rows ? "{ SDFK_EACH " : "", x = rows ? "[q]" : "", z = rows ? " }" : "";
-            const std::string in2 = ind + "    ";
-            s += ind + "if (!" + tb + ") {\n";
-            emit_span(t.b0, t.b1, depth + 1);
-            s += in2 + "if " + ta + " " + e + ra + x + " = " + (neg ? "-" : "") + rc + x + ";" + z + "\n";
-            s += in2 + "else {\n";
-            instr(t.comb, (in2 + "    ").c_str(), rows);
-            s += in2 + "}\n";
-            s += ind + "}\n";
-            if (a != b) s += ind + "else " + e + ra + x + " = " + rb_ + x + ";" + z + "\n";
-            i = t.comb + 1;
+            i = (*sites)[k].comb + 1;
         }
     }
 
@@ -902,7 +992,7 @@ struct Gen {
              "const V3P (&P0)[SDFK_NP], unsigned mw0, unsigned mw1, unsigned mw2, unsigned mw3, "
              "const float* __restrict__ PRM, const float* __restrict__ TAB, f2 (&R)[SDFK_NP]) {\n"
              "    typedef f2 T;\n    V3P C_0[SDFK_NP];\n    SDFK_EACH C_0[q] = P0[q];\n";
-        declare("V3P", "f2", true);
+        declare("V3P", "f2", true, true);
         emit_span(0, n_instr - 1, 0);
         char buf[96];
         snprintf(buf, sizeof buf, "    SDFK_EACH R[q] = V_%d[q];\n}\n", result_reg);
@@ -924,23 +1014,34 @@ struct Gen {
 }  // namespace
 
 std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32_t* code, size_t n_instr,
-                                 int result_reg, const std::vector<sdfk_cullsite>& sites) {
+                                 int result_reg, const std::vector<sdfk_cullsite>& sites, int flavour) {
+    const bool all = flavour == SDFK_FL_ALL;
+    const bool plain = all || flavour == SDFK_FL_PLAIN_ARRAY || flavour == SDFK_FL_PLAIN_GRID;
+    const bool tile = !sites.empty() && (all || flavour == SDFK_FL_TILE_ARRAY || flavour == SDFK_FL_TILE_GRID ||
+                                         flavour == SDFK_FL_TILE_MASK);
+    const bool rowk = !sites.empty() && (all || flavour == SDFK_FL_ROWS_ARRAY || flavour == SDFK_FL_ROWS_GRID ||
+                                         flavour == SDFK_FL_ROWS_MASK);
     Gen g{ops, n_ops, code, n_instr, &sites, std::string()};
     g.s.reserve(sizeof(kEmbeddedDevice) + sizeof(kEmbeddedAccess) + sizeof(kWrappers) + sizeof(kTileKernel) +
-                sizeof(kRowsKernel) + 800 * n_instr + 1024);
+                sizeof(kRowsKernel) + 800 * n_instr + 4096);
     g.s += kEmbeddedDevice;
     g.s += "\n";
     g.s += kEmbeddedAccess;
-    g.s += "\ntemplate <typename T> static __device__ __forceinline__ T sdfk_point(V3T<T> C_0, "
-           "const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ AUX, "
-           "long long AUXS) {\n";
-    g.declare("V3T<T>", "T", false);
-    for (size_t i = 0; i < n_instr; ++i) g.instr(i, "    ");
     char buf[64];
-    snprintf(buf, sizeof buf, "    return V_%d;\n}\n", result_reg);
-    g.s += buf;
-    g.s += kWrappers;
-    if (!sites.empty()) {
+    if (plain) {
+        g.s += "\ntemplate <typename T> static __device__ __forceinline__ T sdfk_point(V3T<T> C_0, "
+               "const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ AUX, "
+               "long long AUXS) {\n";
+        g.declare("V3T<T>", "T", false);
+        for (size_t i = 0; i < n_instr; ++i) g.instr(i, "    ");
+        snprintf(buf, sizeof buf, "    return V_%d;\n}\n", result_reg);
+        g.s += buf;
+        g.s += kWrappers;
+        if (all || flavour == SDFK_FL_PLAIN_ARRAY) g.s += kWrappersArray;
+        if (all || flavour == SDFK_FL_PLAIN_GRID) g.s += kWrappersGrid;
+    }
+    if (tile || rowk) g.s += kWaveHelpers;
+    if (tile) {
         // the flat tile kernel carries 62 mask bits: the first 31 sites; the row-block kernel takes 64
         // (the 31 widest, in program order)
         std::vector<size_t> order(sites.size());
@@ -959,13 +1060,23 @@ std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32
         g.emit_probe();
         g.emit_culled(result_reg);
         g.s += kTileKernel;
+        if (all || flavour == SDFK_FL_TILE_ARRAY) g.s += kTileArray;
+        if (all || flavour == SDFK_FL_TILE_GRID) g.s += kTileGrid;
+        if (all || flavour == SDFK_FL_TILE_MASK) g.s += kTileMask;
         g.sites = &sites;
+    }
+    if (rowk) {
         g.rows = true;
-        g.s += "\n#ifndef SDFK_NP\n#define SDFK_NP 4\n#endif\n"
-               "#define SDFK_EACH _Pragma(\"unroll\") for (int q = 0; q < SDFK_NP; ++q)\n";
+        g.root_slot.clear();
+        g.n_root = 0;
+        g.find_roots();
+        g.s += "\n#define SDFK_NP 4\n#define SDFK_EACH _Pragma(\"unroll\") for (int q = 0; q < SDFK_NP; ++q)\n";
         g.emit_probe();
         g.emit_rows_culled(result_reg);
         g.s += kRowsKernel;
+        if (all || flavour == SDFK_FL_ROWS_ARRAY) g.s += kRowsArray;
+        if (all || flavour == SDFK_FL_ROWS_GRID) g.s += kRowsGrid;
+        if (all || flavour == SDFK_FL_ROWS_MASK) g.s += kRowsMask;
     }
     return g.s;
 }

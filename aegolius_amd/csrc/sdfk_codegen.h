@@ -28,8 +28,22 @@ struct sdfk_cullsite {
 // Specialised per TOPOLOGY: opcodes, register operands and parameter offsets are baked into the
 // text; parameter VALUES stay in the runtime table (PRM), so one compiled kernel serves every
 // tree of the same shape.
+// One hiprtc translation unit per kernel FLAVOUR: a call needs one of them, and hiprtc's time is spent per
+// __global__ function (every flavour inlines the whole tree), so only what is launched is ever compiled.
+enum sdfk_flavour {
+    SDFK_FL_PLAIN_ARRAY = 0,   // sdfk_spec_v4 + sdfk_spec_v1
+    SDFK_FL_PLAIN_GRID,        // sdfk_spec_g4 + sdfk_spec_g1
+    SDFK_FL_TILE_ARRAY,        // sdfk_spec_t
+    SDFK_FL_TILE_GRID,         // sdfk_spec_tg
+    SDFK_FL_TILE_MASK,         // sdfk_spec_tmask (test aid)
+    SDFK_FL_ROWS_ARRAY,        // sdfk_spec_r
+    SDFK_FL_ROWS_GRID,         // sdfk_spec_rg
+    SDFK_FL_ROWS_MASK,         // sdfk_spec_rmask (test aid)
+    SDFK_FL_COUNT,
+    SDFK_FL_ALL = SDFK_FL_COUNT   // everything in one unit (sdfk_program_source, developer tools)
+};
 std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32_t* code, size_t n_instr,
-                                 int result_reg, const std::vector<sdfk_cullsite>& sites);
+                                 int result_reg, const std::vector<sdfk_cullsite>& sites, int flavour);
 
 // Text every chain-specialised vector kernel starts with: sdfk_device.h followed by sdfk_vecdev.h.
 std::string sdfk_vector_prelude();

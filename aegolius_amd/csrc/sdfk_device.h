@@ -755,9 +755,12 @@ SDFK_DEV float prim_nearest2(V3 p, const float* __restrict__ P, const float* __r
     return sd_sqrt(best);
 }
 // interior_polygon C/triangulation_functions.py:355-430 : -1 inside any convex piece, +1 outside.
-// P = (piece count, table offset) ; table: per piece  K, then K rows (px, py, nx, ny)
+// P = (piece count, table offset) ; table: per piece  K, then K rows (px, py, nx, ny).
+// piece count -1: ONE piece, and the value is interior_convex's own (:355-387): max over the edges of
+// sign(dot(p - p_k, n_k)), i.e. -1 inside, 0 on an edge line, +1 outside.
 SDFK_DEV float prim_polysign(V3 p, const float* __restrict__ P, const float* __restrict__ T) {
-    int np_ = (int)P[0];
+    const bool raw = P[0] < 0.0f;
+    int np_ = raw ? 1 : (int)P[0];
     const float* __restrict__ tab = T + (int)P[1];
     float interior = 1.0f;
     for (int j = 0; j < np_; ++j) {
@@ -767,6 +770,7 @@ SDFK_DEV float prim_polysign(V3 p, const float* __restrict__ P, const float* __r
             const float* __restrict__ h = tab + 1 + 4 * i;
             side = sd_max(side, sd_sign(sd_dot2(p.x - h[0], p.y - h[1], h[2], h[3])));
         }
+        if (raw) return side;
         interior = (side <= 0.0f) ? -1.0f : interior;
         tab += 1 + 4 * k;
     }

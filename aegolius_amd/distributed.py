@@ -51,6 +51,123 @@ def gather_slabs(local, n_total, group=None, unit=1):
     return out
 
 
+def chunk_bounds(count, chunks, unit=1):
+    """Cut `count` points into at most `chunks` contiguous pieces that start at multiples of `unit`:
+    [(offset, length)], equal lengths except the last (which also takes what is left of a partial unit), none empty."""
+    if unit < 1:
+        raise ValueError("unit must be positive")
+    if count <= 0:
+        return []
+    units = -(-count // unit)
+    chunks = max(1, min(int(chunks), units))
+    step = -(-units // chunks) * unit
+    return [(o, min(step, count - o)) for o in range(0, count, step)]
+
+
+def evaluate_gathered_overlapped(evaluate_chunk, full, n_total, unit=1, chunks=4, group=None, schedule="direct",
+                                 chunk_unit=None, local=None):
+    """Evaluate this rank's slab and reassemble the field in `full` (an (n_total,) tensor on every rank) WHILE it is
+    being computed.
+
+    The slab (slab_bounds with `unit`) is cut into `chunks` pieces that start at multiples of `chunk_unit` points of
+    the slab (default `unit`; the bench passes 32 rows so that every piece starts on a 128-byte line of the rank's own
+    buffers). `evaluate_chunk(start, count, out)` enqueues the evaluation of the flat range [start, start + count)
+    into `out` — a view of `local`, the rank's own slab buffer — on the current stream. As soon as a piece is done its
+    exchange starts on a second stream, so the transfer of piece i runs under the evaluation of piece i + 1 and only
+    the last piece's transfer is exposed.
+
+    schedule "direct"     each rank sends the piece to every peer and receives the peers' pieces in place, as ONE
+                          grouped point-to-point batch (RCCL send/recv): W - 1 transfers per rank that each use their
+                          own xGMI link — xGMI is point to point (7 links per GPU), a ring would relay every byte
+                          W - 1 times over one link pair. No staging buffer, no padding for the uneven last slab.
+    schedule "collective" all_gather_into_tensor per piece into a (W, piece) staging buffer + one strided copy into
+                          the field; the last rank's surplus rows travel by one broadcast.
+    Works on CPU tensors with gloo (no streams: the same calls in program order) — how the tests run it."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if full.numel() != n_total or not full.is_contiguous():
+        raise ValueError("`full` must be a contiguous tensor of n_total elements")
+    if schedule not in ("direct", "collective"):
+        raise ValueError("unknown schedule %r" % (schedule,))
+    chunk_unit = chunk_unit or unit
+    spans = [slab_bounds(n_total, world, r, unit) for r in range(world)]
+    start, count = spans[rank]
+    if local is None:
+        local = torch.empty(max(count, 1), dtype=full.dtype, device=full.device)
+    if local.numel() < count:
+        raise ValueError("`local` is smaller than the rank's slab")
+    cuda = full.is_cuda
+    comm = torch.cuda.Stream(device=full.device) if cuda else None
+    works = []
+
+    def on_comm(fn):
+        """run fn on the communication stream once everything enqueued so far on the current stream is done"""
+        if not cuda:
+            fn()
+            return
+        done = torch.cuda.Event()
+        done.record()
+        comm.wait_event(done)
+        with torch.cuda.stream(comm):
+            fn()
+
+    def exchange(i, pieces):
+        mine = pieces[rank][i] if i < len(pieces[rank]) else None
+        if mine is not None:                                   # the rank's own piece into its place in the field
+            o, c = mine
+            full[start + o:start + o + c].copy_(local[o:o + c])
+        if world == 1:
+            return
+        if schedule == "direct":
+            ops = []
+            for peer in range(world):
+                if peer == rank:
+                    continue
+                if mine is not None:
+                    ops.append(dist.P2POp(dist.isend, local[mine[0]:mine[0] + mine[1]], peer, group))
+                if i < len(pieces[peer]):
+                    o, c = pieces[peer][i]
+                    ps = spans[peer][0]
+                    ops.append(dist.P2POp(dist.irecv, full[ps + o:ps + o + c], peer, group))
+            if ops:
+                works.extend(dist.batch_isend_irecv(ops))
+        else:
+            o, c = pieces[0][i]                                # the common part: the same piece on every rank
+            stage = torch.empty((world, c), dtype=full.dtype, device=full.device)
+            dist.all_gather_into_tensor(stage.view(-1), local[o:o + c], group=group)
+            per = spans[0][1]
+            full[:world * per].view(world, per)[:, o:o + c].copy_(stage)
+
+    if schedule == "direct" or world == 1:
+        pieces = [chunk_bounds(c, chunks, chunk_unit) for _, c in spans]
+        steps = max(len(p) for p in pieces)
+    else:
+        per = spans[0][1]                                      # every rank cuts the common part alike;
+        pieces = [chunk_bounds(per, chunks, chunk_unit)] * world   # the last rank's surplus follows by broadcast
+        steps = len(pieces[0])
+    mine = pieces[rank]
+    for i in range(steps):
+        if i < len(mine):
+            o, c = mine[i]
+            evaluate_chunk(start + o, c, local[o:o + c])
+        on_comm(lambda i=i: exchange(i, pieces))
+    if schedule == "collective" and world > 1:
+        ls, lc = spans[-1]
+        per = spans[0][1]
+        if lc > per:                                           # surplus rows of the last slab
+            if rank == world - 1:
+                evaluate_chunk(ls + per, lc - per, local[per:lc])
+                on_comm(lambda: full[ls + per:ls + lc].copy_(local[per:lc]))
+            on_comm(lambda: dist.broadcast(full[ls + per:ls + lc], world - 1, group=group))
+    for w in works:
+        w.wait()
+    if cuda:
+        torch.cuda.current_stream(full.device).wait_stream(comm)
+    return full
+
+
 def evaluate_grid_sharded(geometry, size, resolution, gather=True, group=None, evaluate_slab=None):
     """Evaluate `geometry` on generate_grid(size, resolution), this rank computing only its slab.
 

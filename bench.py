@@ -9,17 +9,23 @@ SURVEY.md §8(d) "cfg 2 / north-star" recipe), coordinates resident in HBM, fiel
 
 One "step" = one evaluation of the whole grid. With N > 1 the flat point index is cut into N
 contiguous slabs (= slabs along x), one per rank/GPU, no data-path collective (the path is
-pointwise) -> strong scaling of the same grid. The RCCL all-gather that reassembles the field is
-timed separately after the timed region and reported under "allgather".
+pointwise) -> strong scaling of the same grid. Reassembling the field on every rank (RCCL over xGMI) is
+timed separately after the timed region and reported under "allgather", both after the fact and
+overlapped chunk-wise with the evaluation.
 
-The JSON line carries `roofline` (algorithmic 16 B/point over the live HIP-event kernel time, against
-the 8 TB/s HBM peak) and `cpu_baseline` (the NumPy oracle timed on this host on a bounded x-slab
-sample of the same grid).
+The JSON line carries
+  roofline      algorithmic 16 B/point over the live HIP-event kernel time, against the 8 TB/s HBM peak
+  verified      a random sample of the field the timed region produced, checked against the oracle
+  cpu_baseline  the NumPy oracle timed on this host on a bounded x-slab sample of the same grid
+  grid_512      the same tree on the 512^3-request grid (north_star names both sizes)
+  first_call    cold / warm-cache latency from program creation to the first field (hiprtc JIT)
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -30,6 +36,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 BYTES_PER_POINT = 16            # 3 x fp32 coordinate loads + 1 x fp32 store
+PMC_RECORD = os.path.join("profiles", "r02_pmc_traffic.json")   # static: counters cannot be read from inside a run
 
 
 def parse():
@@ -46,6 +53,9 @@ def parse():
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host_path extra (it launches the "
                     "same kernel on a small array, which skews per-kernel averages under rocprofv3)")
     ap.add_argument("--no-rows", action="store_true", help="do not pass the row-length layout hint (flat 128-point bricks)")
+    ap.add_argument("--no-extras", action="store_true", help="headline, roofline and verification only (profiling runs)")
+    ap.add_argument("--extras-timeout", type=float, default=240.0, help="N > 1: seconds the collective extras may take "
+                    "before the line is printed without them")
     return ap.parse_args()
 
 
@@ -94,6 +104,128 @@ def cpu_baseline(scenes, workload, axes, budget_s):
             "host_cpus": os.cpu_count()}
 
 
+def verify_sample(scenes, workload, axes, start, out, count, samples=20000, seed=11):
+    """The field the timed region left in `out`, at `samples` random points of this rank's slab, against the oracle
+    (float64 on the fp32-rounded coordinates: "identical grids"); tolerance of the parity tests, 1e-6 * max(1, |ref|)."""
+    import torch
+    import aegolius_amd.cores as ns
+    from oracle import sdf_oracle
+    tree, _size, _desc = build_workload(workload, ns, scenes)
+    rng = np.random.default_rng(seed)
+    idx = np.sort(rng.choice(count, size=min(samples, count), replace=False))
+    got = out[torch.from_numpy(idx).to(out.device)].cpu().numpy().astype(np.float64)
+    flat = idx + start
+    n1, n2 = int(axes[1].size), int(axes[2].size)
+    co = np.stack([axes[0][flat // (n1 * n2)], axes[1][(flat // n2) % n1], axes[2][flat % n2]]).astype(np.float64)
+    with np.errstate(all="ignore"):
+        ref = sdf_oracle.evaluate(tree, co)
+    err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+    return {"points": int(idx.size), "max_rel_err": float(err.max()), "tolerance": 1e-6,
+            "violations": int(np.count_nonzero(err > 1e-6)), "against": "oracle/sdf_oracle.evaluate (float64)",
+            "what": "random sample of the buffer the timed steps wrote"}
+
+
+_FIRST_CALL = r"""
+import json, sys, time
+t_import = time.perf_counter()
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+import numpy as np
+import scenes, bench
+import aegolius_amd.cores as ns
+from aegolius_amd import _engine
+_engine.require_gpu()
+co, _ = ns.generate_grid((2, 2, 2), (128, 128, 128))       # configs[0] size: where the reference needs 2.6 s per call
+ns.Sphere(0.25).create(co[:, :4096].copy())                  # device context, allocator: not part of the tree's latency
+t0 = time.perf_counter()
+tree, _size, _desc = bench.build_workload({workload!r}, ns, scenes)
+first = tree.create(co)
+t1 = time.perf_counter()
+second = tree.create(co)
+t2 = time.perf_counter()
+builds, build_s = _engine.jit_stats()
+print(json.dumps(dict(first_create_s=t1 - t0, second_create_s=t2 - t1, hiprtc_builds_so_far=builds,
+                      same_bits=bool(np.array_equal(first, second)))))
+"""
+
+
+def first_call_latency(workload):
+    """Program creation -> first field, in fresh processes (no torch import), on the 129^3 grid through the drop-in
+    API (`tree.create(co)` on a generate_grid array): cold with the disk cache off (AUTO: the interpreter kernel
+    serves the call while hiprtc builds in the background), cold when the call has to wait for the specialised kernel
+    (SDFK_ASYNC_JIT=0), and with a warm on-disk cache."""
+    import tempfile
+    script = _FIRST_CALL.format(root=ROOT, workload=workload)
+    out = {"grid": "129^3 via tree.create(generate_grid(...))"}
+
+    def run(tag, **env):
+        e = dict(os.environ)
+        e.update(env)
+        try:
+            res = subprocess.run([sys.executable, "-c", script], env=e, capture_output=True, text=True, timeout=300)
+            out[tag] = json.loads(res.stdout.strip().splitlines()[-1])
+        except Exception as exc:  # noqa: BLE001
+            out[tag] = {"error": repr(exc)}
+    with tempfile.TemporaryDirectory() as tmp:
+        run("cold_auto", SDFK_CACHE_DIR="off")
+        run("cold_wait_for_specialised", SDFK_CACHE_DIR="off", SDFK_ASYNC_JIT="0")
+        run("fill_cache", SDFK_CACHE_DIR=tmp, SDFK_ASYNC_JIT="0")
+        run("warm_cache", SDFK_CACHE_DIR=tmp, SDFK_ASYNC_JIT="0")
+    out.pop("fill_cache", None)
+    return out
+
+
+class Run:
+    """One resident grid on this rank: coordinates, field, and the timed loop."""
+
+    def __init__(self, torch, dist, engine, prog, axes, world, rank, dev, red_dev, mode, use_rows):
+        self.torch, self.dist, self.engine, self.prog = torch, dist, engine, prog
+        self.axes, self.world, self.rank, self.dev, self.red_dev, self.mode = axes, world, rank, dev, red_dev, mode
+        self.n_total = int(axes[0].size) * int(axes[1].size) * int(axes[2].size)
+        # contiguous slabs of the flat index, whole grid rows each (row = the last axis longer than 1);
+        # remainder to the last rank
+        self.row_len = int(axes[2].size) if axes[2].size > 1 else int(axes[1].size)
+        self.per = (self.n_total // self.row_len // world) * self.row_len
+        self.start = rank * self.per
+        self.count = self.per if rank < world - 1 else self.n_total - self.start
+        self.stride = (self.count + 255) // 256 * 256            # 16-byte aligned rows -> dwordx4 loads
+        self.co = torch.empty((3, self.stride), dtype=torch.float32, device=dev)
+        self.out = torch.empty((self.stride,), dtype=torch.float32, device=dev)
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.use_rows = use_rows
+        engine.grid_fill(self.co.data_ptr(), self.stride, axes, self.start, self.count, stream=self.stream)
+
+    def step(self):
+        self.prog.eval_device(self.co.data_ptr(), self.count, self.stride, self.out.data_ptr(), stream=self.stream,
+                              mode=self.mode, row_len=self.row_len if self.use_rows else None)
+
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def timed(self, steps, warmup):
+        """-> (elapsed seconds over `steps`, kernel ms per step, sorted per-step ms): MAX over ranks for the first two."""
+        for _ in range(warmup):
+            self.step()
+        ev = [self.engine.Event() for _ in range(steps + 1)]
+        self.fence()
+        t0 = time.perf_counter()
+        ev[0].record(self.stream)
+        for k in range(steps):
+            self.step()
+            ev[k + 1].record(self.stream)                      # HIP events on the launch stream
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = ev[0].elapsed_ms(ev[steps]) / steps
+        per_step = sorted(ev[k].elapsed_ms(ev[k + 1]) for k in range(steps))
+        t = self.torch.tensor([elapsed, kernel_ms, per_step[len(per_step) // 2], per_step[0]], dtype=self.torch.float64,
+                              device=self.red_dev)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t[0]), float(t[1]), float(t[2]), float(t[3])
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,116 +262,193 @@ def main():
     import scenes
     import aegolius_amd.cores as ns
     from aegolius_amd import _engine
+    from aegolius_amd import distributed as sdist
     from aegolius_amd._lower import lower_geometry
     from aegolius_amd.cores.helper_functions import grid_axes
     _engine.lib()  # fail loudly if the HIP extension is missing
 
     tree, size, desc = build_workload(args.workload, ns, scenes)
-    axes64, res = grid_axes(size, (args.grid,) * len(size))
-    axes = [a.astype(np.float32) for a in axes64]           # fp32-rounded float64 linspace ("identical grids")
-    n_total = int(axes[0].size) * int(axes[1].size) * int(axes[2].size)
-    # contiguous slabs of the flat index, whole grid rows each (row = the last axis longer than 1);
-    # remainder to the last rank
-    row_len = int(axes[2].size) if axes[2].size > 1 else int(axes[1].size)
-    per = (n_total // row_len // world) * row_len
-    start = rank * per
-    count = per if rank < world - 1 else n_total - start
 
-    stride = (count + 255) // 256 * 256                      # 16-byte aligned rows -> dwordx4 loads
-    co = torch.empty((3, stride), dtype=torch.float32, device=dev)
-    out = torch.empty((stride,), dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    _engine.grid_fill(co.data_ptr(), stride, axes, start, count, stream=stream)
+    def fp32_axes(request):
+        axes64, _res = grid_axes(size, (request,) * len(size))
+        return [a.astype(np.float32) for a in axes64]       # fp32-rounded float64 linspace ("identical grids")
+    axes = fp32_axes(args.grid)
 
     low = lower_geometry(tree)
     prog = _engine.Program.from_lowered(low)
+    # the timed region always waits for the specialised kernel (AUTO would serve the first calls from the interpreter
+    # while hiprtc builds in the background: measured separately under "first_call")
     mode = {"interpret": _engine.MODE_INTERPRET, "nocull": _engine.MODE_NOCULL}.get(args.mode, _engine.MODE_SPECIALIZED)
     culled = mode == _engine.MODE_SPECIALIZED and len(low.cull_sites) > 0
 
-    def step():
-        prog.eval_device(co.data_ptr(), count, stride, out.data_ptr(), stream=stream, mode=mode,
-                         row_len=None if args.no_rows else row_len)
+    run = Run(torch, dist, _engine, prog, axes, world, rank, dev, red_dev, mode, not args.no_rows)
+    n_total, count, start, stride, row_len, stream = run.n_total, run.count, run.start, run.stride, run.row_len, run.stream
+    t_build = time.perf_counter()
+    run.step()                                                # builds (or loads from the disk cache) this flavour
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+    elapsed, kernel_ms_max, median_ms, min_ms = run.timed(args.steps, args.warmup)
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    ev0, ev1 = _engine.Event(), _engine.Event()
-    fence()
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    ev1.record(stream)
-    fence()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_ms(ev1) / args.steps            # HIP events on the launch stream
-
-    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=red_dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, kernel_ms_max = float(t[0]), float(t[1])
-
-    # ---- extras outside the timed region ----
-    probe_gbps = None
+    line = None
     if rank == 0:
-        n4 = count // 4 * 4
-        lib = _engine.lib()
-        for _ in range(2):
-            _engine.check(lib.sdfk_stream_probe(co.data_ptr(), n4, stride, out.data_ptr(), stream), "probe")
-        p0, p1 = _engine.Event(), _engine.Event()
-        p0.record(stream)
-        for _ in range(5):
-            _engine.check(lib.sdfk_stream_probe(co.data_ptr(), n4, stride, out.data_ptr(), stream), "probe")
-        p1.record(stream)
-        probe_gbps = BYTES_PER_POINT * n4 / (p0.elapsed_ms(p1) / 5 * 1e-3) / 1e9
-        step()                                                # restore `out`
-        torch.cuda.synchronize()
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n_total * args.steps / elapsed / 1e6
+        achieved = BYTES_PER_POINT * count / (kernel_ms_max * 1e-3) / 1e9
+        traffic = valu_busy = traffic_source = None
+        pmc = os.path.join(ROOT, PMC_RECORD)
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("points_per_launch") == count and rec.get("workload") == args.workload:
+                    traffic = rec.get("hbm_bytes_per_launch")
+                    valu_busy = rec.get("valu_active_frac")
+                    traffic_source = "%s (static record of a separate rocprofv3 --pmc run of this kernel, commit %s; not " \
+                                     "measured by this run)" % (PMC_RECORD, rec.get("commit", "?"))
+            except Exception:  # noqa: BLE001
+                traffic = None
+        line = {
+            "metric": "Mpoints/sec SDF eval, 1024^3 grid, 10-prim smooth-union tree",
+            "value": value, "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "median_ms": median_ms, "min_ms": min_ms,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "grid": "%dx%dx%d (request %d per axis), size %s" % (
+                axes[0].size, axes[1].size, axes[2].size, args.grid, tuple(size)),
+                       "points": n_total, "points_per_gpu": count, "sharding": "contiguous x-slabs, no collective",
+                       "kernel": (("sdfk_spec_t (hiprtc, topology-specialised, exact culling on 128-point bricks)" if args.no_rows else
+                                   "sdfk_spec_r (hiprtc, topology-specialised, exact culling on 32x16-point row blocks)")
+                                  if culled else
+                                  "sdfk_spec_v4 (hiprtc, topology-specialised)") if mode != _engine.MODE_INTERPRET
+                       else "sdfk_interp_kernel", "instructions": int(low.code.shape[0]),
+                       "cull_sites": int(len(low.cull_sites)) if culled else 0},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel_ms": kernel_ms_max, "kernel_ms_median": median_ms, "kernel_ms_min": min_ms,
+                         "bytes_per_point": BYTES_PER_POINT, "valu_active_frac": valu_busy},
+            "first_kernel_build_s": t_build,
+        }
 
-    # the same evaluation straight from the per-axis tables (no coordinate array: 4 B/point) -- a separate line
-    grid_path = None
-    if rank == 0:
-        for _ in range(2):
-            prog.eval_grid(axes, start, count, out.data_ptr(), stream=stream, mode=mode)
-        torch.cuda.synchronize()
-        g0 = time.perf_counter()
-        for _ in range(5):
-            prog.eval_grid(axes, start, count, out.data_ptr(), stream=stream, mode=mode)
-        torch.cuda.synchronize()
-        gms = (time.perf_counter() - g0) / 5 * 1e3
-        grid_path = {"ms": gms, "mpoints_per_s": count / gms / 1e3, "bytes_per_point": 4,
-                     "note": "sdfk_eval_grid: coordinates expanded in-kernel from three axis tables; includes the "
-                             "per-call table upload and stream sync"}
+    # N > 1: whatever happens in the collective extras, rank 0 prints the headline line and every rank leaves
+    printed = threading.Event()
 
-    # end to end through host memory (PCIe inclusive): create()-style call on a plain (3, M) float32 host array of
-    # whole x-planes of the same grid, bounded size — a separate line, never `value`
-    host_path = None
-    if rank == 0 and world == 1 and not args.no_host_path:
-        planes = max(1, min(int(axes[0].size), int(2.5e7 // (axes[1].size * axes[2].size))))
-        m = planes * int(axes[1].size) * int(axes[2].size)
-        hco = np.empty((3, m), dtype=np.float32)
-        hco[0] = np.repeat(axes[0][:planes], axes[1].size * axes[2].size)
-        hco[1] = np.tile(np.repeat(axes[1], axes[2].size), planes)
-        hco[2] = np.tile(axes[2], planes * axes[1].size)
-        prog.eval_host(hco, device=local_rank, mode=mode)          # warm-up (allocations)
-        h0 = time.perf_counter()
-        prog.eval_host(hco, device=local_rank, mode=mode)
-        hms = (time.perf_counter() - h0) * 1e3
-        host_path = {"ms": hms, "points": m, "mpoints_per_s": m / hms / 1e3, "bytes_over_pcie_per_point": 16,
-                     "note": "sdfk_eval_host: pageable host (3, M) float32 in, (M,) float32 out, synchronous staging"}
-        del hco
+    def emit():
+        if rank == 0 and not printed.is_set():
+            printed.set()
+            print(json.dumps(line), flush=True)
 
-    # the consumers of the field on the field this run has just produced, resident in HBM: separate
-    # numbers, never `value`; any failure is reported, not raised (the headline line must survive)
-    next_rows = None
-    if rank == 0 and world == 1 and not args.no_next_rows:
+    def watchdog():
+        if rank == 0:
+            line["extras_timeout"] = True
+        emit()
+        sys.stdout.flush()
+        os._exit(0)
+    timer = None
+    if world > 1 and not args.no_extras:
+        timer = threading.Timer(args.extras_timeout, watchdog)
+        timer.daemon = True
+        timer.start()
+
+    def extra(name, fn):
+        """an extra outside the timed region: a failure is reported in the line, never raised"""
         try:
+            val = fn()
+        except Exception as exc:  # noqa: BLE001
+            val = {"error": repr(exc)}
+        if line is not None and val is not None:
+            line[name] = val
+
+    # ---- the field the timed steps wrote, against the oracle (every rank checks its slab; rank 0 reports) ----
+    def verified():
+        v = verify_sample(scenes, args.workload, axes, start, run.out, count)
+        if world > 1:
+            t = torch.tensor([v["max_rel_err"], float(v["violations"])], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            v["max_rel_err"], v["violations"] = float(t[0]), int(t[1])
+            v["what"] += " (every rank samples its own slab; worst rank reported)"
+        return v
+    extra("verified", verified)
+
+    if not args.no_extras:
+        lib = _engine.lib()
+
+        # ---- plain (3,N)->(N) stream with the same access width: what this box delivers ----
+        def stream_probe():
+            n4 = count // 4 * 4
+            scratch = torch.empty_like(run.out)
+            for _ in range(2):
+                _engine.check(lib.sdfk_stream_probe(run.co.data_ptr(), n4, stride, scratch.data_ptr(), stream), "probe")
+            p0, p1 = _engine.Event(), _engine.Event()
+            p0.record(stream)
+            for _ in range(5):
+                _engine.check(lib.sdfk_stream_probe(run.co.data_ptr(), n4, stride, scratch.data_ptr(), stream), "probe")
+            p1.record(stream)
+            return BYTES_PER_POINT * n4 / (p0.elapsed_ms(p1) / 5 * 1e-3) / 1e9
+        if rank == 0:
+            try:
+                line["roofline"]["stream_probe_gbps"] = stream_probe()
+            except Exception as exc:  # noqa: BLE001
+                line["roofline"]["stream_probe_gbps"] = None
+                line["roofline"]["stream_probe_error"] = repr(exc)
+
+        # ---- the 512^3-request grid, same tree, same slab partition (north_star names both sizes) ----
+        def grid_512():
+            ax = fp32_axes(512)
+            r2 = Run(torch, dist, _engine, prog, ax, world, rank, dev, red_dev, mode, not args.no_rows)
+            e2, k2, med2, min2 = r2.timed(max(10, args.steps), 3)
+            steps2 = max(10, args.steps)
+            v = verify_sample(scenes, args.workload, ax, r2.start, r2.out, r2.count, samples=5000)
+            return {"grid": "%dx%dx%d" % (ax[0].size, ax[1].size, ax[2].size), "points": r2.n_total, "steps": steps2,
+                    "value": r2.n_total * steps2 / e2 / 1e6, "unit": "Mpoints/s", "ms_per_step": e2 / steps2 * 1e3,
+                    "kernel_ms": k2, "kernel_ms_median": med2, "kernel_ms_min": min2,
+                    "roofline_frac": BYTES_PER_POINT * r2.count / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "verified": {"points": v["points"], "max_rel_err": v["max_rel_err"], "violations": v["violations"]}}
+        if len(size) == 3 and args.grid != 512:
+            extra("grid_512", grid_512)
+
+    if not args.no_extras and rank == 0 and world == 1:
+        # the same evaluation straight from the per-axis tables (no coordinate array: 4 B/point) -- a separate line
+        def grid_path():
+            scratch = torch.empty_like(run.out)
+            for _ in range(2):
+                prog.eval_grid(axes, start, count, scratch.data_ptr(), stream=stream, mode=mode)
+            torch.cuda.synchronize()
+            g0 = time.perf_counter()
+            for _ in range(5):
+                prog.eval_grid(axes, start, count, scratch.data_ptr(), stream=stream, mode=mode)
+            torch.cuda.synchronize()
+            gms = (time.perf_counter() - g0) / 5 * 1e3
+            return {"ms": gms, "mpoints_per_s": count / gms / 1e3, "bytes_per_point": 4,
+                    "note": "sdfk_eval_grid: coordinates expanded in-kernel from three axis tables; includes the "
+                            "per-call table upload and stream sync"}
+        extra("grid_path", grid_path)
+
+        # end to end through host memory (PCIe inclusive): create()-style call on a plain (3, M) float32 host array of
+        # whole x-planes of the same grid, bounded size — a separate line, never `value`
+        def host_path():
+            planes = max(1, min(int(axes[0].size), int(1.0e8 // (axes[1].size * axes[2].size))))
+            m = planes * int(axes[1].size) * int(axes[2].size)
+            hco = np.empty((3, m), dtype=np.float32)
+            hco[0] = np.repeat(axes[0][:planes], axes[1].size * axes[2].size)
+            hco[1] = np.tile(np.repeat(axes[1], axes[2].size), planes)
+            hco[2] = np.tile(axes[2], planes * axes[1].size)
+            prog.eval_host(hco, device=local_rank, mode=mode)          # warm-up (allocations, pinned staging)
+            best = 1e30
+            for _ in range(3):
+                h0 = time.perf_counter()
+                prog.eval_host(hco, device=local_rank, mode=mode)
+                best = min(best, (time.perf_counter() - h0) * 1e3)
+            return {"ms": best, "points": m, "mpoints_per_s": m / best / 1e3, "bytes_over_pcie_per_point": 16,
+                    "gbytes_per_s_over_pcie": 16.0 * m / best / 1e6,
+                    "note": "sdfk_eval_host: pageable host (3, M) float32 in, (M,) float32 out"}
+        if not args.no_host_path:
+            extra("host_path", host_path)
+
+        # the consumers of the field (SURVEY §8(f).3) on the field this run has just produced, resident in HBM: separate
+        # numbers, never `value`
+        def next_rows():
             import ctypes
-            lib, vp = _engine.lib(), ctypes.c_void_p
+            vp = ctypes.c_void_p
+            out = run.out
             torch.cuda.synchronize()
             scratch = torch.empty(lib.sdfk_field_select_scratch(count), dtype=torch.uint8, device=dev)
             selected = ctypes.c_int64(0)
@@ -272,23 +481,22 @@ def main():
                                                       vp(vec.data_ptr()), stride, vp(stream)), "sdfk_field_gradient")
             # a vector-field chain (§8(f).4) on the run's coordinates with the run's field as the per-point angle:
             # radial-cylindrical field, turned about z by the SDF value, revolved about x, normalised (28 B/point)
-            import aegolius_amd.cores as ns_cores
             from aegolius_amd import _vector
             tiny = np.zeros((3, 8))
-            vf = ns_cores.RadialCylindricalVectorField()
+            vf = ns.RadialCylindricalVectorField()
             vf.rotate_phi(np.zeros(8))
             vf.revolution_x(tiny)
             vf.normalize()
             vprog = _vector.program_array(_vector.lower_only(vf.vf, tiny, ())[0])
 
             def chain():
-                _engine.check(lib.sdfk_vec_eval_device(vprog, len(vprog), vp(co.data_ptr()), count, stride, vp(out.data_ptr()), 1,
+                _engine.check(lib.sdfk_vec_eval_device(vprog, len(vprog), vp(run.co.data_ptr()), count, stride, vp(out.data_ptr()), 1,
                                                        stride, 0, vp(vec.data_ptr()), stride, vp(stream)), "sdfk_vec_eval_device")
             chain()                                               # builds the kernel of this chain shape: not timed
             torch.cuda.synchronize()
             sel_ms, grad_ms, chain_ms = best_ms(select), best_ms(gradient), best_ms(chain)
             sel_bytes = 4.0 * count + 8.0 * selected.value
-            next_rows = {
+            return {
                 "interior_selection": {"ms": sel_ms, "selected": selected.value, "bytes": sel_bytes,
                                        "frac_of_hbm_peak": sel_bytes / (sel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
                 "gradient_direction": {"ms": grad_ms, "bytes": (12.0 if flat else 16.0) * count,
@@ -298,70 +506,64 @@ def main():
                                  "frac_of_hbm_peak": 28.0 * count / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
                 "note": "sdfk_field_select (+ _finish), sdfk_field_gradient and a 4-instruction vector-field chain "
                         "(sdfk_vec_eval_device) on the resident coordinates / field of this run"}
-            del scratch, index, vec
-        except Exception as exc:  # noqa: BLE001
-            next_rows = {"error": repr(exc)}
+        if not args.no_next_rows:
+            extra("next_rows", next_rows)
 
-    allgather = None
-    if world > 1 and not args.no_allgather and not rehearse:
-        pad = (n_total - (world - 1) * per)                   # largest slab
-        send = out[:pad].contiguous()
-        full = torch.empty((world * pad,), dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(full, send)               # warm-up (RCCL over xGMI)
-        fence()
-        g0 = time.perf_counter()
-        dist.all_gather_into_tensor(full, send)
-        fence()
-        gt = torch.tensor([time.perf_counter() - g0], dtype=torch.float64, device=dev)
-        dist.all_reduce(gt, op=dist.ReduceOp.MAX)
-        allgather = {"ms": float(gt[0]) * 1e3, "bytes_per_rank": int(pad * 4),
-                     "mpoints_per_s_with_gather": n_total / (elapsed / args.steps + float(gt[0])) / 1e6}
-        del full
+    # ---- reassembling the field on every rank (RCCL over xGMI): never part of `value` ----
+    if world > 1 and not args.no_allgather and not args.no_extras and not rehearse:
+        def allgather():
+            res = {"bytes_per_rank": int(count * 4), "compute_ms_per_step": elapsed / args.steps * 1e3}
+            local = run.out[:count]
+            full = sdist.gather_slabs(local, n_total, unit=row_len)          # warm-up (RCCL communicators, buffers)
+            run.fence()
+            g0 = time.perf_counter()
+            full = sdist.gather_slabs(local, n_total, unit=row_len)
+            run.fence()
+            gt = torch.tensor([time.perf_counter() - g0], dtype=torch.float64, device=dev)
+            dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+            res["after_compute"] = {"gather_ms": float(gt[0]) * 1e3, "schedule": "all_gather_into_tensor after the evaluation",
+                                    "mpoints_per_s_with_gather": n_total / (elapsed / args.steps + float(gt[0])) / 1e6}
+            del full
+            full = torch.empty(n_total, dtype=torch.float32, device=dev)
 
+            def evaluate_chunk(cstart, ccount, out_view):
+                off = cstart - start
+                prog.eval_device(run.co.data_ptr() + 4 * off, ccount, stride, out_view.data_ptr(), stream=stream, mode=mode,
+                                 row_len=row_len if not args.no_rows else None)
+            for schedule in ("direct", "collective"):
+                try:
+                    def once():
+                        sdist.evaluate_gathered_overlapped(evaluate_chunk, full, n_total, unit=row_len, chunks=8, schedule=schedule,
+                                                           chunk_unit=32 * row_len, local=run.out)
+                    once()                                                    # warm-up
+                    run.fence()
+                    o0 = time.perf_counter()
+                    once()
+                    run.fence()
+                    ot = torch.tensor([time.perf_counter() - o0], dtype=torch.float64, device=dev)
+                    dist.all_reduce(ot, op=dist.ReduceOp.MAX)
+                    idx = torch.randint(0, n_total, (4096,), device=dev)
+                    same = torch.tensor([1.0], device=dev)
+                    mine = (idx >= start) & (idx < start + count)
+                    if not torch.equal(full[idx[mine]], run.out[idx[mine] - start]):
+                        same[0] = 0.0
+                    dist.all_reduce(same, op=dist.ReduceOp.MIN)
+                    res["overlapped_" + schedule] = {"evaluate_and_gather_ms": float(ot[0]) * 1e3, "chunks": 8,
+                                                     "mpoints_per_s_with_gather": n_total / float(ot[0]) / 1e6,
+                                                     "own_slab_intact": bool(same[0] > 0)}
+                except Exception as exc:  # noqa: BLE001
+                    res["overlapped_" + schedule] = {"error": repr(exc)}
+            return res
+        extra("allgather", allgather)
+
+    if timer is not None:
+        timer.cancel()
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = n_total * args.steps / elapsed / 1e6
-        achieved = BYTES_PER_POINT * count / (kernel_ms_max * 1e-3) / 1e9
-        traffic = valu_busy = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                rec = json.load(open(pmc))
-                if rec.get("points_per_launch") == count and rec.get("workload") == args.workload:
-                    traffic = rec.get("hbm_bytes_per_launch")
-                    valu_busy = rec.get("valu_active_frac")
-            except Exception:  # noqa: BLE001
-                traffic = None
-        line = {
-            "metric": "Mpoints/sec SDF eval, 1024^3 grid, 10-prim smooth-union tree",
-            "value": value, "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "grid": "%dx%dx%d (request %d per axis), size %s" % (
-                axes[0].size, axes[1].size, axes[2].size, args.grid, tuple(size)),
-                       "points": n_total, "points_per_gpu": count, "sharding": "contiguous x-slabs, no collective",
-                       "kernel": (("sdfk_spec_t (hiprtc, topology-specialised, exact culling on 128-point bricks)" if args.no_rows else
-                                   "sdfk_spec_r (hiprtc, topology-specialised, exact culling on 32x16-point row blocks)")
-                                  if culled else
-                                  "sdfk_spec_v4 (hiprtc, topology-specialised)") if mode != _engine.MODE_INTERPRET
-                       else "sdfk_interp_kernel", "instructions": int(low.code.shape[0]),
-                       "cull_sites": int(len(low.cull_sites)) if culled else 0},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel_ms": kernel_ms_max, "bytes_per_point": BYTES_PER_POINT,
-                         "stream_probe_gbps": probe_gbps, "valu_active_frac": valu_busy},
-        }
-        if host_path:
-            line["host_path"] = host_path
-        if grid_path:
-            line["grid_path"] = grid_path
-        if next_rows:
-            line["next_rows"] = next_rows
-        if allgather:
-            line["allgather"] = allgather
+        if world == 1 and not args.no_extras:
+            extra("first_call", lambda: first_call_latency(args.workload))
         if world == 1 and args.cpu_seconds > 0:
-            line["cpu_baseline"] = cpu_baseline(scenes, args.workload, axes, args.cpu_seconds)
-        print(json.dumps(line), flush=True)
+            extra("cpu_baseline", lambda: cpu_baseline(scenes, args.workload, axes, args.cpu_seconds))
+        emit()
 
     if world > 1:
         dist.barrier()

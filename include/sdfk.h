@@ -26,10 +26,13 @@ extern "C" {
 #define SDFK_ABI_VERSION 1
 
 /* evaluation modes for sdfk_eval_device / sdfk_set_default_mode */
-#define SDFK_MODE_AUTO 0        /* topology-specialised kernel (hiprtc), built on first use and cached; programs beyond
-                                   SDFK_SPECIALIZE_LIMIT (env, default 600) instructions run on the interpreter kernel */
+#define SDFK_MODE_AUTO 0        /* topology-specialised kernel (hiprtc): only the kernel flavour a call launches is built,
+                                   in a background thread, and cached (per process and on disk); until it is ready calls
+                                   are served by the interpreter kernel (bit-identical results; SDFK_ASYNC_JIT=0: wait
+                                   instead). Programs beyond SDFK_SPECIALIZE_LIMIT (env, default 1200) instructions stay
+                                   on the interpreter kernel */
 #define SDFK_MODE_INTERPRET 1   /* generic register-machine interpreter kernel */
-#define SDFK_MODE_SPECIALIZED 2 /* as AUTO but fail instead of falling back if hiprtc fails */
+#define SDFK_MODE_SPECIALIZED 2 /* wait for the specialised kernel; fail instead of falling back if hiprtc fails */
 #define SDFK_MODE_NOCULL 3      /* specialised kernel with brick culling switched off (A/B runs, tests) */
 
 typedef struct sdfk_program sdfk_program;
@@ -68,6 +71,24 @@ const char* sdfk_program_source(sdfk_program* prog);
 /* Compile the specialised kernel for gfx950 with hiprtc without needing a GPU (build check).
  * Returns 0 and the code-object size in *code_size. */
 int sdfk_program_compile_check(sdfk_program* prog, size_t* code_size);
+/* Kernel flavours: one hiprtc translation unit each, built only when a call needs it. */
+#define SDFK_FLAVOUR_PLAIN_ARRAY 0 /* sdfk_spec_v4 / v1: straight-line body on a (3, n) array */
+#define SDFK_FLAVOUR_PLAIN_GRID 1  /* the same from per-axis grid tables */
+#define SDFK_FLAVOUR_TILE_ARRAY 2  /* exact culling on bricks of 128 consecutive points */
+#define SDFK_FLAVOUR_TILE_GRID 3
+#define SDFK_FLAVOUR_TILE_MASK 4   /* test aid (sdfk_debug_brick_masks) */
+#define SDFK_FLAVOUR_ROWS_ARRAY 5  /* exact culling on blocks of 32 points x 16 grid rows (sdfk_eval_device_rows) */
+#define SDFK_FLAVOUR_ROWS_GRID 6
+#define SDFK_FLAVOUR_ROWS_MASK 7   /* test aid (sdfk_debug_row_masks) */
+/* Build (or fetch from the caches) ONE flavour, GPU or not: its code-object size and the seconds this call took. */
+int sdfk_program_compile_flavour(sdfk_program* prog, int flavour, size_t* code_size, double* seconds);
+/* Wait until no background kernel build is queued or running (call before the process tears hiprtc down: the Python
+ * layer registers it with atexit). */
+void sdfk_jit_drain(void);
+/* hiprtc builds this process has actually run (cache hits excluded) and the seconds they took. */
+void sdfk_debug_jit_stats(int64_t* builds, double* seconds);
+/* Extra -D switches handed to hiprtc for kernels built from now on (experiments; also env SDFK_RTC_DEFS). */
+void sdfk_debug_set_rtc_defs(const char* defs);
 
 /* ---- evaluation ------------------------------------------------------------------------------
  * Replaces GenericGeometry.create / propagate (cores/geom.py:29-60) for one whole tree:

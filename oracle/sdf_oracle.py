@@ -464,7 +464,113 @@ def triangulate(vs):                            # :81-105
     return tris
 
 
-def interior_polygon(co, points):               # :390-430 (simple polygons)
+def check_intersection_all(vs):                 # :128-183 (debug prints omitted)
+    ixs = np.linspace(0, vs.shape[1] + 1, vs.shape[1] + 1, endpoint=False, dtype=int)
+    ixs[-1] = 0
+    mask = np.zeros(vs.shape[1] + 1, dtype=bool)
+    vs = vs[:, ixs]
+    six, eix, cs = [], [], []
+    for c in range(vs.shape[1] - 2):
+        m1, m2 = mask.copy(), mask.copy()
+        m1[c + 1:-1] = True
+        m2[c + 2:] = True
+        x, y = vs[:2, m1], vs[:2, m2]
+        v, u = y - x, vs[:2, c + 1] - vs[:2, c]
+        v, u = v / norm(v, axis=0), u / norm(u)
+        dot_mask = np.abs(v[0] * u[0] + v[1] * u[1]) == 1
+        x, y = x[:, ~dot_mask], y[:, ~dot_mask]
+        m1[m1] = ~dot_mask
+        if x.size == 0 or y.size == 0:
+            continue
+        v1, v2 = vs[:2, c], vs[:2, c + 1]           # check_intersection :108-125
+        b = (v2[0] - v1[0]) * (y[1] - x[1]) - (v2[1] - v1[1]) * (y[0] - x[0])
+        t1 = ((x[0] - v1[0]) * (y[1] - x[1]) - (x[1] - v1[1]) * (y[0] - x[0])) / b
+        t2 = ((x[0] - v1[0]) * (v2[1] - v1[1]) - (x[1] - v1[1]) * (v2[0] - v1[0])) / b
+        hit = (t1 > 0) * (t1 < 1) * (t2 > 0) * (t2 < 1)
+        if np.any(hit):
+            six.append(c)
+            eix.append(ixs[m1][hit])
+            cs.append(np.asarray((v1[0] + (v2[0] - v1[0]) * t1, v1[1] + (v2[1] - v1[1]) * t1))[:, hit])
+    return six, eix, cs
+
+
+def create_points_sets(vs, idata):              # :186-302 (debug prints omitted)
+    nv = vs.shape[1]
+    leading_ixs = idata[0]
+    cross_ixs = np.asarray(idata[1])            # ragged crossing counts: ValueError, as in the reference
+    coors = np.asarray(idata[2])
+    n_intersections = cross_ixs.size
+    intersection_ixs = np.linspace(0, n_intersections, n_intersections, endpoint=False, dtype=int) + nv
+    c_cross_ixs = np.concatenate(cross_ixs, axis=0)
+    groups = []
+    c = 0
+    for i in range(len(leading_ixs)):
+        for j in range(cross_ixs[i].size):
+            groups.append([leading_ixs[i], int(intersection_ixs[c]), int(np.mod(cross_ixs[i][j] + 1, nv))])
+            groups.append([int(cross_ixs[i][j]), int(intersection_ixs[c]), int(np.mod(leading_ixs[i] + 1, nv))])
+            c += 1
+    i = 0
+    for _v in range(len(groups)):
+        group_reformat = 0
+        group = np.squeeze(groups[i]).tolist()
+        for g in range(len(groups)):
+            if g == i:
+                continue
+            if group[0] == groups[g][-1] and group[-1] == groups[g][0]:
+                group = np.concatenate((group, groups[g][1:-1])).tolist()
+                group_reformat = 1
+                break
+            c4 = group[1] - groups[g][1] == -1
+            c5 = int(np.mod(group[0] + 1, nv)) == groups[g][2]
+            c10 = (group[0] < group[2]) + (groups[g][0] < groups[g][2])
+            c3 = (group[1] == intersection_ixs[0]) * (groups[g][1] == intersection_ixs[-1])
+            c6 = int(np.mod(groups[g][0] + 1, nv)) == group[2]
+            c7 = len(group) == 3 and len(groups[g]) == 3
+            c8 = group[0] in leading_ixs
+            c9 = (group[2] not in intersection_ixs) and (group[0] not in intersection_ixs)
+            c11 = group[1] != groups[g][1]          # (`is not` on small ints in the reference)
+            if c4 * c5 * c7 * c10:
+                group = [groups[g][0], groups[g][1], group[1], group[-1]]
+                if group[0] == group[-1]:
+                    group = group[:-1]
+                group_reformat = 1
+                break
+            if c3 * c6 * c7 * c8 * c9 * c11:
+                group = [group[0], group[1], groups[g][1], groups[g][2]]
+                if group[0] == group[-1]:
+                    group = group[:-1]
+                group_reformat = 1
+                break
+        if group_reformat:
+            groups[i] = group
+            groups = [groups[k] for k in range(len(groups)) if not k == g]
+            continue
+        for _j in range(nv):
+            if (group[-1] not in c_cross_ixs) and (group[-1] not in leading_ixs):
+                if np.mod(group[-1] + 1, nv) == group[0]:
+                    break
+                elif group[-1] >= nv - 1:
+                    pass
+                else:
+                    group.append(group[-1] + 1)
+            if (group[0] not in c_cross_ixs) and (group[0] - 1 not in leading_ixs):
+                if np.mod(group[-1] + 1, nv) == group[0]:
+                    break
+                elif group[0] == 0 or group[0] >= nv:
+                    pass
+                else:
+                    group.append(group[0] - 1)
+        groups[i] = group
+        i += 1
+        if i == len(groups):
+            break
+    coors_c = np.reshape(np.moveaxis(coors, 1, 0), (2, n_intersections))
+    evs = np.concatenate((vs[:2, :], coors_c), axis=1)
+    evs = np.concatenate((evs, np.zeros((1, evs.shape[1]))), axis=0)
+    return [evs[:, [int(q) for q in groups[i]]] for i in range(n_intersections + 1)]
+
+
+def interior_polygon(co, points):               # :390-430
     points = np.array(points, dtype=float)
     if points.shape[0] == 2:
         points = np.concatenate([points, np.zeros((1, points.shape[1]))])
@@ -478,6 +584,12 @@ def interior_polygon(co, points):               # :390-430 (simple polygons)
     elif np.all(conv <= 0):
         interior[interior_convex(co, points[:, ::-1]) <= 0] = -1
     else:
+        with np.errstate(all="ignore"):
+            intersection_data = check_intersection_all(points)
+        if intersection_data[0]:                # self-intersecting outline: union of its loops (:403-412)
+            for new_points in create_points_sets(points, intersection_data):
+                interior[interior_polygon(co, new_points) <= 0] = -1
+            return interior
         if np.count_nonzero(conv >= 0) < points.shape[0] // 2:
             points = points[:, ::-1]
         for t in triangulate(points):

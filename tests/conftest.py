@@ -37,3 +37,10 @@ def golden():
 @pytest.fixture(scope="session")
 def golden_inputs(golden):
     return golden[0]["inputs"].astype(np.float64)
+
+
+@pytest.fixture(scope="session")
+def engine(built):
+    """The ctypes engine on a box with an MI355X (GPU tests only): there is no CPU evaluation path."""
+    built.require_gpu()
+    return built

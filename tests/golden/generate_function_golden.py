@@ -1,0 +1,83 @@
+"""Golden vectors of the reference's ARRAY-LEVEL functions — runs ONLY in the build container (imports the real
+SPOMSO from /root/reference). Inputs (fp32-representable float64) and float64 outputs of
+  * the scalar post-processing functions  (reference cores/post_processing.py:380-642),
+  * the smooth kernels                    (reference cores/combine.py:12-34),
+  * interior_triangle / interior_convex / interior_polygon (reference cores/triangulation_functions.py:305-430)
+are stored in function_golden.npz; `function_cases()` below is the single list of cases, shared with the tests.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/generate_function_golden.py
+"""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+
+
+def inputs():
+    rng = np.random.default_rng(2024)
+    u = np.concatenate([np.linspace(-2.0, 2.0, 801), rng.normal(0, 0.7, 1199), [0.0, -0.0, 0.25, -0.25, 1.0]])
+    v = np.concatenate([np.linspace(1.5, -1.5, 801), rng.normal(0.1, 0.6, 1199), [0.0, 0.25, 0.25, 0.3, -1.0]])
+    g3 = rng.normal(0, 1, (17, 13, 9))
+    g2 = rng.normal(0, 1, (23, 19))
+    co = np.concatenate([rng.uniform(-1.2, 1.2, (2, 3000)), np.zeros((1, 3000))])
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)      # noqa: E731
+    return {"u": f32(u), "v": f32(v), "g3": f32(g3), "g2": f32(g2), "co": f32(co)}
+
+
+def function_cases(ns, scenes):
+    """name -> (callable on the namespace `ns`, names of its array inputs)"""
+    pp = ns.post_processing
+    tf = ns.triangulation_functions
+    return {
+        "sigmoid_falloff": (lambda d: pp.sigmoid_falloff(d["u"], 1.7, 0.6), ),
+        "positive_sigmoid_falloff": (lambda d: pp.positive_sigmoid_falloff(d["u"], 0.8, 0.9), ),
+        "capped_exponential": (lambda d: pp.capped_exponential(d["u"], 2.0, 1.3), ),
+        "hard_binarization": (lambda d: pp.hard_binarization(d["u"], 0.25), ),
+        "linear_falloff": (lambda d: pp.linear_falloff(d["u"], 1.5, 0.8), ),
+        "relu": (lambda d: pp.relu(d["u"], 0.7), ),
+        "relu_default": (lambda d: pp.relu(d["u"]), ),
+        "smooth_relu": (lambda d: pp.smooth_relu(d["u"], 0.3, 0.9, 0.02), ),
+        "slowstart": (lambda d: pp.slowstart(d["u"], 0.3, 1.1, 0.02, True), ),
+        "slowstart_unground": (lambda d: pp.slowstart(d["u"], 0.2, ground=False), ),
+        "gaussian_boundary": (lambda d: pp.gaussian_boundary(d["u"], 1.2, 0.7), ),
+        "gaussian_falloff": (lambda d: pp.gaussian_falloff(d["u"], 1.2, 0.7), ),
+        "conv_averaging_3d": (lambda d: pp.conv_averaging(d["g3"], (3, 3, 3), 2), ),
+        "conv_averaging_3d_int": (lambda d: pp.conv_averaging(d["g3"], 3, 1), ),
+        "conv_averaging_2d": (lambda d: pp.conv_averaging(d["g2"], (5, 3), 3), ),
+        "conv_edge_detection_3d": (lambda d: pp.conv_edge_detection(d["g3"]), ),
+        "conv_edge_detection_2d": (lambda d: pp.conv_edge_detection(d["g2"]), ),
+        "custom_post_process": (lambda d: pp.custom_post_process(d["u"], lambda w, a, b: a * w + b, (2.0, -1.0)), ),
+        "smoothmin_poly2": (lambda d: ns.combine.smoothmin_poly2(d["u"], d["v"], 0.4), ),
+        "smoothmin_poly2_zero": (lambda d: ns.combine.smoothmin_poly2(d["u"], d["v"], 0), ),
+        "smoothmin_poly3": (lambda d: ns.combine.smoothmin_poly3(d["u"], d["v"], 0.3), ),
+        "smoothmax_boltz": (lambda d: ns.combine.smoothmax_boltz(d["u"], d["v"], 0.25), ),
+        "interior_triangle": (lambda d: tf.interior_triangle(d["co"], scenes.CONVEX_POLY[:, :3].copy()), ),
+        "interior_convex": (lambda d: tf.interior_convex(d["co"], scenes.CONVEX_POLY.copy()), ),
+        "interior_polygon_convex_cw": (lambda d: tf.interior_polygon(d["co"], scenes.CONVEX_POLY[:, ::-1].copy()), ),
+        "interior_polygon_concave": (lambda d: tf.interior_polygon(d["co"], scenes.CONCAVE_POLY.copy()), ),
+        "interior_polygon_bowtie": (lambda d: tf.interior_polygon(d["co"], scenes.BOWTIE_POLY.copy()), ),
+        "interior_polygon_figure8": (lambda d: tf.interior_polygon(d["co"], scenes.FIGURE8_POLY.copy()), ),
+    }
+
+
+def main():
+    sys.path.insert(0, "/root/reference/Code/spomso")
+    import spomso.cores as ref
+    import scenes
+    data = inputs()
+    out = {"in/" + k: v for k, v in data.items()}
+    for name, (fn,) in function_cases(ref, scenes).items():
+        with contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):
+            out["out/" + name] = np.asarray(fn({k: v.copy() for k, v in data.items()}), dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "function_golden.npz"), **out)
+    print("functions:", len(out) - len(data))
+
+
+if __name__ == "__main__":
+    main()

@@ -70,6 +70,15 @@ ZIGZAG2 = np.asarray([[-0.9, -0.3, 0.2, 0.8, 0.4], [-0.5, 0.6, -0.4, 0.5, -0.7],
 CONVEX_POLY = np.asarray([[-0.8, 0.7, 0.9, 0.1, -0.7], [-0.6, -0.7, 0.3, 0.9, 0.4], [0, 0, 0, 0, 0]], dtype=float)
 CONCAVE_POLY = np.asarray([[-0.9, 0.0, 0.9, 0.6, 0.0, -0.6], [-0.7, -0.2, -0.7, 0.8, 0.1, 0.8], [0, 0, 0, 0, 0, 0]],
                           dtype=float)
+BOWTIE_POLY = np.asarray([[-0.8, 0.7, 0.8, -0.7], [-0.6, 0.5, -0.7, 0.6], [0, 0, 0, 0]], dtype=float)
+FIGURE8_POLY = np.asarray([[-0.9, -0.3, 0.3, 0.9, 0.9, 0.3, -0.3, -0.9], [-0.3, -0.6, 0.6, 0.3, -0.3, -0.6, 0.6, 0.3],
+                           [0, 0, 0, 0, 0, 0, 0, 0]], dtype=float)
+FISH_POLY = np.asarray([[-0.9, -0.9, 0.2, 0.8, 0.2], [0.4, -0.4, 0.35, 0.0, -0.35], [0, 0, 0, 0, 0]], dtype=float)
+# every turn of a pentagram goes the same way: the reference takes it for a convex outline (its inner pentagon)
+PENTAGRAM_POLY = np.asarray([[np.cos(2 * np.pi * k * 2 / 5 + np.pi / 2) for k in range(5)],
+                             [np.sin(2 * np.pi * k * 2 / 5 + np.pi / 2) for k in range(5)], [0.0] * 5])
+# edges that cross different numbers of other edges: the reference's decomposition raises ValueError (ragged index array)
+RAGGED_CROSSINGS_POLY = np.asarray([[-0.9, 0.8, 0.2, -0.2, -0.8, 0.9], [0.0, 0.1, -0.8, 0.8, -0.1, 0.05], [0.0] * 6])
 CLOUD3 = np.random.default_rng(5).uniform(-1.0, 1.0, size=(3, 37))
 
 
@@ -120,6 +129,11 @@ _PRIMS = {
     "arc": lambda ns: ns.Arc(0.7, 0.2, 2.6),
     "polygon_convex": lambda ns: ns.Polygon(CONVEX_POLY.copy()),
     "polygon_concave": lambda ns: ns.Polygon(CONCAVE_POLY.copy()),
+    # self-intersecting outlines: cut into loops at the crossing points (C/triangulation_functions.py:128-302, 403-412)
+    "polygon_bowtie": lambda ns: ns.Polygon(BOWTIE_POLY.copy()),
+    "polygon_figure8": lambda ns: ns.Polygon(FIGURE8_POLY.copy()),
+    "polygon_fish": lambda ns: ns.Polygon(FISH_POLY.copy()),
+    "polygon_pentagram": lambda ns: ns.Polygon(PENTAGRAM_POLY.copy()),
     "segmented_line2d": lambda ns: ns.SegmentedLine(ZIGZAG2),
     "segmented_line2d_closed": lambda ns: ns.SegmentedLine(ZIGZAG2, closed=True),
     "segmented_curve2d": lambda ns: ns.SegmentedParametricCurve(ZIGZAG2, (0, 5, 19)),
@@ -128,7 +142,7 @@ _PRIMS = {
     "parametric_curve2d_closed": lambda ns: ns.ParametricCurve(ellipse, (0.8, 0.5), (0, 5.5, 33), closed=True),
     "point_cloud2d": lambda ns: ns.PointCloud2D(CLOUD3),
 }
-_DISCONT_PRIMS = {"polygon_convex", "polygon_concave", "oriented_infinite_cone", "infinite_sector", "solid_angle",
+_DISCONT_PRIMS = {"polygon_convex", "polygon_concave", "polygon_bowtie", "polygon_figure8", "polygon_fish", "polygon_pentagram", "oriented_infinite_cone", "infinite_sector", "solid_angle",
                   "sector", "cone", "triangle", "ngon", "ngon_3", "ngon_8", "ngon_16", "ngon_17"}
 
 for _name, _make in _PRIMS.items():

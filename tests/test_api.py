@@ -1,9 +1,11 @@
 """CPU: drop-in surface of the reference's operator API (names, signatures, histories, errors)."""
 import inspect
+import os
 
 import numpy as np
 import pytest
 
+import scenes
 import aegolius_amd.cores as ns
 from aegolius_amd._ir import CombineSDF, ModSDF, NodeSDF, PrimSDF, SDFExpr
 from aegolius_amd._lower import as_expr, lower_geometry
@@ -255,3 +257,81 @@ def test_host_side_helpers_match_the_reference_semantics():
     assert hasattr(ns.EuclideanTransform, "apply") and hasattr(ns.EuclideanTransform, "apply_ec_transforms")
     assert issubclass(ns.geom_3d.GenericGeometry3D, ns.GenericGeometry)
     assert issubclass(ns.geom_2d.GenericGeometry2D, ns.GenericGeometry)
+
+
+# ---- the whole public surface against the reference's, name by name (tests/golden/reference_api.json) ---------------
+# names of SURVEY.md §2's OUT-OF-SCOPE rows: the point-cloud container, its transform mixin, the stand-alone closure
+# builder that duplicates the ModifyObject post-process methods, and the liquid-crystal special fields
+OUT_OF_SCOPE = {("geom", "Points"), ("transformations", "EuclideanTransformPoints"), ("post_processing", "PostProcess")}
+OUT_OF_SCOPE_PACKAGE_NAMES = {"Points", "EuclideanTransformPoints", "PostProcess", "compute_crossings_2d",
+                              "geom_vector_special", "vector_functions_special"}
+
+
+def _params(obj):
+    import inspect
+    return [[p.name, p.kind.name, None if p.default is inspect.Parameter.empty else repr(p.default)]
+            for p in inspect.signature(obj).parameters.values()]
+
+
+def test_public_api_matches_the_reference_name_by_name():
+    """Every public function, class, method and property of the in-scope `spomso.cores` modules exists here under the
+    same module path with the same parameter names, kinds and defaults (recorded from the real reference by
+    tests/golden/generate_api_signatures.py); only SURVEY §2's out-of-scope names are absent."""
+    import importlib
+    import json
+    rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_api.json")))
+    diffs = []
+    for mod_name, names in rec["modules"].items():
+        mod = importlib.import_module("aegolius_amd.cores." + mod_name)
+        for name, d in names.items():
+            if (mod_name, name) in OUT_OF_SCOPE:
+                continue
+            obj = getattr(mod, name, None)
+            if obj is None:
+                diffs.append("%s.%s missing" % (mod_name, name))
+                continue
+            if d["kind"] == "function":
+                if _params(obj) != d["signature"]:
+                    diffs.append("%s.%s%r, reference %r" % (mod_name, name, _params(obj), d["signature"]))
+                continue
+            for meth, want in d["methods"].items():
+                have = getattr(obj, meth, None)
+                if have is None:
+                    diffs.append("%s.%s.%s missing" % (mod_name, name, meth))
+                elif _params(have) != want:
+                    diffs.append("%s.%s.%s%r, reference %r" % (mod_name, name, meth, _params(have), want))
+            for prop in d["properties"]:
+                if not hasattr(obj, prop):
+                    diffs.append("%s.%s.%s (property) missing" % (mod_name, name, prop))
+    assert not diffs, "\n".join(diffs)
+    import aegolius_amd.cores as ours
+    missing = set(rec["package_names"]) - set(dir(ours)) - OUT_OF_SCOPE_PACKAGE_NAMES
+    assert not missing, sorted(missing)
+
+
+def test_sdf_functions_take_the_reference_s_keyword_arguments():
+    import inspect
+    assert str(inspect.signature(ns.sdf_sphere)) == "(co, radius)"
+    assert str(inspect.signature(ns.sdf_box)) == "(co, size)"
+    assert str(inspect.signature(ns.sdf_torus)) == "(co, R, r)"
+    assert str(inspect.signature(ns.aar_vector_field_cylindrical)) == "(r, alpha)"
+    with pytest.raises(TypeError):
+        ns.sdf_sphere(np.zeros((3, 4)), radius=1.0, extra=2)
+    with pytest.raises(TypeError):
+        ns.sdf_torus(np.zeros((3, 4)), 1.0)
+
+
+def test_self_intersecting_outlines_are_cut_into_loops_like_the_reference():
+    """One crossing: two loops (bow-tie, figure 8, fish) — pinned on the GPU by goldens, like the pentagram, which the
+    reference takes for a convex outline; outlines whose edges cross different numbers of other edges raise the
+    ValueError the reference raises."""
+    from aegolius_amd import _polygon
+    for poly, loops in ((scenes.BOWTIE_POLY, [3, 3]), (scenes.FIGURE8_POLY, [5, 5]), (scenes.FISH_POLY, [3, 4])):
+        sets = ns.triangulation_functions.create_points_sets(poly, ns.triangulation_functions.check_intersection_all(poly))
+        assert [s.shape[1] for s in sets] == loops
+        assert len(_polygon.convex_pieces(poly)) >= 2
+    assert len(_polygon.convex_pieces(scenes.PENTAGRAM_POLY)) == 1
+    with pytest.raises(ValueError):
+        _polygon.convex_pieces(scenes.RAGGED_CROSSINGS_POLY)
+    with pytest.raises(ValueError):
+        lower_geometry(ns.Polygon(scenes.RAGGED_CROSSINGS_POLY.copy()))

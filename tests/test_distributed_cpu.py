@@ -228,3 +228,60 @@ def test_sharded_vector_field_partitions_whole_rows():
             n = int(np.prod([a for a in ns.generate_grid(size, resolution)[0].shape[1:]]))
             assert seen[0][0] == 0 and sum(c for _, c in seen) == n
             assert all(a[0] + a[1] == b[0] for a, b in zip(seen, seen[1:]))
+
+
+# ---- reassembly overlapped with the evaluation -------------------------------------------------------
+def _overlap_worker(rank, world, port, shape, chunks, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from aegolius_amd.distributed import evaluate_gathered_overlapped, gather_slabs, slab_bounds
+        n, unit = shape[0] * shape[1] * shape[2], shape[2]
+        calls = []
+
+        def evaluate_chunk(start, count, out):                     # "field" = a function of the flat index
+            calls.append((start, count))
+            out.copy_(torch.arange(start, start + count, dtype=torch.float32) * 0.5 + 1.0)
+        res = {}
+        for schedule in ("direct", "collective"):
+            calls.clear()
+            full = torch.full((n,), -7.0)
+            evaluate_gathered_overlapped(evaluate_chunk, full, n, unit=unit, chunks=chunks, schedule=schedule,
+                                         chunk_unit=2 * unit)
+            s, c = slab_bounds(n, world, rank, unit)
+            covered = sorted(calls)
+            ok = (covered[0][0] == s if covered else c == 0) and sum(k for _, k in covered) == c and \
+                all((a - s) % (2 * unit) == 0 or (schedule == "collective" and a - s == (n // unit // world) * unit)
+                    for a, k in covered)
+            res[schedule] = (ok, full.numpy().copy())
+        s, c = slab_bounds(n, world, rank, unit)                   # the plain gather (what bench.py times first)
+        local = torch.arange(s, s + c, dtype=torch.float32) * 0.5 + 1.0
+        res["after"] = (True, gather_slabs(local, n, unit=unit).numpy().copy())
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape,chunks", [(2, (7, 5, 33), 3), (3, (5, 3, 9), 4), (2, (3, 1, 40), 8), (3, (2, 1, 5), 2)])
+def test_overlapped_gather_reassembles_the_field(world, shape, chunks):
+    """evaluate_gathered_overlapped: slabs of whole rows with an uneven last slab (odd-converted grids never divide),
+    more chunks than rows, ranks whose slab is empty; both schedules give the single-rank field on every rank, and
+    every rank evaluates exactly its slab in chunks that start at multiples of the chunk unit (two rows here). Also the after-the-fact gather of bench.py."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, shape, chunks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    n = shape[0] * shape[1] * shape[2]
+    want = np.arange(n, dtype=np.float32) * 0.5 + 1.0
+    for _rank, res in got:
+        for schedule, (ok, full) in res.items():
+            assert ok, schedule
+            np.testing.assert_array_equal(full, want, err_msg=schedule)

@@ -3,6 +3,7 @@ validates programs, generates + hiprtc-compiles specialised kernels for gfx950, 
 keeps the reference's aliasing rules. No compute calls."""
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -223,21 +224,40 @@ def test_no_gpu_means_an_error_never_a_cpu_result(built):
             call()
 
 
-def test_disk_cache_of_compiled_kernels_is_opt_in_and_reused(built, tmp_path, monkeypatch):
-    """SDFK_CACHE_DIR: the code object of a tree shape is written once and loaded by the next compile of that shape."""
-    import ctypes
-    import time
-    low = lower_geometry(scenes.SCENES[sorted(scenes.SCENES)[3]](ns))
-    prog = built.Program.from_lowered(low)
-    monkeypatch.delenv("SDFK_CACHE_DIR", raising=False)
-    assert prog.compile_check() > 0 and not list(tmp_path.iterdir())           # off by default: nothing written
-    monkeypatch.setenv("SDFK_CACHE_DIR", str(tmp_path))
-    t0 = time.perf_counter()
-    size = prog.compile_check()
-    cold = time.perf_counter() - t0
+_CACHE_SCRIPT = """
+import json, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+import scenes
+import aegolius_amd.cores as ns
+from aegolius_amd import _engine
+from aegolius_amd._lower import lower_geometry
+prog = _engine.Program.from_lowered(lower_geometry(scenes.cfg2_tree(ns)))
+size, seconds = prog.compile_flavour(_engine.FLAVOUR_ROWS_ARRAY)
+again = prog.compile_flavour(_engine.FLAVOUR_ROWS_ARRAY)
+other = _engine.Program.from_lowered(lower_geometry(scenes.cfg2_tree(ns))).compile_flavour(_engine.FLAVOUR_ROWS_ARRAY)
+print(json.dumps(dict(size=size, seconds=seconds, again=again[1], other=other[1], builds=_engine.jit_stats()[0])))
+"""
+
+
+def test_code_objects_are_built_once_per_process_and_cached_on_disk(built, tmp_path):
+    """One flavour of one tree shape: built by hiprtc once per process (a second program of the same shape and a second
+    request find the code object), written to the on-disk cache (on by default, here pointed at a scratch directory),
+    loaded from there by the next process without any hiprtc build; SDFK_CACHE_DIR=off writes nothing."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _CACHE_SCRIPT.format(root=root)
+
+    def run(cache):
+        env = dict(os.environ, SDFK_CACHE_DIR=cache)
+        res = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, check=True)
+        return json.loads(res.stdout.strip().splitlines()[-1])
+    cold = run(str(tmp_path))
     files = list(tmp_path.iterdir())
-    assert len(files) == 1 and files[0].suffix == ".co" and files[0].stat().st_size == size
-    t0 = time.perf_counter()
-    assert prog.compile_check() == size
-    assert time.perf_counter() - t0 < 0.5 * cold                               # read back, not compiled
+    assert cold["builds"] == 1 and cold["again"] < 0.05 and cold["other"] < 0.05
+    assert len(files) == 1 and files[0].suffix == ".co" and files[0].stat().st_size == cold["size"]
+    warm = run(str(tmp_path))
+    assert warm["builds"] == 0 and warm["size"] == cold["size"] and warm["seconds"] < 0.05
     assert len(list(tmp_path.iterdir())) == 1
+    off = run("off")
+    assert off["builds"] == 1 and len(list(tmp_path.iterdir())) == 1
