@@ -1350,6 +1350,73 @@ static int64_t detect_row_len(const T* co, int64_t n, int64_t stride) {
     return 0;
 }
 
+// ---- host arrays in, host array out: a two-slot pipeline over pinned staging buffers ------------------------------
+// A pageable (3, n) array cannot be DMA'd directly: hipMemcpy stages it through an internal bounce buffer, one
+// synchronous chunk at a time (measured 24-26 GB/s over a 63 GB/s link, kernel and copies never overlapping). Here the
+// array is cut into chunks; a few host threads copy (or narrow float64 -> float32) chunk i + 1 into pinned slot B and
+// copy chunk i - 1's field out of it, while slot A's stream runs H2D -> kernel -> D2H of chunk i. The pinned slots
+// and their device buffers are allocated once per device and kept (256 MiB pinned for 8 Mi-point chunks).
+struct HostSlot {
+    float *h_co = nullptr, *h_out = nullptr, *d_co = nullptr, *d_out = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    int64_t pending_start = -1, pending_count = 0;        // field in h_out still to be handed to the caller
+};
+struct HostStage {
+    std::mutex mu;                                          // one host-path call per device at a time
+    int64_t chunk = 0;
+    HostSlot slot[2];
+};
+static std::mutex g_stage_mu;
+static std::map<int, std::unique_ptr<HostStage>> g_stage;
+static int host_threads() {
+    static int v = [] {
+        const char* e = getenv("SDFK_HOST_THREADS");
+        int t = e ? atoi(e) : 0;
+        if (t < 1) t = std::min(8, std::max(1, (int)std::thread::hardware_concurrency() / 4));
+        return std::min(t, 64);
+    }();
+    return v;
+}
+// run fn(lo, hi) over [0, count) on the calling thread plus helpers
+template <typename F>
+static void parallel_ranges(int64_t count, F fn) {
+    const int t = (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, count >> 18));
+    if (t <= 1) {
+        fn(0, count);
+        return;
+    }
+    std::vector<std::thread> helpers;
+    const int64_t step = (count + t - 1) / t;
+    for (int i = 1; i < t; ++i) helpers.emplace_back([=] { fn(std::min(count, i * step), std::min(count, (i + 1) * step)); });
+    fn(0, std::min(count, step));
+    for (std::thread& h : helpers) h.join();
+}
+static int stage_for(int device, int64_t want, HostStage** out) {
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    std::unique_ptr<HostStage>& st = g_stage[device];
+    if (!st) st.reset(new HostStage);
+    if (st->chunk < want) {
+        for (HostSlot& sl : st->slot) {
+            if (sl.h_co) (void)hipHostFree(sl.h_co);
+            if (sl.h_out) (void)hipHostFree(sl.h_out);
+            if (sl.d_co) (void)hipFree(sl.d_co);
+            if (sl.d_out) (void)hipFree(sl.d_out);
+            sl.h_co = sl.h_out = sl.d_co = sl.d_out = nullptr;
+            if (!sl.stream) HIPCHK(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+            if (!sl.done) HIPCHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+            st->chunk = 0;
+            HIPCHK(hipHostMalloc((void**)&sl.h_co, (size_t)want * 3 * sizeof(float), hipHostMallocDefault));
+            HIPCHK(hipHostMalloc((void**)&sl.h_out, (size_t)want * sizeof(float), hipHostMallocDefault));
+            HIPCHK(hipMalloc(&sl.d_co, (size_t)want * 3 * sizeof(float)));
+            HIPCHK(hipMalloc(&sl.d_out, (size_t)want * sizeof(float)));
+        }
+        st->chunk = want;
+    }
+    *out = st.get();
+    return 0;
+}
+
 // out_on_device: `out` is device memory of the same device (the field stays resident, nothing comes back)
 static int eval_host_impl(sdfk_program* p, const void* co, int co_dtype, int64_t n, int64_t row_stride, float* out,
                           int device, int mode, bool out_on_device) {
@@ -1359,44 +1426,80 @@ static int eval_host_impl(sdfk_program* p, const void* co, int co_dtype, int64_t
     if (row_stride < n) return fail(-1, "sdfk_eval_host: row stride smaller than the point count");
     if (n == 0) return 0;
     HIPCHK(hipSetDevice(device));
-    int64_t chunk = std::min<int64_t>(n, (int64_t)1 << 25);  // 32 Mi points = 512 MiB of device staging
+    static const int64_t max_chunk = [] {
+        const char* e = getenv("SDFK_HOST_CHUNK");
+        const int64_t v = e ? atoll(e) : 0;
+        return v >= 4096 ? v : ((int64_t)1 << 23);           // 8 Mi points: 96 MiB in + 32 MiB out per slot
+    }();
+    int64_t chunk = std::min<int64_t>(n, max_chunk);
     const int64_t row_len = p->sites.empty() ? 0
                             : co_dtype == 0 ? detect_row_len(static_cast<const float*>(co), n, row_stride)
                                             : detect_row_len(static_cast<const double*>(co), n, row_stride);
     if (row_len > 0 && chunk > row_len) chunk = chunk / row_len * row_len;   // whole rows per chunk
     const int64_t stride = (chunk + 63) & ~(int64_t)63;
-    float *d_co = nullptr, *d_out = nullptr;
-    HIPCHK(hipMalloc(&d_co, (size_t)stride * 3 * sizeof(float)));
-    if (hipMalloc(&d_out, (size_t)stride * sizeof(float)) != hipSuccess) {
-        (void)hipFree(d_co);
-        return fail(-5, "sdfk_eval_host: out of device memory");
-    }
-    std::vector<float> tmp;
-    if (co_dtype == 1) tmp.resize((size_t)chunk);
-    int rc = 0;
-    for (int64_t s = 0; s < n && rc == 0; s += chunk) {
-        const int64_t m = std::min(chunk, n - s);
-        for (int r = 0; r < 3 && rc == 0; ++r) {
-            const float* srcf;
-            if (co_dtype == 0) {
-                srcf = static_cast<const float*>(co) + r * row_stride + s;
-            } else {
-                const double* sd = static_cast<const double*>(co) + r * row_stride + s;
-                for (int64_t i = 0; i < m; ++i) tmp[(size_t)i] = (float)sd[i];
-                srcf = tmp.data();
-            }
-            if (hipMemcpy(d_co + r * stride, srcf, (size_t)m * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
-                rc = fail(-6, "sdfk_eval_host: host-to-device copy failed");
+    HostStage* st = nullptr;
+    int rc = stage_for(device, stride, &st);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(st->mu);
+    // the first call of a program builds its kernel: do that before anything is in flight (the build may take seconds)
+    auto hand_over = [&](HostSlot& sl) -> int {             // wait for the slot's chunk and give its field to the caller
+        if (sl.pending_start < 0) return 0;
+        HIPCHK(hipEventSynchronize(sl.done));
+        if (!out_on_device) {
+            const float* src = sl.h_out;
+            float* dst = out + sl.pending_start;
+            parallel_ranges(sl.pending_count, [=](int64_t lo, int64_t hi) { memcpy(dst + lo, src + lo, (size_t)(hi - lo) * sizeof(float)); });
         }
+        sl.pending_start = -1;
+        return 0;
+    };
+    int k = 0;
+    for (int64_t s = 0; s < n && rc == 0; s += chunk, ++k) {
+        HostSlot& sl = st->slot[k & 1];
+        rc = hand_over(sl);                                  // the slot's previous chunk (two chunks ago) is done: reuse it
+        if (rc) break;
+        const int64_t m = std::min(chunk, n - s);
+        float* h = sl.h_co;
+        if (co_dtype == 0) {
+            const float* base = static_cast<const float*>(co) + s;
+            parallel_ranges(m, [=](int64_t lo, int64_t hi) {
+                for (int r = 0; r < 3; ++r) memcpy(h + r * stride + lo, base + r * row_stride + lo, (size_t)(hi - lo) * sizeof(float));
+            });
+        } else {
+            const double* base = static_cast<const double*>(co) + s;
+            parallel_ranges(m, [=](int64_t lo, int64_t hi) {
+                for (int r = 0; r < 3; ++r) {
+                    const double* src = base + r * row_stride;
+                    float* dst = h + r * stride;
+                    for (int64_t i = lo; i < hi; ++i) dst[i] = (float)src[i];
+                }
+            });
+        }
+        for (int r = 0; r < 3 && rc == 0; ++r)
+            if (hipMemcpyAsync(sl.d_co + r * stride, h + r * stride, (size_t)m * sizeof(float), hipMemcpyHostToDevice, sl.stream) != hipSuccess)
+                rc = fail(-6, "sdfk_eval_host: host-to-device copy failed");
         if (rc == 0)
-            rc = (row_len > 0 && m % row_len == 0) ? sdfk_eval_device_rows(p, d_co, m, stride, row_len, d_out, nullptr, mode)
-                                                   : sdfk_eval_device(p, d_co, m, stride, d_out, nullptr, mode);
-        if (rc == 0 && hipMemcpy(out + s, d_out, (size_t)m * sizeof(float),
-                                 out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost) != hipSuccess)
-            rc = fail(-6, "sdfk_eval_host: copy of the result failed");
+            rc = (row_len > 0 && m % row_len == 0) ? sdfk_eval_device_rows(p, sl.d_co, m, stride, row_len, sl.d_out, sl.stream, mode)
+                                                   : sdfk_eval_device(p, sl.d_co, m, stride, sl.d_out, sl.stream, mode);
+        if (rc == 0) {
+            const hipError_t e = out_on_device
+                                     ? hipMemcpyAsync(out + s, sl.d_out, (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, sl.stream)
+                                     : hipMemcpyAsync(sl.h_out, sl.d_out, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, sl.stream);
+            if (e != hipSuccess) rc = fail(-6, "sdfk_eval_host: copy of the result failed");
+        }
+        if (rc == 0 && hipEventRecord(sl.done, sl.stream) != hipSuccess) rc = fail(-6, "sdfk_eval_host: event record failed");
+        if (rc == 0) {
+            sl.pending_start = s;
+            sl.pending_count = m;
+        }
     }
-    (void)hipFree(d_co);
-    (void)hipFree(d_out);
+    for (HostSlot& sl : st->slot) {                         // drain (also on errors: nothing of this call stays in flight)
+        if (rc == 0) rc = hand_over(sl);
+        else {
+            (void)hipStreamSynchronize(sl.stream);
+            sl.pending_start = -1;
+        }
+    }
     return rc;
 }
 

@@ -858,6 +858,10 @@ struct Gen {
                  "const float* __restrict__ PRM, const float* __restrict__ TAB) {\n";
         declare("V3", "float", false);
         s += rows ? "    mask = 0ull; mask1 = 0ull;\n" : "    unsigned long long mask = 0ull;\n";
+        // fp32 rounding of an operand grows with the magnitude of the coordinates it is computed from (about
+        // 6e-8 |p| per rounding step of a transform), not with its value: a scene far from the origin needs a margin
+        // in |c| + rho, scaled by the Lipschitz sum of the site, on top of the margin in the operand values
+        s += "    const float cmag = 1e-6f * (fabsf(C_0.x) + fabsf(C_0.y) + fabsf(C_0.z) + rho);\n";
         char buf[512], gB[64], gA[64], wx[32];
         for (size_t i = 0; i < n_instr; ++i) {
             for (size_t k = 0; k < sites->size(); ++k) {   // decisions read the operands BEFORE the combiner
@@ -870,10 +874,10 @@ struct Gen {
                 const char* mv = k < 32 ? "mask" : "mask1";
                 const unsigned sh = 2 * (unsigned)(k & 31);
                 snprintf(buf, sizeof buf,
-                         "    { const float thr = %s + %.9gf * rho + 1e-6f * (1.0f + fabsf(V_%u) + fabsf(V_%u));\n"
+                         "    { const float thr = %s + %.9ef * rho + %.9ef * cmag + 1e-6f * (1.0f + fabsf(V_%u) + fabsf(V_%u));\n"
                          "      if (%d && %s >= thr) %s |= %lluull;\n"
                          "      else if (%d && %s >= thr) %s |= %lluull; }\n",
-                         wx, (double)t.k * 1.0001, b, c, t.skip_b_ok, gB, mv, 2ull << sh, t.skip_a_ok, gA, mv,
+                         wx, (double)t.k * 1.0001, (double)t.k, b, c, t.skip_b_ok, gB, mv, 2ull << sh, t.skip_a_ok, gA, mv,
                          1ull << sh);
                 s += buf;
             }

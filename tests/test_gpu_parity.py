@@ -11,6 +11,7 @@ coordinates it is computed from: for those scenes (only) the denominator is
 max(1, |ref|, largest intermediate magnitude at that point) as reported by the float64 oracle.
 """
 import ctypes
+import json
 import os
 
 import numpy as np
@@ -40,14 +41,24 @@ def violations(out, ref, magnitude=None):
     return err, bad
 
 
-def check(name, out, ref, magnitude=None):
+# Off-point counts per scene, recorded on an MI355X by `python tests/report_gpu_parity.py --write-budget` (scenes that
+# are not listed have NONE): a point within fp32 rounding of a jump of the scene (sign, binarisation, cell and sector
+# boundaries) may land on the other side, and a handful of scenes have such points in the fixed input cloud. The count
+# is pinned, not bounded by a percentage: a regression that corrupts a few points of any scene fails.
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "parity_budget.json")) as _f:
+    BUDGET = json.load(_f)
+
+
+def check(name, out, ref, magnitude=None, budget=None):
     assert out.dtype == np.float32 and out.shape == ref.shape
     err, bad = violations(out, ref, magnitude)
-    if name in scenes.DISCONTINUOUS:
-        assert bad.sum() <= max(1, int(0.005 * ref.size)), "%s: %d points off (max %.2e)" % (name, bad.sum(),
-                                                                                             np.nanmax(err))
-    else:
-        assert not bad.any(), "%s: %d points off, max rel err %.3e" % (name, bad.sum(), np.nanmax(err))
+    allowed = (BUDGET["scenes"].get(name, 0) if budget is None else budget)
+    assert bad.sum() <= allowed, "%s: %d points off (recorded: %d), max rel err %.3e" % (name, bad.sum(), allowed,
+                                                                                       np.nanmax(err))
+    if allowed:
+        # a point on the other side of a jump is off by the height of the jump, never by more than the scene's range
+        span = np.nanmax(ref) - np.nanmin(ref)
+        assert np.all(np.abs(out.astype(np.float64) - ref)[bad] <= span * (1 + 1e-6) + 1e-6), name
 
 
 @pytest.fixture(scope="module")
@@ -105,7 +116,7 @@ def test_grid_neighbourhood_scene_matches_reference_golden(name, engine, golden)
         for arr in (co.copy(), tagged):
             out = build(ns, res).create(arr)
             assert list(out.shape) == meta["grid_scenes"][name]["shape"]
-            check(name, out.ravel(), ref.ravel(), magnitude)
+            check(name, out.ravel(), ref.ravel(), magnitude, budget=BUDGET["grid_scenes"].get(name, 0))
             outs.append(out)
     for o in outs[1:]:
         np.testing.assert_array_equal(o, outs[0])
@@ -128,7 +139,8 @@ def test_grid_operators_at_scale(engine):
     ref = sdf_oracle.evaluate(build(), co64)
     assert (ref < 0).sum() > 0.05 * ref.size
     err, bad = violations(got, ref)
-    assert bad.sum() <= 0.0005 * ref.size, (int(bad.sum()), float(np.nanmax(err)))
+    # sign flips of `signed` for the points whose boundary test sits within rounding of the threshold: recorded count
+    assert bad.sum() <= BUDGET["grid_operators_at_scale"], (int(bad.sum()), float(np.nanmax(err)))
     # constant field / linear ramp through the operator alone
     lib = engine.lib()
     n0, n1, n2 = 33, 41, 130
@@ -455,6 +467,39 @@ def test_row_block_culling_is_bit_exact(name, engine):
     plain = _device_eval(engine, prog, pts, pts.shape[1], pts.shape[1], 0, engine.MODE_NOCULL)
     rows = _device_eval(engine, prog, pts, pts.shape[1], pts.shape[1], 0, engine.MODE_SPECIALIZED, row_len=48)
     np.testing.assert_array_equal(rows, plain)
+
+
+@pytest.mark.parametrize("shift", [1.0e3, 1.0e5])
+@pytest.mark.parametrize("name", ["tree_cfg2_smooth_union10", "tree_cfg5_three_level"])
+def test_culling_far_from_the_origin_is_bit_exact(name, shift, engine):
+    """The whole scene moved to |p| ~ 1e3 and ~ 1e5: fp32 rounding of the operands now grows with the coordinates
+    (about 6e-8 |p| per step), not with their values — the cull margin carries a term in |c| + rho for that
+    (csrc/sdfk_codegen.cpp emit_probe). Both culling kernels still return the plain kernel's bits, and the field
+    stays within the movement of the float64 oracle under a one-ulp change of its fp32 inputs."""
+    tree = scenes.SCENES[name](ns)
+    tree.move((shift, -shift, 0.5 * shift))
+    low = lower_geometry(tree)
+    assert len(low.cull_sites) > 0
+    prog = engine.Program.from_lowered(low)
+    co, _ = ns.generate_grid((2.6, 2.6, 2.6), (36, 40, 257))
+    co = np.asarray(co) + np.asarray([[shift], [-shift], [0.5 * shift]])
+    co32 = np.ascontiguousarray(co, dtype=np.float32)
+    n = co32.shape[1]
+    plain = _device_eval(engine, prog, co32, n, n, 0, engine.MODE_NOCULL)
+    bricks = _device_eval(engine, prog, co32, n, n, 0, engine.MODE_SPECIALIZED)
+    rows = _device_eval(engine, prog, co32, n, n, 0, engine.MODE_SPECIALIZED, row_len=257)
+    np.testing.assert_array_equal(bricks, plain)
+    np.testing.assert_array_equal(rows, plain)
+    co64 = co32.astype(np.float64)
+    with np.errstate(all="ignore"):
+        ref = sdf_oracle.evaluate(tree, co64)
+        moved = np.zeros_like(ref)
+        for axis in range(3):                                   # the oracle's own sensitivity to an ulp of the input
+            bump = co64.copy()
+            bump[axis] = np.nextafter(co32[axis], np.float32(np.inf)).astype(np.float64)
+            moved = np.maximum(moved, np.abs(sdf_oracle.evaluate(tree, bump) - ref))
+    err = np.abs(plain.astype(np.float64) - ref)
+    assert np.all(err <= 1e-6 * np.maximum(1.0, np.abs(ref)) + 8.0 * moved + 8.0 * np.spacing(np.float32(shift))), float(err.max())
 
 
 @pytest.mark.parametrize("name", CULL_SCENES)
