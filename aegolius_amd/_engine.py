@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libsdfk.so")
 
 MODE_AUTO, MODE_INTERPRET, MODE_SPECIALIZED, MODE_NOCULL = 0, 1, 2, 3
 (FLAVOUR_PLAIN_ARRAY, FLAVOUR_PLAIN_GRID, FLAVOUR_TILE_ARRAY, FLAVOUR_TILE_GRID, FLAVOUR_TILE_MASK, FLAVOUR_ROWS_ARRAY,
- FLAVOUR_ROWS_GRID, FLAVOUR_ROWS_MASK) = range(8)
+ FLAVOUR_ROWS_GRID, FLAVOUR_ROWS_MASK, FLAVOUR_ROWS2D_ARRAY, FLAVOUR_ROWS2D_GRID) = range(10)
 
 _c = ctypes
 _vp, _i64, _int, _sz = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t
@@ -40,6 +40,7 @@ SIGNATURES = {
     "sdfk_debug_set_rtc_defs": (None, [_c.c_char_p]),
     "sdfk_eval_device": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _int]),
     "sdfk_eval_device_rows": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int]),
+    "sdfk_eval_device_rows2d": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int]),
     "sdfk_debug_row_masks": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _c.POINTER(_i64), _c.POINTER(_int), _vp]),
     "sdfk_eval_grid_sharded": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _int, _vp, _vp, _int]),
     "sdfk_eval_device_aux": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _i64, _vp, _vp, _int]),
@@ -230,10 +231,15 @@ class Program:
                                    mode), "sdfk_eval_host")
         return out
 
-    def eval_device(self, d_co, n, row_stride, d_out, stream=None, mode=MODE_AUTO, row_len=None):
+    def eval_device(self, d_co, n, row_stride, d_out, stream=None, mode=MODE_AUTO, row_len=None, flat=False):
         """Device pointers (ints). Asynchronous on `stream` (a hipStream_t as int, None = default).
         `row_len`: layout hint — the points are consecutive rows of that many points (the last grid
-        dimension of a generate_grid array); speeds up brick culling, never changes the field."""
+        dimension of a generate_grid array); speeds up brick culling, never changes the field.
+        `flat`: the rows are those of a flat (two-size) grid: z = 0, rows along y."""
+        if row_len and flat:
+            check(lib().sdfk_eval_device_rows2d(self._h, _vp(d_co), n, row_stride, int(row_len), _vp(d_out),
+                                                _vp(stream or 0), mode), "sdfk_eval_device_rows2d")
+            return
         if row_len:
             check(lib().sdfk_eval_device_rows(self._h, _vp(d_co), n, row_stride, int(row_len), _vp(d_out),
                                               _vp(stream or 0), mode), "sdfk_eval_device_rows")

@@ -716,7 +716,8 @@ static int rtc_compile(const std::string& src, std::vector<char>* out, std::stri
 // ---- code objects (per process) and modules (per device) -----------------------------------------
 static const char* const kFlavourFn[SDFK_FL_COUNT][2] = {
     {"sdfk_spec_v4", "sdfk_spec_v1"}, {"sdfk_spec_g4", "sdfk_spec_g1"}, {"sdfk_spec_t", nullptr}, {"sdfk_spec_tg", nullptr},
-    {"sdfk_spec_tmask", nullptr},     {"sdfk_spec_r", nullptr},         {"sdfk_spec_rg", nullptr}, {"sdfk_spec_rmask", nullptr}};
+    {"sdfk_spec_tmask", nullptr},     {"sdfk_spec_r", nullptr},         {"sdfk_spec_rg", nullptr}, {"sdfk_spec_rmask", nullptr},
+    {"sdfk_spec_r", nullptr},         {"sdfk_spec_rg", nullptr}};
 
 // hiprtc is entered by ONE thread at a time, and never while a code object is being loaded (hipModuleLoadData):
 // g_rtc_mu. Background builds are queued to one worker thread, which is drained before the interpreter / the
@@ -939,8 +940,10 @@ static inline unsigned blocks_for(long long n, int vec) {
     return (unsigned)((n + (long long)SDFK_BLOCK * vec - 1) / ((long long)SDFK_BLOCK * vec));
 }
 
+// flat: the caller states that the rows of the array are rows of a flat grid (z = 0, rows along y); grids know it
 static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long long n, float* d_out, void* stream_,
-               int mode, bool vec_ok, long long row_len = 0, const float* aux = nullptr, long long aux_stride = 0) {
+               int mode, bool vec_ok, long long row_len = 0, const float* aux = nullptr, long long aux_stride = 0,
+               bool flat = false) {
     if (!p) return fail(-1, "null program");
     if (n < 0) return fail(-1, "negative point count");
     if (p->n_aux > 0 && (!aux || aux_stride < n))
@@ -973,9 +976,10 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
     int flavour = arr ? SDFK_FL_PLAIN_ARRAY : SDFK_FL_PLAIN_GRID;
     const long long grow = grid ? (grid->n2 > 1 ? (long long)grid->n2 : (long long)grid->n1) : 0;
     if (!p->sites.empty() && mode != SDFK_MODE_NOCULL && mode != SDFK_MODE_INTERPRET) {
-        if (arr && rows_geometry(n, row_len, &rg)) flavour = SDFK_FL_ROWS_ARRAY;          // rows need no alignment beyond 4 bytes
+        if (arr && rows_geometry(n, row_len, &rg)) flavour = flat ? SDFK_FL_ROWS2D_ARRAY : SDFK_FL_ROWS_ARRAY;   // rows need no alignment beyond 4 bytes
         else if (arr && vec_ok) flavour = SDFK_FL_TILE_ARRAY;
-        else if (grid && grid->start % grow == 0 && rows_geometry(n, grow, &rg)) flavour = SDFK_FL_ROWS_GRID;
+        else if (grid && grid->start % grow == 0 && rows_geometry(n, grow, &rg))
+            flavour = grid->n2 > 1 ? SDFK_FL_ROWS_GRID : SDFK_FL_ROWS2D_GRID;
         else if (grid && vec_ok) flavour = SDFK_FL_TILE_GRID;
     }
     std::shared_ptr<SpecModule> sk;
@@ -1004,7 +1008,8 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
     const float* prm = d->d_params;
     const float* tab = d->d_tables;
     if (sk) {
-        if (flavour == SDFK_FL_ROWS_ARRAY || flavour == SDFK_FL_ROWS_GRID) {
+        if (flavour == SDFK_FL_ROWS_ARRAY || flavour == SDFK_FL_ROWS_GRID || flavour == SDFK_FL_ROWS2D_ARRAY ||
+            flavour == SDFK_FL_ROWS2D_GRID) {
             const unsigned per_tile = (unsigned)(tile_waves() * rows_wbricks(p));
             const unsigned tiles = ((rg.nbricks + per_tile - 1) / per_tile + 7u) & ~7u;   // whole rounds over the 8 XCDs
             if (arr) {
@@ -1112,6 +1117,17 @@ extern "C" int sdfk_eval_device_rows(sdfk_program* p, const float* d_co, int64_t
     SrcArray a = {d_co, (long long)row_stride};
     bool vec_ok = aligned16(d_co) && aligned16(d_out) && (row_stride % 4 == 0);
     return run(p, &a, nullptr, n, d_out, stream, mode, vec_ok, row_len);
+}
+
+extern "C" int sdfk_eval_device_rows2d(sdfk_program* p, const float* d_co, int64_t n, int64_t row_stride, int64_t row_len,
+                                       float* d_out, void* stream, int mode) {
+    if (!d_co || !d_out) return fail(-1, "sdfk_eval_device_rows2d: null device pointer");
+    if (row_stride < n) return fail(-1, "sdfk_eval_device_rows2d: row stride smaller than the point count");
+    if (row_len < 1 || (n > 0 && n % row_len != 0))
+        return fail(-1, "sdfk_eval_device_rows2d: the point count is not a multiple of the row length");
+    SrcArray a = {d_co, (long long)row_stride};
+    bool vec_ok = aligned16(d_co) && aligned16(d_out) && (row_stride % 4 == 0);
+    return run(p, &a, nullptr, n, d_out, stream, mode, vec_ok, row_len, nullptr, 0, true);
 }
 
 extern "C" int sdfk_eval_device_aux(sdfk_program* p, const float* d_co, int64_t n, int64_t row_stride, const float* d_aux,
@@ -1337,16 +1353,20 @@ extern "C" int sdfk_grid_fill(float* d_co, int64_t row_stride, const float* ax0,
 // changes (3-D grids: rows along z) or, failing that, at which x first changes (2-D grids: rows along y).
 // Only a layout hint for the row-block kernel — a wrong guess costs speed, never correctness.
 template <typename T>
-static int64_t detect_row_len(const T* co, int64_t n, int64_t stride) {
+static int64_t detect_row_len(const T* co, int64_t n, int64_t stride, bool* flat) {
     const int64_t scan = std::min<int64_t>(n, (int64_t)1 << 22);
-    const T *x = co, *y = co + stride;
+    const T *x = co, *y = co + stride, *z = co + 2 * stride;
     int64_t a = 0, b = 0;
+    *flat = false;
     for (int64_t i = 1; i < scan && (!a || !b); ++i) {
         if (!b && x[i] != x[0]) b = i;
         if (!a && (x[i] != x[0] || y[i] != y[0])) a = i;
     }
     if (a >= 32 && n % a == 0) return a;
-    if (b >= 32 && n % b == 0) return b;
+    if (b >= 32 && n % b == 0) {
+        *flat = z[0] == (T)0 && z[b - 1] == (T)0 && z[n - 1] == (T)0;   // (a hint: the kernel checks every point it reads)
+        return b;
+    }
     return 0;
 }
 
@@ -1432,9 +1452,10 @@ static int eval_host_impl(sdfk_program* p, const void* co, int co_dtype, int64_t
         return v >= 4096 ? v : ((int64_t)1 << 23);           // 8 Mi points: 96 MiB in + 32 MiB out per slot
     }();
     int64_t chunk = std::min<int64_t>(n, max_chunk);
+    bool flat = false;
     const int64_t row_len = p->sites.empty() ? 0
-                            : co_dtype == 0 ? detect_row_len(static_cast<const float*>(co), n, row_stride)
-                                            : detect_row_len(static_cast<const double*>(co), n, row_stride);
+                            : co_dtype == 0 ? detect_row_len(static_cast<const float*>(co), n, row_stride, &flat)
+                                            : detect_row_len(static_cast<const double*>(co), n, row_stride, &flat);
     if (row_len > 0 && chunk > row_len) chunk = chunk / row_len * row_len;   // whole rows per chunk
     const int64_t stride = (chunk + 63) & ~(int64_t)63;
     HostStage* st = nullptr;
@@ -1479,8 +1500,9 @@ static int eval_host_impl(sdfk_program* p, const void* co, int co_dtype, int64_t
             if (hipMemcpyAsync(sl.d_co + r * stride, h + r * stride, (size_t)m * sizeof(float), hipMemcpyHostToDevice, sl.stream) != hipSuccess)
                 rc = fail(-6, "sdfk_eval_host: host-to-device copy failed");
         if (rc == 0)
-            rc = (row_len > 0 && m % row_len == 0) ? sdfk_eval_device_rows(p, sl.d_co, m, stride, row_len, sl.d_out, sl.stream, mode)
-                                                   : sdfk_eval_device(p, sl.d_co, m, stride, sl.d_out, sl.stream, mode);
+            rc = !(row_len > 0 && m % row_len == 0) ? sdfk_eval_device(p, sl.d_co, m, stride, sl.d_out, sl.stream, mode)
+                 : flat                             ? sdfk_eval_device_rows2d(p, sl.d_co, m, stride, row_len, sl.d_out, sl.stream, mode)
+                                                    : sdfk_eval_device_rows(p, sl.d_co, m, stride, row_len, sl.d_out, sl.stream, mode);
         if (rc == 0) {
             const hipError_t e = out_on_device
                                      ? hipMemcpyAsync(out + s, sl.d_out, (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, sl.stream)

@@ -465,6 +465,9 @@ struct sdfk_rowregs {
 template <typename SRC>
 static __device__ __forceinline__ void sdfk_rows_load(const SRC& s, const sdfk_rowgeom& g, long long r0, unsigned k, int lane,
                                                       sdfk_rowregs& r) {
+    // SDFK_FLAT (flat grids: rows run along y, z = 0 everywhere): the roles of y and z are swapped from here to the
+    // end of phase A — r.Y holds z (the coordinate a row shares, which must be exactly 0) and r.Z holds y (the one
+    // that varies along the row) — so that "uniform", the staging and the bounding sphere work unchanged
     const bool interior = sdfk_interior(g.L, k);
 #pragma unroll
     for (int t = 0; t < SDFK_RLOADS; ++t) {
@@ -472,7 +475,11 @@ static __device__ __forceinline__ void sdfk_rows_load(const SRC& s, const sdfk_r
         if (r0 + dr >= g.R) dr = (int)(g.R - 1 - r0);
         long long flat;
         const int z = sdfk_win_z(r0 + dr, g.L, k, 4 * (lane & 7), &flat);
+        #ifdef SDFK_FLAT
+        sdfk_rows_fetch(s, g, r0, dr, z, interior, r.X[t], r.Z[t], r.Y[t]);
+#else
         sdfk_rows_fetch(s, g, r0, dr, z, interior, r.X[t], r.Y[t], r.Z[t]);
+#endif
     }
 }
 // phase A, part 2: z and the row heads to LDS, "every row has one x and one y", bounding sphere
@@ -492,6 +499,9 @@ static __device__ __forceinline__ void sdfk_rows_bounds(const sdfk_rowregs& r, i
         const bool head = (lane & 7) == 0;
         uni = uni && r.X[t].x == r.X[t].y && r.X[t].x == r.X[t].z && r.X[t].x == r.X[t].w && r.Y[t].x == r.Y[t].y &&
               r.Y[t].x == r.Y[t].z && r.Y[t].x == r.Y[t].w && (head || (px == r.X[t].x && py == r.Y[t].x));
+#ifdef SDFK_FLAT
+        uni = uni && r.Y[t].x == 0.0f;                             // (M2 * 0 drops out of every root transform exactly)
+#endif
         if (head) meta->xy[b][8 * t + (lane >> 3)] = make_float2(r.X[t].x, r.Y[t].x);
     }
     const bool uniform = __ballot(uni) == ~0ull;
@@ -519,7 +529,11 @@ static __device__ __forceinline__ void sdfk_rows_bounds(const sdfk_rowregs& r, i
     }
     const float r2 = sdfk_wave_max(d2);
     if (lane == 0) {
+#ifdef SDFK_FLAT
+        meta->bound[b] = make_float4(cx, cz, cy, 1.00001f * sqrtf(r2) + 1e-30f);
+#else
         meta->bound[b] = make_float4(cx, cy, cz, 1.00001f * sqrtf(r2) + 1e-30f);
+#endif
         meta->uniform[b] = uniform ? 1u : 0u;
     }
 }
@@ -615,23 +629,43 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
         const int last = (int)g.L - 1;
         V3P P[SDFK_NP];
         f2 res[SDFK_NP];
+        // the staged coordinate: z (SDFK_FLAT: y, see sdfk_rows_load)
+#ifdef SDFK_FLAT
+        SDFK_EACH P[q].y = *reinterpret_cast<const f2*>(&meta.z[b][lr * SDFK_RZ + zq + 2 * q]);
+#else
         SDFK_EACH P[q].z = *reinterpret_cast<const f2*>(&meta.z[b][lr * SDFK_RZ + zq + 2 * q]);
+#endif
 #ifdef SDFK_ABLATE_EVAL
         if (true) {
+#ifdef SDFK_FLAT
+            SDFK_EACH res[q] = P[q].y + __builtin_bit_cast(float, w0 ^ w1 ^ w2 ^ w3);
+#else
             SDFK_EACH res[q] = P[q].z + __builtin_bit_cast(float, w0 ^ w1 ^ w2 ^ w3);
+#endif
         } else
 #endif
         if (uniform) {
             const float2 xy = meta.xy[b][lr];
+#ifdef SDFK_FLAT
+            SDFK_EACH { P[q].x = sp<f2>(xy.x); P[q].z = sp<f2>(xy.y); }      // (x, 0)
+#else
             SDFK_EACH { P[q].x = sp<f2>(xy.x); P[q].y = sp<f2>(xy.y); }
+#endif
             sdfk_rows_culled<true>(xy.x, xy.y, P, w0, w1, w2, w3, PRM, TAB, res);
-        } else {                                                  // x, y of every point again (L2-resident)
+        } else {                                                  // the other coordinates of every point again (L2-resident)
 #pragma unroll
             for (int q = 0; q < SDFK_NP; q += 2) {
                 float4 X, Y, Z;
                 sdfk_rows_fetch(s, g, r0, dr, z + 2 * q, interior, X, Y, Z);
-                P[q].x = {X.x, X.y}; P[q].y = {Y.x, Y.y};
-                P[q + 1].x = {X.z, X.w}; P[q + 1].y = {Y.z, Y.w};
+                P[q].x = {X.x, X.y};
+                P[q + 1].x = {X.z, X.w};
+#ifdef SDFK_FLAT
+                P[q].z = {Z.x, Z.y};
+                P[q + 1].z = {Z.z, Z.w};
+#else
+                P[q].y = {Y.x, Y.y};
+                P[q + 1].y = {Y.z, Y.w};
+#endif
             }
             sdfk_rows_culled<false>(0.0f, 0.0f, P, w0, w1, w2, w3, PRM, TAB, res);
         }
@@ -731,16 +765,25 @@ struct Gen {
             instr(i, indent, rows && mode == 2);
             return;
         }
-        char buf[800];
+        char buf[1400];
         const uint32_t w = code[2 * i], poff = code[2 * i + 1];
         const unsigned a = (w >> 8) & 255u;
         if (rows) {
+            // (SDFK_FLAT: x shared, z = 0 exactly, y varies: M2 * 0 drops out of the sum without a rounding, so
+            //  fma(M1, y, fma(M0, x, -c)) IS op_xform's value and the x part is one value per row)
             snprintf(buf, sizeof buf,
-                     "%sif constexpr (ZRUN) { const V3T<float> bs = op_xform_base(X, Y, PRM + %u);\n"
+                     "%sif constexpr (ZRUN) {\n"
+                     "#ifdef SDFK_FLAT\n"
+                     "%s  const V3T<float> bs = op_xform_base_x(X, PRM + %u);\n"
                      "%s  const V3P bp = {sp<f2>(bs.x), sp<f2>(bs.y), sp<f2>(bs.z)};\n"
-                     "%s  SDFK_EACH C_%u[q] = op_xform_z(bp, C_0[q].z, PRM + %u); }\n"
-                     "%selse { SDFK_EACH C_%u[q] = op_xform(C_0[q], PRM + %u, TAB, 0); }\n",
-                     indent, poff, indent, indent, a, poff, indent, a, poff);
+                     "%s  SDFK_EACH C_%u[q] = op_xform_y(bp, C_0[q].y, PRM + %u);\n"
+                     "#else\n"
+                     "%s  const V3T<float> bs = op_xform_base(X, Y, PRM + %u);\n"
+                     "%s  const V3P bp = {sp<f2>(bs.x), sp<f2>(bs.y), sp<f2>(bs.z)};\n"
+                     "%s  SDFK_EACH C_%u[q] = op_xform_z(bp, C_0[q].z, PRM + %u);\n"
+                     "#endif\n"
+                     "%s} else { SDFK_EACH C_%u[q] = op_xform(C_0[q], PRM + %u, TAB, 0); }\n",
+                     indent, indent, poff, indent, indent, a, poff, indent, poff, indent, indent, a, poff, indent, a, poff);
         } else if (mode == 1) {
             snprintf(buf, sizeof buf,
                      "%s{ const V3T<float> bs = op_xform_base(C_0.x, C_0.y, PRM + %u); bases[%d] = bs.x; bases[%d] = bs.y; "
@@ -1023,7 +1066,8 @@ std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32
     const bool plain = all || flavour == SDFK_FL_PLAIN_ARRAY || flavour == SDFK_FL_PLAIN_GRID;
     const bool tile = !sites.empty() && (all || flavour == SDFK_FL_TILE_ARRAY || flavour == SDFK_FL_TILE_GRID ||
                                          flavour == SDFK_FL_TILE_MASK);
-    const bool rowk = !sites.empty() && (all || flavour == SDFK_FL_ROWS_ARRAY || flavour == SDFK_FL_ROWS_GRID ||
+    const bool flat = flavour == SDFK_FL_ROWS2D_ARRAY || flavour == SDFK_FL_ROWS2D_GRID;
+    const bool rowk = !sites.empty() && (all || flat || flavour == SDFK_FL_ROWS_ARRAY || flavour == SDFK_FL_ROWS_GRID ||
                                          flavour == SDFK_FL_ROWS_MASK);
     Gen g{ops, n_ops, code, n_instr, &sites, std::string()};
     g.s.reserve(sizeof(kEmbeddedDevice) + sizeof(kEmbeddedAccess) + sizeof(kWrappers) + sizeof(kTileKernel) +
@@ -1074,12 +1118,13 @@ std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32
         g.root_slot.clear();
         g.n_root = 0;
         g.find_roots();
+        if (flat) g.s += "\n#define SDFK_FLAT 1\n";
         g.s += "\n#define SDFK_NP 4\n#define SDFK_EACH _Pragma(\"unroll\") for (int q = 0; q < SDFK_NP; ++q)\n";
         g.emit_probe();
         g.emit_rows_culled(result_reg);
         g.s += kRowsKernel;
-        if (all || flavour == SDFK_FL_ROWS_ARRAY) g.s += kRowsArray;
-        if (all || flavour == SDFK_FL_ROWS_GRID) g.s += kRowsGrid;
+        if (all || flavour == SDFK_FL_ROWS_ARRAY || flavour == SDFK_FL_ROWS2D_ARRAY) g.s += kRowsArray;
+        if (all || flavour == SDFK_FL_ROWS_GRID || flavour == SDFK_FL_ROWS2D_GRID) g.s += kRowsGrid;
         if (all || flavour == SDFK_FL_ROWS_MASK) g.s += kRowsMask;
     }
     return g.s;

@@ -39,6 +39,8 @@ enum sdfk_flavour {
     SDFK_FL_ROWS_ARRAY,        // sdfk_spec_r
     SDFK_FL_ROWS_GRID,         // sdfk_spec_rg
     SDFK_FL_ROWS_MASK,         // sdfk_spec_rmask (test aid)
+    SDFK_FL_ROWS2D_ARRAY,      // sdfk_spec_r  built for flat grids (rows along y, z = 0: SDFK_FLAT)
+    SDFK_FL_ROWS2D_GRID,       // sdfk_spec_rg built for flat grids
     SDFK_FL_COUNT,
     SDFK_FL_ALL = SDFK_FL_COUNT   // everything in one unit (sdfk_program_source, developer tools)
 };

@@ -137,6 +137,17 @@ template <typename T> SDFK_DEV V3T<T> op_xform_z(V3T<T> base, T z, const float* 
 template <typename T> SDFK_DEV V3T<T> op_xform(V3T<T> p, const float* __restrict__ P, const float* __restrict__, int) {
     return op_xform_z(op_xform_base(p.x, p.y, P), p.z, P);
 }
+// Flat grids (z = 0 exactly, rows along y): M2 * 0 = 0 adds to the sum without a rounding, so
+// op_xform(x, y, 0) = fma(M1, y, fma(M0, x, -c)) bit for bit (up to the sign of a zero) — the x part is one value
+// per row (op_xform_base_x) and only op_xform_y depends on the point.
+template <typename T> SDFK_DEV V3T<T> op_xform_base_x(T x, const float* __restrict__ P) {
+    V3T<T> b = {sd_fma(sp<T>(P[0]), x, sp<T>(-P[9])), sd_fma(sp<T>(P[3]), x, sp<T>(-P[10])), sd_fma(sp<T>(P[6]), x, sp<T>(-P[11]))};
+    return b;
+}
+template <typename T> SDFK_DEV V3T<T> op_xform_y(V3T<T> base, T y, const float* __restrict__ P) {
+    V3T<T> q = {sd_fma(sp<T>(P[1]), y, base.x), sd_fma(sp<T>(P[4]), y, base.y), sd_fma(sp<T>(P[7]), y, base.z)};
+    return q;
+}
 // R = I, s = 1 (I·co and co/1.0 are exact in the reference): q = p - t.  Also move_sdf C/modifications.py:1283
 template <typename T> SDFK_DEV V3T<T> op_xlate(V3T<T> p, const float* __restrict__ P, const float* __restrict__, int) {
     V3T<T> q = {p.x - P[0], p.y - P[1], p.z - P[2]};

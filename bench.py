@@ -196,7 +196,8 @@ class Run:
 
     def step(self):
         self.prog.eval_device(self.co.data_ptr(), self.count, self.stride, self.out.data_ptr(), stream=self.stream,
-                              mode=self.mode, row_len=self.row_len if self.use_rows else None)
+                              mode=self.mode, row_len=self.row_len if self.use_rows else None,
+                              flat=self.axes[2].size == 1)
 
     def fence(self):
         self.torch.cuda.synchronize()
@@ -529,7 +530,7 @@ def main():
             def evaluate_chunk(cstart, ccount, out_view):
                 off = cstart - start
                 prog.eval_device(run.co.data_ptr() + 4 * off, ccount, stride, out_view.data_ptr(), stream=stream, mode=mode,
-                                 row_len=row_len if not args.no_rows else None)
+                                 row_len=row_len if not args.no_rows else None, flat=axes[2].size == 1)
             for schedule in ("direct", "collective"):
                 try:
                     def once():

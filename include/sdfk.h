@@ -80,6 +80,8 @@ int sdfk_program_compile_check(sdfk_program* prog, size_t* code_size);
 #define SDFK_FLAVOUR_ROWS_ARRAY 5  /* exact culling on blocks of 32 points x 16 grid rows (sdfk_eval_device_rows) */
 #define SDFK_FLAVOUR_ROWS_GRID 6
 #define SDFK_FLAVOUR_ROWS_MASK 7   /* test aid (sdfk_debug_row_masks) */
+#define SDFK_FLAVOUR_ROWS2D_ARRAY 8 /* the row-block kernel built for flat grids (sdfk_eval_device_rows2d) */
+#define SDFK_FLAVOUR_ROWS2D_GRID 9
 /* Build (or fetch from the caches) ONE flavour, GPU or not: its code-object size and the seconds this call took. */
 int sdfk_program_compile_flavour(sdfk_program* prog, int flavour, size_t* code_size, double* seconds);
 /* Wait until no background kernel build is queued or running (call before the process tears hiprtc down: the Python
@@ -106,6 +108,13 @@ int sdfk_eval_device(sdfk_program* prog, const float* d_co, int64_t n, int64_t r
  * one y per row" test and every skip decision are derived from the coordinates actually read). */
 int sdfk_eval_device_rows(sdfk_program* prog, const float* d_co, int64_t n, int64_t row_stride, int64_t row_len,
                           float* d_out, void* stream, int mode);
+/* The same for the array of a FLAT grid (generate_grid with two sizes, cores/helper_functions.py:63-75: rows run
+ * along y, row_len = the second grid dimension, the z row is all zeros): the kernel is built so that the x part of
+ * every root transform is computed once per row. Again a hint only — bricks whose z is not exactly 0 or whose x
+ * varies along a row take the general path, and the field is bit-identical to sdfk_eval_device (up to the sign of
+ * a zero). */
+int sdfk_eval_device_rows2d(sdfk_program* prog, const float* d_co, int64_t n, int64_t row_stride, int64_t row_len,
+                            float* d_out, void* stream, int mode);
 /* Host-buffer convenience: stages co (dtype 0 = fp32, 1 = fp64; (3, n) with row stride in elements)
  * through device memory in chunks, evaluates and copies the fp32 field back. */
 int sdfk_eval_host(sdfk_program* prog, const void* co, int co_dtype, int64_t n, int64_t row_stride, float* out,

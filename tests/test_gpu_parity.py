@@ -189,7 +189,7 @@ def test_empty_and_ragged_inputs(engine):
         tree.create(np.zeros((2, 10)))
 
 
-def _device_eval(engine, prog, co32, n, stride, misalign=0, mode=None, row_len=None):
+def _device_eval(engine, prog, co32, n, stride, misalign=0, mode=None, row_len=None, flat=False):
     """eval_device on raw HIP buffers (optionally shifted by `misalign` floats to defeat 16-B alignment)."""
     lib = engine.lib()
     d_co = lib.sdfk_malloc((3 * stride + misalign + 4) * 4)
@@ -200,7 +200,7 @@ def _device_eval(engine, prog, co32, n, stride, misalign=0, mode=None, row_len=N
         engine.check(lib.sdfk_memcpy_h2d(ctypes.c_void_p(d_co + 4 * misalign), host.ctypes.data_as(ctypes.c_void_p),
                                          host.nbytes), "h2d")
         prog.eval_device(d_co + 4 * misalign, n, stride, d_out + 4 * misalign,
-                         mode=engine.MODE_SPECIALIZED if mode is None else mode, row_len=row_len)
+                         mode=engine.MODE_SPECIALIZED if mode is None else mode, row_len=row_len, flat=flat)
         engine.check(lib.sdfk_sync(None), "sync")
         out = np.empty(n, dtype=np.float32)
         engine.check(lib.sdfk_memcpy_d2h(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_out + 4 * misalign),
@@ -454,6 +454,10 @@ def test_row_block_culling_is_bit_exact(name, engine):
         plain = _device_eval(engine, prog, co32, n, stride, mis, engine.MODE_NOCULL)
         rows = _device_eval(engine, prog, co32, n, stride, mis, engine.MODE_SPECIALIZED, row_len=row_len)
         np.testing.assert_array_equal(rows, plain)
+        # the kernel built for flat grids (x shared by a row, z = 0): on the 2-D scenes its fast path, on the 3-D
+        # ones (z is not 0, x and y change along "rows") every brick must fall back to the general path
+        flat = _device_eval(engine, prog, co32, n, stride, mis, engine.MODE_SPECIALIZED, row_len=row_len, flat=True)
+        np.testing.assert_array_equal(flat, plain)
         # grid flavour (coordinates from the per-axis tables): the whole grid and a slab of whole rows
         axes = [a.astype(np.float32) for a in co.grid_axes]
         np.testing.assert_array_equal(prog.eval_grid_host(axes), plain)
