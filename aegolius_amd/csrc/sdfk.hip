@@ -523,6 +523,15 @@ static int tile_wbricks() {
 static int tile_points() { return tile_waves() * tile_wbricks() * 128; }
 // bricks per wave of the row-block kernel: 2 — except for big trees (> 150 instructions, e.g. the 50-primitive 2-D
 // union), whose whole-tree probe is better shared by 16 bricks per workgroup than by 8 (measured -11 %)
+// waves per workgroup of the row-block kernel: 2 — many small workgroups interleave their memory and VALU phases
+// best (north-star tree -0.5 %, 50-primitive flat union -10 % against 4 waves)
+static std::atomic<int> g_rwaves_override{0};
+static int rows_waves(const sdfk_program*) {
+    if (const int o = g_rwaves_override.load()) return o;
+    return 2;
+}
+static int rows_wbricks(const sdfk_program* p);
+static int rows_geo(const sdfk_program* p) { return rows_wbricks(p) | (rows_waves(p) << 4); }
 static int rows_wbricks(const sdfk_program* p) {
     static int forced = [] { const char* e = getenv("SDFK_RWBRICKS"); int t = e ? atoi(e) : 0; return (t >= 1 && t <= 16) ? t : 0; }();
     if (const int o = g_rwbricks_override.load()) return o;
@@ -626,7 +635,7 @@ static std::string g_rtc_defs = [] { const char* e = getenv("SDFK_RTC_DEFS"); re
 extern "C" void sdfk_debug_set_rtc_defs(const char* defs) {
     std::lock_guard<std::mutex> lk(g_defs_mu);
     std::string rest;
-    int tw = 0, rwb = 0;
+    int tw = 0, rwb = 0, rwv = 0;
     const std::string all = defs ? defs : "";
     size_t pos = 0;
     while (pos < all.size()) {
@@ -635,20 +644,24 @@ extern "C" void sdfk_debug_set_rtc_defs(const char* defs) {
         const std::string tok = all.substr(pos, sp - pos);
         if (tok.compare(0, 14, "-DSDFK_TWAVES=") == 0) tw = atoi(tok.c_str() + 14);
         else if (tok.compare(0, 16, "-DSDFK_RWBRICKS=") == 0) rwb = atoi(tok.c_str() + 16);
+        else if (tok.compare(0, 14, "-DSDFK_RWAVES=") == 0) rwv = atoi(tok.c_str() + 14);
         else if (!tok.empty()) rest += tok + " ";
         pos = sp + 1;
     }
     g_twaves_override = (tw >= 1 && tw <= 16) ? tw : 0;
-    g_rwbricks_override = (rwb >= 1 && rwb <= 16) ? rwb : 0;
+    g_rwbricks_override = (rwb >= 1 && rwb <= 15) ? rwb : 0;
+    g_rwaves_override = (rwv >= 1 && rwv <= 16) ? rwv : 0;
     g_rtc_defs = rest;
 }
-static std::vector<std::string> rtc_options(int rwb) {
+// geo: bricks per wave | waves per workgroup << 4 of the row-block kernel (rows_geo)
+static std::vector<std::string> rtc_options(int geo) {
+    const int rwb = geo & 15, rwaves = (geo >> 4) ? (geo >> 4) : 2;
     std::vector<std::string> o = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17",
                                   // -fno-honor-nans -mno-amdgpu-ieee: v_min/v_max without the canonicalising pre-op (same
                                   // flags as the hipcc build of the interpreter kernel: both flavours stay bit-identical)
                                   "-fno-honor-nans", "-mno-amdgpu-ieee",
                                   "-DSDFK_TWAVES=" + std::to_string(tile_waves()), "-DSDFK_WBRICKS=" + std::to_string(tile_wbricks()),
-                                  "-DSDFK_RWBRICKS=" + std::to_string(rwb)};
+                                  "-DSDFK_RWBRICKS=" + std::to_string(rwb), "-DSDFK_RWAVES=" + std::to_string(rwaves)};
     std::string all;
     {
         std::lock_guard<std::mutex> lk(g_defs_mu);
@@ -833,7 +846,7 @@ extern "C" int sdfk_program_compile_check(sdfk_program* p, size_t* code_size) {
     // every flavour this program can be launched with, each as its own translation unit (what a run would build)
     if (!p) return fail(-1, "null program");
     size_t total = 0;
-    const int rwb = rows_wbricks(p);
+    const int rwb = rows_geo(p);
     for (int f = 0; f < SDFK_FL_COUNT; ++f) {
         if (p->sites.empty() && f != SDFK_FL_PLAIN_ARRAY && f != SDFK_FL_PLAIN_GRID) continue;
         std::shared_ptr<CodeObject> e = code_get(flavour_key(p, f, rwb), [&] { return flavour_source(p, f); }, rwb, true);
@@ -849,7 +862,7 @@ extern "C" int sdfk_program_compile_flavour(sdfk_program* p, int flavour, size_t
     if (flavour < 0 || flavour >= SDFK_FL_COUNT) return fail(-1, "sdfk_program_compile_flavour: unknown flavour");
     if (p->sites.empty() && flavour != SDFK_FL_PLAIN_ARRAY && flavour != SDFK_FL_PLAIN_GRID)
         return fail(-2, "sdfk_program_compile_flavour: the program has no cull sites");
-    const int rwb = rows_wbricks(p);
+    const int rwb = rows_geo(p);
     const auto t0 = std::chrono::steady_clock::now();
     std::shared_ptr<CodeObject> e = code_get(flavour_key(p, flavour, rwb), [&] { return flavour_source(p, flavour); }, rwb, true);
     if (e->state != 2) return fail(-3, e->error);
@@ -861,7 +874,7 @@ extern "C" int sdfk_program_compile_flavour(sdfk_program* p, int flavour, size_t
 // The module of one flavour on one device. wait = false: nullptr while the code object is still being built in the
 // background (the caller serves this call from the interpreter kernel — same bits). *err is set on failure.
 static std::shared_ptr<SpecModule> get_module(sdfk_program* p, int device, int flavour, bool wait, std::string* err) {
-    const int rwb = rows_wbricks(p);
+    const int rwb = rows_geo(p);
     const std::string key = flavour_key(p, flavour, rwb);
     std::shared_ptr<SpecModule> m;
     {
@@ -1010,13 +1023,14 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
     if (sk) {
         if (flavour == SDFK_FL_ROWS_ARRAY || flavour == SDFK_FL_ROWS_GRID || flavour == SDFK_FL_ROWS2D_ARRAY ||
             flavour == SDFK_FL_ROWS2D_GRID) {
-            const unsigned per_tile = (unsigned)(tile_waves() * rows_wbricks(p));
+            const unsigned per_tile = (unsigned)(rows_waves(p) * rows_wbricks(p));
             const unsigned tiles = ((rg.nbricks + per_tile - 1) / per_tile + 7u) & ~7u;   // whole rounds over the 8 XCDs
+            const unsigned rthreads = 64u * (unsigned)rows_waves(p);
             if (arr) {
                 const float* co = arr->co;
                 long long stride = arr->stride;
                 void* args[] = {&prm, &tab, &co, &stride, &rg, &d_out};
-                HIPCHK(hipModuleLaunchKernel(sk->fn[0], tiles, 1, 1, tile_threads(), 1, 1, 0, stream, args, nullptr));
+                HIPCHK(hipModuleLaunchKernel(sk->fn[0], tiles, 1, 1, rthreads, 1, 1, 0, stream, args, nullptr));
             } else {
                 // whole grid rows (x-slabs of a sharded evaluation always are); rows along the third axis, or along
                 // the second one when the grid is flat (n2 == 1)
@@ -1024,7 +1038,7 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
                 rg.row0 = grid->start / grow;
                 rg.yrows = grid->n2 > 1 ? 0 : 1;
                 void* args[] = {&prm, &tab, &g, &rg, &d_out};
-                HIPCHK(hipModuleLaunchKernel(sk->fn[0], tiles, 1, 1, tile_threads(), 1, 1, 0, stream, args, nullptr));
+                HIPCHK(hipModuleLaunchKernel(sk->fn[0], tiles, 1, 1, rthreads, 1, 1, 0, stream, args, nullptr));
             }
             return 0;
         }
@@ -1163,8 +1177,8 @@ extern "C" int sdfk_debug_row_masks(sdfk_program* p, const float* d_co, int64_t 
     const float* tab = d->d_tables;
     long long stride = row_stride;
     void* args[] = {&prm, &tab, &d_co, &stride, &rg, &d_masks};
-    const unsigned per_tile = (unsigned)(tile_waves() * rows_wbricks(p));
-    HIPCHK(hipModuleLaunchKernel(sk->fn[0], (rg.nbricks + per_tile - 1) / per_tile, 1, 1, tile_threads(), 1, 1, 0, stream,
+    const unsigned per_tile = (unsigned)(rows_waves(p) * rows_wbricks(p));
+    HIPCHK(hipModuleLaunchKernel(sk->fn[0], (rg.nbricks + per_tile - 1) / per_tile, 1, 1, 64 * rows_waves(p), 1, 1, 0, stream,
                                  args, nullptr));
     return 0;
 }

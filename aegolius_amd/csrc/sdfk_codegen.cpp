@@ -375,14 +375,17 @@ static const char kRowsKernel[] = R"SDFKR(
 #ifndef SDFK_RWBRICKS
 #define SDFK_RWBRICKS 2
 #endif
+#ifndef SDFK_RWAVES
+#define SDFK_RWAVES 2                           // waves per workgroup (host launch code must agree: sdfk.hip)
+#endif
 #define SDFK_RZ 32
 #define SDFK_RLPR (SDFK_RZ / (2 * SDFK_NP))     // lanes per row in phase C
 #define SDFK_RROWS (64 / SDFK_RLPR)             // rows per brick
 #define SDFK_RBRICK (SDFK_RZ * SDFK_RROWS)
 #define SDFK_RLOADS (SDFK_RROWS / 8)            // load instructions per array and brick
-#define SDFK_RNBRICK (SDFK_TWAVES * SDFK_RWBRICKS)
+#define SDFK_RNBRICK (SDFK_RWAVES * SDFK_RWBRICKS)
 static_assert(SDFK_NP == 2 || SDFK_NP == 4, "2 or 4 packed pairs per lane");
-static_assert(SDFK_RNBRICK <= 64 * SDFK_TWAVES, "one probe lane per brick");
+static_assert(SDFK_RNBRICK <= 64 * SDFK_RWAVES, "one probe lane per brick");
 
 typedef float sdfk_f4u __attribute__((ext_vector_type(4), aligned(4)));
 
@@ -548,7 +551,9 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
     rb0 = __builtin_amdgcn_readfirstlane(q0 / g.nchunk);        // (the division runs on the vector unit: back to an SGPR,
     c0 = q0 - rb0 * g.nchunk;                                    //  so that what is derived from it stays scalar)
     unsigned rb = rb0, c = c0;
-#ifdef SDFK_HOIST
+#if SDFK_RWBRICKS <= 2 && !defined(SDFK_NOHOIST)
+    // two bricks per wave: all of the wave's loads are in flight before the first one is used (-0.8 % together with
+    // two-wave workgroups on the north-star grid; with four bricks per wave the registers this takes cost more)
     sdfk_rowregs hregs[SDFK_RWBRICKS];
 #pragma unroll
     for (int j = 0; j < SDFK_RWBRICKS; ++j) {
@@ -559,8 +564,6 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
     for (int j = 0; j < SDFK_RWBRICKS; ++j)
         if (q0 + j < g.nbricks) sdfk_rows_bounds(hregs[j], lane, meta, wave * SDFK_RWBRICKS + j);
 #else
-    // (hoisting all loads of the wave ahead of the first use was measured slower: registers, not memory-level
-    // parallelism, limit this phase)
 #pragma unroll
     for (int j = 0; j < SDFK_RWBRICKS; ++j) {
 #ifdef SDFK_ABLATE_EDGE
@@ -694,7 +697,7 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
 #endif
 )SDFKR";
 static const char kRowsArray[] = R"SDFKR(
-extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) SDFK_ROWS_ATTR void sdfk_spec_r(
+extern "C" __global__ __launch_bounds__(64 * SDFK_RWAVES) SDFK_ROWS_ATTR void sdfk_spec_r(
     const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
     sdfk_rowgeom g, float* __restrict__ out) {
     const SrcArray s = {co, stride};
@@ -704,7 +707,7 @@ extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) SDFK_ROWS_ATTR void sdfk_
 static const char kRowsGrid[] = R"SDFKR(
 // the same on a regular grid expanded from three per-axis tables (no coordinate array: 4 B/point); the slab
 // starts at a row boundary and out[0] is its first point
-extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_rg(
+extern "C" __global__ __launch_bounds__(64 * SDFK_RWAVES) void sdfk_spec_rg(
     const float* __restrict__ PRM, const float* __restrict__ TAB, SrcGrid s, sdfk_rowgeom g, float* __restrict__ out) {
     sdfk_rows_kernel(PRM, TAB, s, g, out);
 }
@@ -712,7 +715,7 @@ extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_rg(
 static const char kRowsMask[] = R"SDFKR(
 // test aid: the skip masks (two 64-bit words per brick: sites 0-31, 32-63; bit 2k = first operand of site k
 // skipped, bit 2k+1 = second) followed by the "uniform rows" flag in a third word
-extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_rmask(
+extern "C" __global__ __launch_bounds__(64 * SDFK_RWAVES) void sdfk_spec_rmask(
     const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
     sdfk_rowgeom g, unsigned long long* __restrict__ masks) {
     __shared__ __attribute__((aligned(16))) sdfk_rowmeta meta;

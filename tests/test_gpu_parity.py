@@ -830,6 +830,42 @@ def test_largest_baseline_grid_2049_cubed_on_one_gpu(engine):
         check("tree_cfg5_three_level", got, sdf_oracle.evaluate(tree, pts))
 
 
+def test_flat_baseline_grid_16385_squared(engine):
+    """BASELINE configs[3] at FULL size: the 50-primitive n-ary UNION on the 16385 x 16385 flat grid (268 M points),
+    resident array + row hint + flat hint (the kernel built for flat grids) and straight from the axis tables;
+    20,000 sampled points against the oracle, the two routes and the un-culled kernel agree on a window."""
+    import torch
+    from aegolius_amd.cores.helper_functions import grid_axes
+    tree = scenes.cfg4_scene2d(ns)
+    prog = engine.Program.from_lowered(lower_geometry(tree))
+    axes = [a.astype(np.float32) for a in grid_axes((10, 10), (16384, 16384))[0]]
+    n1d = int(axes[0].size)
+    n = n1d * n1d
+    assert n1d == 16385 and axes[2].size == 1
+    co = torch.empty((3, n), dtype=torch.float32, device="cuda")
+    out = torch.empty((n,), dtype=torch.float32, device="cuda")
+    engine.grid_fill(co.data_ptr(), n, axes, 0, n)
+    prog.eval_device(co.data_ptr(), n, n, out.data_ptr(), mode=engine.MODE_SPECIALIZED, row_len=n1d, flat=True)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(16385)
+    idx = np.unique(np.concatenate([rng.integers(0, n, 20000), [0, n - 1, n1d - 1, n1d]]))
+    got = out[torch.from_numpy(idx).cuda()].cpu().numpy()
+    ix, iy = np.divmod(idx, n1d)
+    pts = np.stack([axes[0][ix], axes[1][iy], np.zeros(idx.size, dtype=np.float32)]).astype(np.float64)
+    with np.errstate(all="ignore"):
+        check("tree_cfg4_union50_2d", got, sdf_oracle.evaluate(tree, pts))
+    # a window of whole rows: axis-table route and un-culled kernel
+    r0, rows = 5000, 40
+    w0, wn = r0 * n1d, rows * n1d
+    win = torch.empty((wn,), dtype=torch.float32, device="cuda")
+    prog.eval_grid(axes, w0, wn, win.data_ptr(), mode=engine.MODE_SPECIALIZED)
+    torch.cuda.synchronize()
+    assert torch.equal(win, out[w0:w0 + wn])
+    prog.eval_device(co.data_ptr() + 4 * w0, wn, n, win.data_ptr(), mode=engine.MODE_NOCULL)
+    torch.cuda.synchronize()
+    assert torch.equal(win, out[w0:w0 + wn])
+
+
 def test_apply_and_generic_geometry_variants(engine, golden_inputs):
     """EuclideanTransform.apply / apply_ec_transforms (reference cores/transformations.py:232-264) and the
     GenericGeometry2D / 3D classes evaluate like the object protocol they are part of."""

@@ -1,22 +1,29 @@
 #!/bin/bash
-# Developer tool (GPU box): everything profiles/ quotes for the headline workload, in one call.
-# usage: tools/collect_profiles.sh <tag>      -> gpurun_out/<tag>/
-set -e
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=$1
-OUT=$R/gpurun_out/$TAG
-mkdir -p "$OUT"
+# Developer tool (GPU box): the evidence set of one round. Writes gpurun_out/<tag>_*; copy what is to be judged to profiles/.
+#   tools/collect_profiles.sh r02
+set -u
+tag=${1:-r02}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+mkdir -p "$O"
 cd "$R"
-python bench.py > "$OUT/cfg2_bench.json" 2> "$OUT/cfg2_bench.err"
-python bench.py --no-rows --cpu-seconds 0 > "$OUT/cfg2_bench_line_bricks.json" 2>> "$OUT/cfg2_bench.err"
-python bench.py --mode nocull --cpu-seconds 0 > "$OUT/cfg2_bench_nocull.json" 2>> "$OUT/cfg2_bench.err"
-python bench.py --workload cfg1 --cpu-seconds 0 > "$OUT/cfg1_bench.json" 2>> "$OUT/cfg2_bench.err"
-python bench.py --workload cfg3 --cpu-seconds 0 > "$OUT/cfg3_bench.json" 2>> "$OUT/cfg2_bench.err"
-python bench.py --workload cfg5 --cpu-seconds 0 > "$OUT/cfg5_bench.json" 2>> "$OUT/cfg2_bench.err"
-python bench.py --workload cfg4 --grid 16384 --cpu-seconds 0 > "$OUT/cfg4_bench.json" 2>> "$OUT/cfg2_bench.err"
+B="python3 $R/bench.py --steps 20 --warmup 5 --no-extras --cpu-seconds 0"
+# 1. the driver's command, with every extra
+python3 bench.py --steps 20 --warmup 5 > "$O/${tag}_cfg2_bench.json" 2> "$O/${tag}_cfg2_bench.err"
+# 2. the same timed region under rocprofv3 (kernel trace + stats), then the counter passes (each in its own run)
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -- python "$R/bench.py" --steps 20 --warmup 3 --cpu-seconds 0 --no-host-path --no-next-rows > "$OUT/cfg2_bench_under_rocprof.json" 2> "$OUT/stats.err"
-cp $(find "$OUT/stats" -name "*kernel_stats.csv" | head -1) "$OUT/cfg2_kernel_stats.csv"
-bash "$R/tools/pmc_collect.sh" "$TAG/pmc"
-python "$R/tools/pmc_summarize.py" "$OUT/pmc" sdfk_spec_r "$OUT/cfg2_pmc_summary.json" > /dev/null
-echo done
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${tag}_prof" -- $B > "$O/${tag}_cfg2_bench_under_rocprof.json" 2> "$O/${tag}_prof.log"
+cp "$O/${tag}_prof"/*/*kernel_stats.csv "$O/${tag}_cfg2_kernel_stats.csv"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d "$O/${tag}_pmc/sq" -- $B > /dev/null 2> "$O/${tag}_pmc_sq.log"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/${tag}_pmc/fetch" -- $B > /dev/null 2> "$O/${tag}_pmc_fetch.log"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/${tag}_pmc/write" -- $B > /dev/null 2> "$O/${tag}_pmc_write.log"
+cd "$R"
+python3 tools/pmc_summarize.py "$O/${tag}_pmc" sdfk_spec_r "$O/${tag}_cfg2_pmc_summary.json" > /dev/null
+# 3. the other BASELINE configs on the same box (headline + verification only)
+for w in cfg1 cfg3 cfg5; do
+  python3 bench.py --workload $w --steps 20 --warmup 5 --no-extras --cpu-seconds 0 > "$O/${tag}_${w}_bench.json" 2>/dev/null
+done
+python3 bench.py --workload cfg4 --grid 16384 --steps 20 --warmup 5 --no-extras --cpu-seconds 0 > "$O/${tag}_cfg4_bench.json" 2>/dev/null
+python3 bench.py --mode nocull --steps 10 --warmup 3 --no-extras --cpu-seconds 0 > "$O/${tag}_cfg2_bench_nocull.json" 2>/dev/null
+python3 bench.py --mode interpret --steps 5 --warmup 2 --no-extras --cpu-seconds 0 > "$O/${tag}_cfg2_bench_interpreter.json" 2>/dev/null
+echo "collected $tag"

@@ -30,6 +30,9 @@ def main(root, kernel="sdfk_spec_v4", out=None):
         rec["hbm_read_bytes_per_launch"] = avg["FETCH_SIZE"] * 1024 * 2
         rec["hbm_write_bytes_per_launch"] = avg["WRITE_SIZE"] * 1024
         rec["hbm_bytes_per_launch"] = rec["hbm_read_bytes_per_launch"] + rec["hbm_write_bytes_per_launch"]
+    if "SQ_ACTIVE_INST_VALU" in avg and "GRBM_GUI_ACTIVE" in avg:
+        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs; GRBM_GUI_ACTIVE is the sum over the 8 XCDs
+        rec["valu_active_frac"] = avg["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * avg["GRBM_GUI_ACTIVE"] / 8.0)
     print(json.dumps(rec, indent=1))
     if out:
         with open(out, "w") as f:
