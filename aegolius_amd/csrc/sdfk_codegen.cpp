@@ -395,6 +395,9 @@ struct sdfk_rowmeta {
     float4 bound[SDFK_RNBRICK];
     unsigned long long mask0[SDFK_RNBRICK], mask1[SDFK_RNBRICK];
     unsigned uniform[SDFK_RNBRICK];
+#ifdef SDFK_LDSPAD
+    float pad[SDFK_LDSPAD / 4];                 // experiment: a larger LDS footprint per workgroup
+#endif
 };
 struct sdfk_rowgeom {
     unsigned L, nchunk, nbricks;                // row length, windows per row, bricks in total
@@ -596,6 +599,9 @@ template <typename SRC>
 static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict__ PRM, const float* __restrict__ TAB,
                                                         const SRC& s, const sdfk_rowgeom& g, float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) sdfk_rowmeta meta;
+#ifdef SDFK_LDSPAD
+    if (g.L == 0xffffffffu) meta.pad[threadIdx.x] = 1.0f;
+#endif
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane / SDFK_RLPR;
     const int zq = (lane % SDFK_RLPR) * (2 * SDFK_NP);
