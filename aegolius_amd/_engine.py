@@ -49,6 +49,8 @@ SIGNATURES = {
     "sdfk_grid_box_average": (_int, [_vp, _i64, _i64, _i64, _int, _int, _int, _int, _vp, _vp]),
     "sdfk_grid_edge_detect": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "sdfk_grid_signed": (_int, [_vp, _i64, _i64, _i64, _c.c_float, _int, _vp, _vp]),
+    "sdfk_grid_boundary_mask": (_int, [_vp, _i64, _c.c_float, _vp, _vp]),
+    "sdfk_grid_signed_slab": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _vp, _vp]),
     "sdfk_eval_host": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _int, _int]),
     "sdfk_eval_host_resident": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _int, _int]),
     "sdfk_field_select_scratch": (_sz, [_i64]),

@@ -439,11 +439,14 @@ def _run_staged(lower, co, root=None, resident=False):
 # ---------------------------------------------------------------------------------------------------
 # staged evaluation of ONE SLAB of a grid (multi-GPU: aegolius_amd.distributed)
 # ---------------------------------------------------------------------------------------------------
-def _halo_planes(stages, grid_shape, n_total):
+def _halo_planes(stages, grid_shape, n_total, exchange=False):
     """Planes of halo a slab needs so that its interior is exact after every operator of `stages`: the reach
-    of each box / edge kernel along the first axis, times its iterations, summed over the chain."""
+    of each box / edge kernel along the first axis, times its iterations, summed over the chain. `signed` needs no
+    halo — its scan lines need the whole grid's boundary bits, which the ranks exchange (`exchange`)."""
     halo = 0
     for _low, node, _key, _params in stages:
+        if exchange and node.name in ("signed", "signed_old"):
+            continue
         if node.name not in ("conv_averaging", "conv_edge_detection"):
             raise NotImplementedError(
                 "%r cannot run on a slab of the grid (it scans whole grid lines or runs user code on the whole "
@@ -461,12 +464,16 @@ def _halo_planes(stages, grid_shape, n_total):
     return halo
 
 
-def evaluate_slab_staged(lower, axes, plane0, planes, out_ptr):
+def evaluate_slab_staged(lower, axes, plane0, planes, out_ptr, comm=None):
     """Planes [plane0, plane0 + planes) of the grid spanned by `axes` (three per-axis tables) for a tree with
-    conv_averaging / conv_edge_detection nodes, written to the device buffer `out_ptr` (planes * n1 * n2 fp32).
+    conv_averaging / conv_edge_detection / signed nodes, written to the device buffer `out_ptr` (planes * n1 * n2 fp32).
     The slab is evaluated together with a halo of neighbouring planes (recomputed locally: the per-point stages are
     cheap, nothing is exchanged); at the true ends of the grid the operators' reflect boundary applies, at the cut
-    ends the contaminated halo planes are dropped. Bit-identical to the same planes of a whole-grid evaluation."""
+    ends the contaminated halo planes are dropped. Bit-identical to the same planes of a whole-grid evaluation.
+
+    `signed` scans whole grid lines: it needs `comm`, the exchange between the slabs — an object with
+    `allreduce_min(float) -> float` and `allgather_bytes(ptr, start, count, total) -> ptr` (device pointers; the
+    bytes [start, start + count) of a `total`-byte array, returns the whole array) — see distributed._TorchComm."""
     _engine.require_gpu()
     lib = _engine.lib()
     vp = _engine._vp
@@ -476,13 +483,14 @@ def evaluate_slab_staged(lower, axes, plane0, planes, out_ptr):
     grid_shape = (n0, n1) if flat2d else (n0, n1, n2)
     plane = n1 * n2
     stages, final, _fields = _plan_stages(lower)
-    halo = _halo_planes(stages, grid_shape, n0 * plane)
+    halo = _halo_planes(stages, grid_shape, n0 * plane, exchange=comm is not None)
     e0, e1 = max(0, plane0 - halo), min(n0, plane0 + planes + halo)
     n = (e1 - e0) * plane
     ext_shape = (e1 - e0, n1) if flat2d else (e1 - e0, n1, n2)
     stride = (n + 63) // 64 * 64
     d_aux = lib.sdfk_malloc(max(1, len(stages)) * stride * 4)
     d_tmp = lib.sdfk_malloc(stride * 4)
+    d_mask = None
     if not d_aux or not d_tmp:
         raise _engine.SdfkError("staged slab evaluation: out of device memory")
     try:
@@ -494,7 +502,42 @@ def evaluate_slab_staged(lower, axes, plane0, planes, out_ptr):
         for k, (lowered, node, key, _params) in enumerate(stages):
             row = d_aux + 4 * k * stride
             run_program(lowered, row, k)
-            _apply_grid_op(lib, node, key, row, n, lower, known, None, d_tmp, shape=ext_shape)
+            if node.name in ("signed", "signed_old"):
+                if flat2d:
+                    raise ValueError("Dimension of the kernel and the field must match!")   # conv_averaging((2, 2, 1)) on 2-D
+                shape = _grid_shape(n0 * plane, node.args["co_resolution"])
+                if tuple(shape) != tuple(grid_shape):
+                    raise ValueError("co_resolution %r of %s does not describe the evaluated grid %r"
+                                     % (node.args["co_resolution"], node.name, tuple(grid_shape)))
+                # "already signed" (C/modifications.py:236-237): the minimum over the whole grid = over every rank's
+                # planes (the halo planes are grid planes too, with their owners' values: the union is the grid)
+                own = row + 4 * (plane0 - e0) * plane
+                fmin = _engine._c.c_float(0.0)
+                if n > 0:
+                    _engine.check(lib.sdfk_field_min(vp(row), n, _engine.ctypes.byref(fmin), None), "sdfk_field_min")
+                gmin = comm.allreduce_min(float(fmin.value) if n > 0 else float("inf"))
+                if not gmin < 0.0:
+                    # grid spacings as the operator sees them: coordinate i of the neighbour along axis i minus that of point 0
+                    points4 = np.asarray([[ax[0][0], ax[0][1], ax[0][0], ax[0][0]], [ax[1][0], ax[1][0], ax[1][1], ax[1][0]],
+                                          [ax[2][0], ax[2][0], ax[2][0], ax[2][1]]], dtype=np.float64)
+                    seps = []
+                    for axis in range(3):
+                        vals = _eval_few(lib, lower(fields=known, stop_at=key, probe_axis=axis), points4, len(known))
+                        seps.append(abs(float(vals[1 + axis]) - float(vals[0])))
+                    sep = float(np.float32(min(seps)))
+                    d_mask = lib.sdfk_malloc(max(1, planes * plane))
+                    if not d_mask:
+                        raise _engine.SdfkError("staged slab evaluation: out of device memory")
+                    _engine.check(lib.sdfk_grid_boundary_mask(vp(own), planes * plane, sep, vp(d_mask), None), "sdfk_grid_boundary_mask")
+                    _engine.check(lib.sdfk_sync(None), "sdfk_sync")
+                    d_full = comm.allgather_bytes(d_mask, plane0 * plane, planes * plane, n0 * plane)
+                    _engine.check(lib.sdfk_grid_signed_slab(vp(row), e0, e1 - e0, vp(d_full), n0, n1, n2,
+                                                            0 if node.name == "signed_old" else 1, None, None),
+                                  "sdfk_grid_signed_slab")
+                    lib.sdfk_free(vp(d_mask))
+                    d_mask = None
+            else:
+                _apply_grid_op(lib, node, key, row, n, lower, known, None, d_tmp, shape=ext_shape)
             known[key] = k
         run_program(final, d_tmp, len(stages))
         # hipMemcpy device-to-device through the plumbing entry point (any direction works for device pointers)
@@ -502,3 +545,5 @@ def evaluate_slab_staged(lower, axes, plane0, planes, out_ptr):
     finally:
         lib.sdfk_free(vp(d_aux))
         lib.sdfk_free(vp(d_tmp))
+        if d_mask:
+            lib.sdfk_free(vp(d_mask))

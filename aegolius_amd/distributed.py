@@ -40,8 +40,13 @@ def gather_slabs(local, n_total, group=None, unit=1):
     if count != pad:
         send = torch.zeros(pad, dtype=local.dtype, device=local.device)
         send[:count] = local
-    full = torch.empty(world * pad, dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(full, send.contiguous(), group=group)
+    if local.is_cuda and dist.get_backend(group) == "gloo":          # gloo moves host tensors (several ranks on one GPU: the tests)
+        host = torch.empty(world * pad, dtype=local.dtype)
+        dist.all_gather_into_tensor(host, send.contiguous().cpu(), group=group)
+        full = host.to(local.device)
+    else:
+        full = torch.empty(world * pad, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(full, send.contiguous(), group=group)
     if pad * world == n_total:
         return full
     out = torch.empty(n_total, dtype=local.dtype, device=local.device)
@@ -182,7 +187,7 @@ def evaluate_grid_sharded(geometry, size, resolution, gather=True, group=None, e
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if evaluate_slab is None:
-        evaluate_slab = _GpuSlabEvaluator(geometry)
+        evaluate_slab = _GpuSlabEvaluator(geometry, group)
     # whole grid rows per slab (rows run along the last axis longer than one point); trees with grid-neighbourhood
     # operators are cut between planes of the first axis (their slabs carry a halo of planes)
     unit = int(axes64[2].size) if axes64[2].size > 1 else int(axes64[1].size)
@@ -195,30 +200,102 @@ def evaluate_grid_sharded(geometry, size, resolution, gather=True, group=None, e
     return local, res
 
 
+class _LocalComm:
+    """One slab = the whole grid: nothing to exchange."""
+
+    def allreduce_min(self, value):
+        return value
+
+    def allgather_bytes(self, ptr, start, count, total):
+        if start != 0 or count != total:
+            raise ValueError("a single slab must cover the whole grid")
+        return ptr
+
+
+class _TorchComm:
+    """What `signed` needs between the slabs of a sharded grid (aegolius_amd._eval.evaluate_slab_staged): the minimum
+    of the field over all ranks and an all-gather of ONE BYTE per point (field < grid spacing) — its scan lines cross
+    every slab, but that bit is all they read. RCCL moves device tensors directly; gloo (the tests: several ranks on
+    one GPU) goes through host copies."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.on_device = dist.get_backend(group) == "nccl"
+        self._keep = None                                     # the gathered mask: alive while the C side reads it
+
+    def allreduce_min(self, value):
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([value], dtype=torch.float64, device="cuda" if self.on_device else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return float(t[0])
+
+    def allgather_bytes(self, ptr, start, count, total):
+        import torch
+        import torch.distributed as dist
+        from . import _engine
+        dev = "cuda" if self.on_device else "cpu"
+        spans = torch.zeros((self.world, 2), dtype=torch.int64, device=dev)
+        mine = torch.tensor([start, count], dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(spans.view(-1), mine, group=self.group)
+        spans = spans.cpu().tolist()
+        pad = max(1, max(c for _s, c in spans))
+        send = torch.zeros(pad, dtype=torch.uint8, device="cuda")
+        if count:
+            _engine.check(_engine.lib().sdfk_memcpy_d2d(_engine._vp(send.data_ptr()), _engine._vp(ptr), count), "d2d")
+        if self.on_device:
+            parts = torch.empty(self.world * pad, dtype=torch.uint8, device="cuda")
+            dist.all_gather_into_tensor(parts, send, group=self.group)
+        else:
+            host = torch.empty(self.world * pad, dtype=torch.uint8)
+            dist.all_gather_into_tensor(host, send.cpu(), group=self.group)
+            parts = host.cuda()
+        full = torch.empty(total, dtype=torch.uint8, device="cuda")
+        for r, (s0, c) in enumerate(spans):
+            full[s0:s0 + c] = parts[r * pad:r * pad + c]
+        torch.cuda.synchronize()
+        self._keep = full
+        return full.data_ptr()
+
+
 class _GpuSlabEvaluator:
     """Evaluates a slab straight from the per-axis tables into a torch tensor on the current device."""
 
-    def __init__(self, geometry):
+    def __init__(self, geometry, group=None):
         from . import _engine
         from ._eval import program_for
         from ._lower import NeedsStage, lower_geometry
         self._engine = _engine
         self.staged = False
+        self.exchange = False                                 # the tree contains `signed`: every rank takes part, empty slab or not
+        self._group = group
         try:
             self._prog = program_for(lower_geometry(geometry))
         except NeedsStage:
-            # conv_averaging / conv_edge_detection: slabs of whole planes with a recomputed halo (_eval);
-            # signed / opaque user code need the whole field: refused here with the reason
+            # conv_averaging / conv_edge_detection: slabs of whole planes with a recomputed halo; signed: the slabs
+            # exchange one byte per point (_TorchComm); opaque user code needs the whole field: refused with the reason
             from ._eval import _halo_planes, _plan_stages
             self._lower = lambda **kw: lower_geometry(geometry, **kw)
             stages, _final, _ = _plan_stages(self._lower)
             for _low, node, _key, _params in stages:
-                if node.name not in ("conv_averaging", "conv_edge_detection"):
+                if node.name in ("signed", "signed_old"):
+                    self.exchange = True
+                elif node.name not in ("conv_averaging", "conv_edge_detection"):
                     raise NotImplementedError(
                         "the tree contains %r, which needs the whole field on one device: evaluate it with "
                         "geometry.create(co) on a single GPU" % (node.name,)) from None
             self._halo = _halo_planes
             self.staged = True
+
+    def _comm(self):
+        import torch.distributed as dist
+        if not self.exchange:
+            return None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self._group) > 1:
+            return _TorchComm(self._group)
+        return _LocalComm()
 
     def __call__(self, axes, start, count):
         import torch
@@ -230,8 +307,8 @@ class _GpuSlabEvaluator:
             if start % plane or count % plane:
                 raise ValueError("slabs of a tree with grid-neighbourhood operators must be whole planes of the first axis")
             torch.cuda.synchronize()
-            if count:
-                evaluate_slab_staged(self._lower, axes, start // plane, count // plane, out.data_ptr())
+            if count or self.exchange:
+                evaluate_slab_staged(self._lower, axes, start // plane, count // plane, out.data_ptr(), comm=self._comm())
             return out
         stream = torch.cuda.current_stream().cuda_stream
         self._prog.eval_grid(axes, start, count, out.data_ptr(), stream=stream)

@@ -181,6 +181,14 @@ int sdfk_grid_box_average(float* d_field, int64_t n0, int64_t n1, int64_t n2, in
 int sdfk_grid_edge_detect(float* d_field, int64_t n0, int64_t n1, int64_t n2, void* d_scratch, void* stream);
 int sdfk_grid_signed(float* d_field, int64_t n0, int64_t n1, int64_t n2, float sep_min, int crop, void* d_scratch,
                      void* stream);
+/* `signed` on ONE SLAB of a grid that is sharded over several GPUs: the scan lines cross every slab, but all they
+ * read is one bit per point (field < sep_min). sdfk_grid_boundary_mask writes that test for n points as bytes; the
+ * ranks exchange the bytes (aegolius_amd/distributed.py); sdfk_grid_signed_slab runs the scans on the WHOLE grid's
+ * mask (n0 * n1 * n2 bytes) and flips the sign of the planes [plane0, plane0 + planes) held in d_slab. The "already
+ * signed" test of the reference (modifications.py:236-237) is the caller's, as a minimum over all ranks. */
+int sdfk_grid_boundary_mask(const float* d_field, int64_t n, float sep_min, unsigned char* d_mask, void* stream);
+int sdfk_grid_signed_slab(float* d_slab, int64_t plane0, int64_t planes, const unsigned char* d_mask, int64_t n0, int64_t n1,
+                          int64_t n2, int crop, void* d_scratch, void* stream);
 
 /* ---- consumers of a resident field -------------------------------------------------------------
  * What the reference does with the (N,) field right after create(), on the device, synchronous:

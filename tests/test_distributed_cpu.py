@@ -100,17 +100,21 @@ def test_sharded_evaluation_equals_single_rank(world, resolution):
         np.testing.assert_array_equal(full, want)
 
 
-def test_sharded_evaluator_refuses_staged_trees():
-    """signed / conv_* / opaque callables need the whole field on one device: the slab evaluator says so instead of
-    leaking a lowering exception."""
+def test_sharded_evaluator_refuses_user_code_but_takes_signed():
+    """Opaque callables need the whole field on one device: the slab evaluator says so instead of leaking a lowering
+    exception. `signed` shards (the slabs exchange one byte per point), conv_* shard with a recomputed halo."""
     sys.path.insert(0, ROOT)
     import aegolius_amd.cores as ns
     from aegolius_amd.distributed import _GpuSlabEvaluator
     s = ns.Sphere(0.5)
     s.boundary()
     s.signed((8, 8, 8))
+    ev = _GpuSlabEvaluator(s)
+    assert ev.staged and ev.exchange
+    t = ns.Sphere(0.5)
+    t.custom_post_process(lambda u, a: a * u, (2.0,))
     with pytest.raises(NotImplementedError, match="single GPU"):
-        _GpuSlabEvaluator(s)
+        _GpuSlabEvaluator(t)
 
 
 # ---- consumers of the field, sharded (DESIGN.md §4.7) ---------------------------------------------------------------
