@@ -124,6 +124,15 @@ def main(which="reference", first=0, count=400):
         except Exception as exc:  # noqa: BLE001
             ok, bad, worst = False, -1, float("nan")
             print("seed %d (%s) raised %r" % (seed, kind, exc))
+            if which != "reference":
+                # an input the reference refuses (e.g. a (3, 2) point array, which its constructor transposes): the
+                # product has to refuse it with the same exception type
+                try:
+                    build(ns, seed)[0].create(co.copy())
+                except type(exc):
+                    ok, bad, kind = True, 0, kind + " (refused by both with %s)" % type(exc).__name__
+                except Exception:  # noqa: BLE001
+                    pass
         failures += not ok
         print("seed %d %s: %d off, worst %.2e %s" % (seed, kind, bad, worst, "" if ok else " <-- FAIL"), flush=True)
     print("%s: %d cases, %d failures" % (which, int(count), failures))
