@@ -71,8 +71,8 @@ __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_interp_kernel(const uint2* __
                                                                 const float* __restrict__ tab, SRC src, long long off,
                                                                 long long n, float* __restrict__ out, int result_reg,
                                                                 const float* __restrict__ aux, long long aux_stride) {
-    const long long block_base = (long long)blockIdx.x * (SDFK_BLOCK * VEC);
-    const unsigned lane_off = threadIdx.x * VEC;
+    const long long block_base = (long long)sdfk_bx() * (SDFK_BLOCK * VEC);
+    const unsigned lane_off = sdfk_tx() * VEC;
     if (block_base + lane_off >= n) return;
     V3 C[SDFK_NC][VEC];
     float V[SDFK_NV][VEC];
@@ -110,8 +110,8 @@ __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_interp_kernel(const uint2* __
 
 // (3,n) -> (n) streaming probe with the evaluation kernels' access pattern
 __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_probe_kernel(SrcArray src, long long n, float* __restrict__ out) {
-    const long long block_base = (long long)blockIdx.x * (SDFK_BLOCK * 4);
-    const unsigned lane_off = threadIdx.x * 4;
+    const long long block_base = (long long)sdfk_bx() * (SDFK_BLOCK * 4);
+    const unsigned lane_off = sdfk_tx() * 4;
     if (block_base + lane_off >= n) return;
     V3 p[4];
     sdfk_load<4>(src, block_base, lane_off, p);
@@ -122,8 +122,8 @@ __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_probe_kernel(SrcArray src, lo
 
 __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_gridfill_kernel(SrcGrid src, long long n, float* __restrict__ co,
                                                                   long long stride) {
-    const long long block_base = (long long)blockIdx.x * (SDFK_BLOCK * 4);
-    const unsigned lane_off = threadIdx.x * 4;
+    const long long block_base = (long long)sdfk_bx() * (SDFK_BLOCK * 4);
+    const unsigned lane_off = sdfk_tx() * 4;
     const long long i = block_base + lane_off;
     if (i >= n) return;
     V3 p[4];

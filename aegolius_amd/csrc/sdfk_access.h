@@ -34,7 +34,7 @@ static __device__ __forceinline__ void sdfk_stream_store4(float* p, float a, flo
     __builtin_nontemporal_store(v, reinterpret_cast<sdfk_f4*>(p));
 }
 
-// block_base : index of the workgroup's first point (wave-uniform), lane_off : threadIdx.x * VEC
+// block_base : index of the workgroup's first point (wave-uniform), lane_off : sdfk_tx() * VEC
 template <int VEC>
 static __device__ __forceinline__ void sdfk_load(const SrcArray& s, long long block_base, unsigned lane_off,
                                                  V3 (&p)[VEC]) {

@@ -17,8 +17,8 @@ static __device__ __forceinline__ void sdfk_body(const float* __restrict__ PRM, 
                                                  const SRC& src, long long off, long long n,
                                                  float* __restrict__ out, const float* __restrict__ aux,
                                                  long long aux_stride) {
-    const long long block_base = (long long)blockIdx.x * (SDFK_BLOCK * VEC);
-    const unsigned lane_off = threadIdx.x * VEC;
+    const long long block_base = (long long)sdfk_bx() * (SDFK_BLOCK * VEC);
+    const unsigned lane_off = sdfk_tx() * VEC;
     if (block_base + lane_off >= n) return;
     V3 p[VEC];
     sdfk_load<VEC>(src, off + block_base, lane_off, p);
@@ -308,12 +308,12 @@ static __device__ __forceinline__ void sdfk_tile_evaluate(const float* __restric
 template <typename SRC>
 static __device__ __forceinline__ void sdfk_tile_prepare(const float* __restrict__ PRM, const float* __restrict__ TAB,
                                                          const SRC& src, long long n, sdfk_tilemeta* meta) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = sdfk_tx() & 63, wave = sdfk_tx() >> 6;
     sdfk_tileregs r;
-    sdfk_tile_load(src, n, (long long)blockIdx.x * SDFK_TILE, lane, wave, r);
+    sdfk_tile_load(src, n, (long long)sdfk_bx() * SDFK_TILE, lane, wave, r);
     sdfk_tile_bounds(r, meta, lane, wave);
     __syncthreads();
-    sdfk_tile_probe(PRM, TAB, meta, threadIdx.x);
+    sdfk_tile_probe(PRM, TAB, meta, sdfk_tx());
     __syncthreads();
 }
 // One tile per workgroup; many short-lived workgroups per CU sit in different phases at any time, which is
@@ -325,8 +325,8 @@ static __device__ __forceinline__ void sdfk_tile_kernel(const float* __restrict_
                                                         const SRC& src, long long n, float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) sdfk_tilemeta meta;
     sdfk_tile_prepare(PRM, TAB, src, n, &meta);
-    sdfk_tile_evaluate(PRM, TAB, src, n, (long long)blockIdx.x * SDFK_TILE, &meta, out, threadIdx.x & 63,
-                       threadIdx.x >> 6);
+    sdfk_tile_evaluate(PRM, TAB, src, n, (long long)sdfk_bx() * SDFK_TILE, &meta, out, sdfk_tx() & 63,
+                       sdfk_tx() >> 6);
 }
 )SDFKT";
 static const char kTileArray[] = R"SDFKT(
@@ -353,8 +353,8 @@ extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_tmask(
     __shared__ __attribute__((aligned(16))) sdfk_tilemeta meta;
     const SrcArray s = {co, stride};
     sdfk_tile_prepare(PRM, TAB, s, n, &meta);
-    for (int b = threadIdx.x; b < SDFK_NBRICK; b += SDFK_TTHREADS)
-        masks[(long long)blockIdx.x * SDFK_NBRICK + b] = sdfk_brick_mask(&meta, b);
+    for (int b = sdfk_tx(); b < SDFK_NBRICK; b += SDFK_TTHREADS)
+        masks[(long long)sdfk_bx() * SDFK_NBRICK + b] = sdfk_brick_mask(&meta, b);
 }
 )SDFKT";
 
@@ -549,7 +549,7 @@ template <typename SRC>
 static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict__ PRM, const float* __restrict__ TAB,
                                                          const SRC& s, const sdfk_rowgeom& g, sdfk_rowmeta* meta,
                                                          unsigned tile, unsigned& rb0, unsigned& c0) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = sdfk_tx() & 63, wave = __builtin_amdgcn_readfirstlane(sdfk_tx() >> 6);
     const unsigned q0 = tile * SDFK_RNBRICK + wave * SDFK_RWBRICKS;            // first brick of this wave
     rb0 = __builtin_amdgcn_readfirstlane(q0 / g.nchunk);        // (the division runs on the vector unit: back to an SGPR,
     c0 = q0 - rb0 * g.nchunk;                                    //  so that what is derived from it stays scalar)
@@ -582,15 +582,15 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
     }
 #endif
     __syncthreads();
-    if (threadIdx.x < SDFK_RNBRICK && tile * SDFK_RNBRICK + threadIdx.x < g.nbricks) {
-        const float4 bb = meta->bound[threadIdx.x];
+    if (sdfk_tx() < SDFK_RNBRICK && tile * SDFK_RNBRICK + sdfk_tx() < g.nbricks) {
+        const float4 bb = meta->bound[sdfk_tx()];
         V3T<float> ctr = {bb.x, bb.y, bb.z};
         unsigned long long m0 = 0ull, m1 = 0ull;
 #ifndef SDFK_ABLATE_PROBE
         sdfk_probe_r(ctr, bb.w, PRM, TAB, m0, m1);
 #endif
-        meta->mask0[threadIdx.x] = m0;
-        meta->mask1[threadIdx.x] = m1;
+        meta->mask0[sdfk_tx()] = m0;
+        meta->mask1[sdfk_tx()] = m1;
     }
     __syncthreads();
 }
@@ -600,9 +600,9 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
                                                         const SRC& s, const sdfk_rowgeom& g, float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) sdfk_rowmeta meta;
 #ifdef SDFK_LDSPAD
-    if (g.L == 0xffffffffu) meta.pad[threadIdx.x] = 1.0f;
+    if (g.L == 0xffffffffu) meta.pad[sdfk_tx()] = 1.0f;
 #endif
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = sdfk_tx() & 63, wave = __builtin_amdgcn_readfirstlane(sdfk_tx() >> 6);
     const int lr = lane / SDFK_RLPR;
     const int zq = (lane % SDFK_RLPR) * (2 * SDFK_NP);
 #ifndef SDFK_RTILES
@@ -610,7 +610,7 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
 #endif
 #pragma unroll 1
   for (unsigned tt = 0; tt < SDFK_RTILES; ++tt) {
-    const unsigned tile = blockIdx.x * SDFK_RTILES + tt;
+    const unsigned tile = sdfk_bx() * SDFK_RTILES + tt;
     if (tile * SDFK_RNBRICK >= g.nbricks) break;
     if (tt) __syncthreads();
     unsigned rb, c;
@@ -727,12 +727,12 @@ extern "C" __global__ __launch_bounds__(64 * SDFK_RWAVES) void sdfk_spec_rmask(
     __shared__ __attribute__((aligned(16))) sdfk_rowmeta meta;
     const SrcArray s = {co, stride};
     unsigned rb, c;
-    sdfk_rows_prepare(PRM, TAB, s, g, &meta, blockIdx.x, rb, c);
-    const unsigned q = blockIdx.x * SDFK_RNBRICK + threadIdx.x;
-    if (threadIdx.x < SDFK_RNBRICK && q < g.nbricks) {
-        masks[3ull * q] = meta.mask0[threadIdx.x];
-        masks[3ull * q + 1] = meta.mask1[threadIdx.x];
-        masks[3ull * q + 2] = meta.uniform[threadIdx.x];
+    sdfk_rows_prepare(PRM, TAB, s, g, &meta, sdfk_bx(), rb, c);
+    const unsigned q = sdfk_bx() * SDFK_RNBRICK + sdfk_tx();
+    if (sdfk_tx() < SDFK_RNBRICK && q < g.nbricks) {
+        masks[3ull * q] = meta.mask0[sdfk_tx()];
+        masks[3ull * q + 1] = meta.mask1[sdfk_tx()];
+        masks[3ull * q + 2] = meta.uniform[sdfk_tx()];
     }
 }
 )SDFKR";

@@ -24,6 +24,17 @@
 
 #define SDFK_DEV static __device__ __forceinline__
 
+// Launch indices straight from the hardware registers. The HIP spellings (blockIdx.x, threadIdx.x ...) go through
+// device-library functions (__ockl_get_group_id ...) that are NOT inlined into kernels built with -mno-amdgpu-ieee
+// (the attribute differs from the library's, so the inliner refuses): they stay real calls whose result comes back in
+// a VGPR, and everything derived from the workgroup index then counts as divergent — vector address arithmetic and
+// vector loads where scalar ones would do. The builtins below are SGPR reads.
+SDFK_DEV unsigned sdfk_bx() { return __builtin_amdgcn_workgroup_id_x(); }
+SDFK_DEV unsigned sdfk_by() { return __builtin_amdgcn_workgroup_id_y(); }
+SDFK_DEV unsigned sdfk_bz() { return __builtin_amdgcn_workgroup_id_z(); }
+SDFK_DEV unsigned sdfk_tx() { return __builtin_amdgcn_workitem_id_x(); }
+SDFK_DEV unsigned sdfk_gx() { return __builtin_amdgcn_grid_size_x() / __builtin_amdgcn_workgroup_size_x(); }   // gridDim.x
+
 // Lane value types. `float` = one point per lane; `f2` = TWO points per lane, which lets the
 // compiler use the packed-fp32 VALU forms (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): measured on
 // MI355X a packed instruction costs ~1.2x a plain one and does 2x the work (tools/valu_peak.hip),

@@ -776,11 +776,17 @@ def test_sharded_evaluation_of_trees_with_conv_operators(engine):
             parts = [ev(axes, *slab_bounds(whole.size, world, r, plane)) for r in range(world)]
             torch.cuda.synchronize()
             np.testing.assert_array_equal(torch.cat(parts).cpu().numpy(), whole)
+    # `signed` crosses every slab: a single rank (no process group) holds the whole grid and must reproduce the plain
+    # evaluation; the exchange between ranks is covered by test_gpu_consumers.test_signed_shards_across_ranks
     s = ns.Sphere(0.5)
     s.boundary()
     s.signed((8, 8, 8))
-    with pytest.raises(NotImplementedError, match="single GPU"):
-        _GpuSlabEvaluator(s)
+    co, _ = ns.generate_grid((2, 2, 2), (8, 8, 8))
+    whole = np.asarray(s.create(co)).ravel()
+    axes = [a.astype(np.float32) for a in grid_axes((2, 2, 2), (8, 8, 8))[0]]
+    ev = _GpuSlabEvaluator(s)
+    assert ev.staged
+    np.testing.assert_array_equal(ev(axes, 0, whole.size).cpu().numpy(), whole)
 
 
 def test_library_and_torch_share_one_hip_runtime(engine):
