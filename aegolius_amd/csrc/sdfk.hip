@@ -657,8 +657,11 @@ extern "C" void sdfk_debug_set_rtc_defs(const char* defs) {
 static std::vector<std::string> rtc_options(int geo) {
     const int rwb = geo & 15, rwaves = (geo >> 4) ? (geo >> 4) : 2;
     std::vector<std::string> o = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17",
-                                  // -fno-honor-nans -mno-amdgpu-ieee: v_min/v_max without the canonicalising pre-op (same
+                                  // -fno-honor-nans: v_min/v_max without the canonicalising pre-op. -mno-amdgpu-ieee (same
                                   // flags as the hipcc build of the interpreter kernel: both flavours stay bit-identical)
+                                  // keeps the device library's sincos / atan2 / pow out of line — the inliner refuses
+                                  // across the attribute — which is what a 50-primitive 2-D tree wants: 296 KB of code
+                                  // instead of 490 KB, 10 s of compile instead of 15 s, 1.19 vs 1.22 ms at 16385^2
                                   "-fno-honor-nans", "-mno-amdgpu-ieee",
                                   "-DSDFK_TWAVES=" + std::to_string(tile_waves()), "-DSDFK_WBRICKS=" + std::to_string(tile_wbricks()),
                                   "-DSDFK_RWBRICKS=" + std::to_string(rwb), "-DSDFK_RWAVES=" + std::to_string(rwaves)};
