@@ -506,6 +506,45 @@ def test_culling_far_from_the_origin_is_bit_exact(name, shift, engine):
     assert np.all(err <= 1e-6 * np.maximum(1.0, np.abs(ref)) + 8.0 * moved + 8.0 * np.spacing(np.float32(shift))), float(err.max())
 
 
+def _ill_conditioned(ns):
+    """scenes whose float64 reference itself moves by more than 1e-6 under a one-ulp change of its fp32 inputs"""
+    out = {}
+    out["neucircle_order_0.3_moved"] = ns.NEUCircle(0.5, 0.3)    # |x|^p + |y|^p with p < 1: unbounded slope at the axes
+    out["neucircle_order_0.3_moved"].move((0.2, -0.1, 0.0))
+    s = ns.Sphere(0.6)
+    s.capped_exponential(1.5, 0.004)                              # value map of width 4e-3: slope 1 / 4e-3
+    out["capped_exponential_narrow"] = s
+    g = ns.Sphere(0.6)
+    g.gaussian_boundary(2.0, 0.03)
+    out["gaussian_boundary_narrow"] = g
+    t = ns.Torus(0.6, 0.2)
+    t.sigmoid_falloff(1.0, 0.003)
+    out["sigmoid_falloff_narrow"] = t
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(_ill_conditioned(ns)))
+def test_ill_conditioned_scenes_stay_within_the_references_own_sensitivity(name, engine):
+    """Fractional super-ellipse orders and narrow value maps amplify the fp32 rounding of the INPUT beyond 1e-6: there
+    the bar is the movement of the float64 reference under a one-ulp change of its inputs (x8), and the plain 1e-6
+    everywhere else. Bounded both ways: no point outside the combined bar, and the scene really is of that class
+    (some point does need the sensitivity term — otherwise it belongs with the ordinary scenes)."""
+    geo = _ill_conditioned(ns)[name]
+    co = scenes.input_points()
+    with np.errstate(all="ignore"):
+        ref = np.asarray(sdf_oracle.evaluate(geo, co.copy()), dtype=np.float64)
+        sens = scenes.input_sensitivity(lambda c: sdf_oracle.evaluate(_ill_conditioned(ns)[name], c), co)
+    for mode in (engine.MODE_SPECIALIZED, engine.MODE_INTERPRET):
+        prog = engine.Program.from_lowered(lower_geometry(geo))
+        got = prog.eval_host(np.ascontiguousarray(co, dtype=np.float32), mode=mode).astype(np.float64)
+        err = np.abs(got - ref)
+        err[np.isnan(got) & np.isnan(ref)] = 0.0
+        plain_bar = 1e-6 * np.maximum(1.0, np.abs(ref))
+        assert np.all(err <= plain_bar + 8.0 * sens), (name, float(np.nanmax(err - plain_bar - 8.0 * sens)))
+        assert np.mean(err > plain_bar) <= 0.10, (name, float(np.mean(err > plain_bar)))
+    assert np.any(sens > 1e-6 * np.maximum(1.0, np.abs(ref))), name
+
+
 @pytest.mark.parametrize("name", CULL_SCENES)
 def test_brick_culling_is_bit_exact(name, engine):
     """The culling tile kernel (skips operand subtrees per 128-point brick) returns exactly what the
