@@ -1,5 +1,5 @@
-"""Developer tool (GPU): the gradient kernels against each other on a few shapes — flat (SDFK_GRADIENT_FLAT=1), register
-carry (default) and LDS marching (SDFK_GRADIENT_MARCH=1): first mismatches, raw and normalised."""
+"""Developer tool (GPU): the gradient kernels against each other on a few shapes — flat (SDFK_GRADIENT_FLAT=1) and register
+carry (default): first mismatches, raw and normalised."""
 import os, sys, subprocess
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,15 +17,12 @@ if len(sys.argv) > 1:
     np.savez(sys.argv[1], **out)
 else:
     env = dict(os.environ)
-    env.pop("SDFK_GRADIENT_MARCH", None)
     env["SDFK_GRADIENT_FLAT"] = "1"
     subprocess.check_call([sys.executable, __file__, "/tmp/g_flat.npz"], env=env)
     env.pop("SDFK_GRADIENT_FLAT")
     subprocess.check_call([sys.executable, __file__, "/tmp/g_carry.npz"], env=env)
-    env["SDFK_GRADIENT_MARCH"] = "1"
-    subprocess.check_call([sys.executable, __file__, "/tmp/g_march.npz"], env=env)
     b = np.load("/tmp/g_flat.npz")
-    for tag in ("carry", "march"):
+    for tag in ("carry",):
         a = np.load("/tmp/g_%s.npz" % tag)
         for k in a.files:
             x, y = a[k], b[k]
