@@ -506,6 +506,56 @@ def test_culling_far_from_the_origin_is_bit_exact(name, shift, engine):
     assert np.all(err <= 1e-6 * np.maximum(1.0, np.abs(ref)) + 8.0 * moved + 8.0 * np.spacing(np.float32(shift))), float(err.max())
 
 
+def _signed_numpy(s, sep, crop):
+    """`signed` / `signed_old` on a 3-D array, restated from the oracle (oracle/sdf_oracle._signed; C/modifications.py:163-275)"""
+    boundary = s < sep
+    interior = None
+    for axis in (0, 1):
+        b = np.moveaxis(boundary, axis, 0)
+        chu, chuu = np.zeros(b.shape), np.zeros(b.shape)
+        chu[1:] = b[1:] * ~b[:-1]
+        chuu[:-1] = b[:-1] * ~b[1:]
+        mark = np.cumsum(chu, axis=0)
+        fmark = np.flip(np.cumsum(chuu, axis=0), axis=0) if crop else np.flip(np.cumsum(np.flip(chuu, axis=0), axis=0), axis=0)
+        part = np.moveaxis(np.clip(mark % 2 + fmark % 2, 0, 1), 0, axis)
+        interior = part if interior is None else interior * part
+    interior = sdf_oracle._conv_averaging(interior, (2, 2, 1), 1)
+    if crop:
+        interior = np.pad(interior[1:-1, 1:-1, 1:-1], pad_width=1, mode="edge")
+    return s * (1 - 2 * (interior > 0.5))
+
+
+@pytest.mark.parametrize("shape", [(3, 3, 3), (5, 4, 33), (9, 7, 65), (4, 6, 64), (7, 5, 32), (6, 6, 97), (12, 9, 129),
+                                   (3, 40, 10), (40, 3, 5), (2, 2, 2), (17, 33, 31), (8, 8, 257)])
+@pytest.mark.parametrize("crop", [1, 0])
+def test_signed_bit_planes_on_awkward_shapes(shape, crop, engine):
+    """sdfk_grid_signed packs the boundary test 32 points to a word along the last axis: word edges (32, 33, 64, 65
+    points), a last point alone in its word (33, 65, 97, 129, 257), rows shorter than a word, the crop's clamps on all
+    three axes and grids too thin for the caller's scratch — on noise, where every scan line changes parity many times.
+    Bit-exact against the restated reference arithmetic."""
+    if crop and min(shape) < 3:
+        pytest.skip("the reference's crop needs three points per axis")
+    rng = np.random.default_rng(sum(shape) + crop)
+    lib = engine.lib()
+    for density in (0.5, 0.15, 0.9):
+        s = rng.uniform(0.0, 1.0, shape)
+        # blobs as well as noise: runs of boundary points along both scan axes
+        s[rng.uniform(size=shape) < 0.3] = 0.0
+        sep = density
+        host = np.ascontiguousarray(s, dtype=np.float32).ravel()
+        want = _signed_numpy(host.astype(np.float64).reshape(shape), np.float64(np.float32(sep)), bool(crop)).astype(np.float32).ravel()
+        d = lib.sdfk_malloc(host.nbytes + 64)
+        try:
+            engine.check(lib.sdfk_memcpy_h2d(ctypes.c_void_p(d), host.ctypes.data_as(ctypes.c_void_p), host.nbytes), "h2d")
+            engine.check(lib.sdfk_grid_signed(ctypes.c_void_p(d), shape[0], shape[1], shape[2], float(np.float32(sep)), crop, None, None), "signed")
+            got = np.empty_like(host)
+            engine.check(lib.sdfk_memcpy_d2h(got.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d), host.nbytes), "d2h")
+        finally:
+            lib.sdfk_free(ctypes.c_void_p(d))
+        np.testing.assert_array_equal(got, want)
+        assert (want < 0).any() or density < 0.2 or min(shape) < 4
+
+
 def _ill_conditioned(ns):
     """scenes whose float64 reference itself moves by more than 1e-6 under a one-ulp change of its fp32 inputs"""
     out = {}

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main(res=1024, rounds=2):
+def main(res=1024, rounds=2, ballast_gb=0):
     import aegolius_amd.cores as ns
     from aegolius_amd import _engine
     from aegolius_amd._lower import lower_geometry
@@ -22,12 +22,13 @@ def main(res=1024, rounds=2):
     n = n0 * n1 * n2
     vp = ctypes.c_void_p
     stride = (n + 63) // 64 * 64
+    ballast = [lib.sdfk_malloc(1 << 30) for _ in range(int(ballast_gb))]   # other allocations of the process, made first
     d_f = lib.sdfk_malloc(n * 4)
     d_v = lib.sdfk_malloc(3 * stride * 4)
     prog.eval_grid(axes, 0, n, d_f)
     line = []
     for r in range(rounds):
-        for tag in ("flat", "carry16", "carry32", "carry64", "carry128"):
+        for tag in ("flat", "carry32"):
             if tag == "flat":
                 os.environ["SDFK_GRADIENT_FLAT"] = "1"
             else:
