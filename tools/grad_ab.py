@@ -1,4 +1,6 @@
-"""Developer tool (GPU): flat and register-carry gradient kernels alternating inside one process (1025^3, raw gradient)."""
+"""Developer tool (GPU): flat and register-carry gradient kernels alternating inside one process (1025^3, raw gradient);
+carryG = runs of G consecutive chunks per XCD (0: one contiguous eighth of the work per XCD). Times are constant inside a
+process and differ between processes and boxes: run it several times."""
 import ctypes
 import os
 import sys
@@ -9,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main(res=1024, rounds=2, ballast_gb=0):
+def main(res=1024, rounds=1, ballast_gb=0):
     import aegolius_amd.cores as ns
     from aegolius_amd import _engine
     from aegolius_amd._lower import lower_geometry
@@ -28,12 +30,12 @@ def main(res=1024, rounds=2, ballast_gb=0):
     prog.eval_grid(axes, 0, n, d_f)
     line = []
     for r in range(rounds):
-        for tag in ("flat", "carry32"):
+        for tag in ("flat", "carry0", "carry8", "carry32"):
             if tag == "flat":
                 os.environ["SDFK_GRADIENT_FLAT"] = "1"
             else:
                 os.environ.pop("SDFK_GRADIENT_FLAT", None)
-                os.environ["SDFK_GC_SEG"] = tag[5:]
+                os.environ["SDFK_GC_GROUP"] = tag[5:]
             ts = []
             for _ in range(3):
                 e0, e1 = _engine.Event(), _engine.Event()
