@@ -1027,7 +1027,7 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
         if (flavour == SDFK_FL_ROWS_ARRAY || flavour == SDFK_FL_ROWS_GRID || flavour == SDFK_FL_ROWS2D_ARRAY ||
             flavour == SDFK_FL_ROWS2D_GRID) {
             const unsigned per_tile = (unsigned)(rows_waves(p) * rows_wbricks(p));
-            const unsigned tiles = ((rg.nbricks + per_tile - 1) / per_tile + 7u) & ~7u;   // whole rounds over the 8 XCDs
+            const unsigned tiles = ((rg.nbricks + per_tile - 1) / per_tile + 127u) & ~127u;   // whole rounds of 8 XCDs x SDFK_XGROUP = 16 tiles (sdfk_codegen.cpp)
             const unsigned rthreads = 64u * (unsigned)rows_waves(p);
             if (arr) {
                 const float* co = arr->co;

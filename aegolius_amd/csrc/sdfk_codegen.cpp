@@ -608,9 +608,18 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
 #ifndef SDFK_RTILES
 #define SDFK_RTILES 1
 #endif
+#ifndef SDFK_XGROUP
+#define SDFK_XGROUP (SDFK_RNBRICK <= 4 ? 16 : (SDFK_RNBRICK <= 8 ? 8 : 4))    // runs of about 64 bricks: two row blocks at 1025
+#endif
 #pragma unroll 1
   for (unsigned tt = 0; tt < SDFK_RTILES; ++tt) {
-    const unsigned tile = sdfk_bx() * SDFK_RTILES + tt;
+    // Workgroups go round-robin to the 8 XCDs: an XCD takes runs of SDFK_XGROUP consecutive tiles (the grid is a
+    // multiple of 8 * SDFK_XGROUP), i.e. a few whole row blocks at a time, so the window a row shares with the next
+    // one is fetched from HBM once and found in that XCD's L2 the second time, while all XCDs stay in the same
+    // neighbourhood of the arrays. Runs of 1 (plain round-robin): +0.7 to +3 % on the north-star grid depending on the
+    // box, +18 % on the MEDIAN at 513^3; one contiguous eighth of the grid per XCD: +7 % (eight far-apart streams).
+    const unsigned xg_t = sdfk_bx() / 8;
+    const unsigned tile = (((xg_t / SDFK_XGROUP) * 8 + sdfk_bx() % 8) * SDFK_XGROUP + xg_t % SDFK_XGROUP) * SDFK_RTILES + tt;
     if (tile * SDFK_RNBRICK >= g.nbricks) break;
     if (tt) __syncthreads();
     unsigned rb, c;
