@@ -61,11 +61,15 @@ extern "C" const sdfk_opinfo* sdfk_op_table(int* count) {
 // interpreter register-file limits (the specialised path has none beyond the 8-bit operand fields)
 #define SDFK_NC 8
 #define SDFK_NV 8
+// six programs in seven need at most 2 coordinate and 3 value registers (every BASELINE config does): that register
+// file fits the VGPRs, the full one lives in scratch
+#define SDFK_NC_SMALL 2
+#define SDFK_NV_SMALL 3
 
 // ------------------------------------------------------------------------------------------------
 // interpreter kernel
 // ------------------------------------------------------------------------------------------------
-template <int VEC, typename SRC>
+template <int VEC, int NC, int NV, typename SRC>
 __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_interp_kernel(const uint2* __restrict__ code, int n_instr,
                                                                 const float* __restrict__ prm,
                                                                 const float* __restrict__ tab, SRC src, long long off,
@@ -74,11 +78,30 @@ __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_interp_kernel(const uint2* __
     const long long block_base = (long long)sdfk_bx() * (SDFK_BLOCK * VEC);
     const unsigned lane_off = sdfk_tx() * VEC;
     if (block_base + lane_off >= n) return;
-    V3 C[SDFK_NC][VEC];
-    float V[SDFK_NV][VEC];
-    sdfk_load<VEC>(src, off + block_base, lane_off, C[0]);
+    // Register files indexed by the (wave-uniform) register number. The small coordinate file is three plain float
+    // arrays, which the compiler keeps in VGPRs next to V; the full-size one is an array of structs and lives in
+    // scratch — as plain arrays it takes 173 VGPRs, two waves per SIMD, and is slower (52.7 against 44.7 ms on the
+    // north-star tree). (Wrapping either in a struct sends V to scratch as well: 62 ms.)
+    constexpr bool SPLIT = NC <= SDFK_NC_SMALL;
+    float CX[SPLIT ? NC : 1][VEC], CY[SPLIT ? NC : 1][VEC], CZ[SPLIT ? NC : 1][VEC];
+    V3 CS[SPLIT ? 1 : NC][VEC];
+    float V[NV][VEC];
+#define SDFK_CGET(r, v) (SPLIT ? V3{CX[SPLIT ? (r) : 0][v], CY[SPLIT ? (r) : 0][v], CZ[SPLIT ? (r) : 0][v]} : CS[SPLIT ? 0 : (r)][v])
+#define SDFK_CSET(r, v, q)                                                                      \
+    do {                                                                                        \
+        const V3 q_ = (q);                                                                      \
+        if constexpr (SPLIT) { CX[SPLIT ? (r) : 0][v] = q_.x; CY[SPLIT ? (r) : 0][v] = q_.y; CZ[SPLIT ? (r) : 0][v] = q_.z; } \
+        else CS[SPLIT ? 0 : (r)][v] = q_;                                                       \
+    } while (0)
+    {
+        V3 p0[VEC];
+        sdfk_load<VEC>(src, off + block_base, lane_off, p0);
+        _Pragma("unroll") for (int v = 0; v < VEC; ++v) SDFK_CSET(0, v, p0[v]);
+    }
+    uint2 fetched = code[0];         // wave-uniform -> scalar load; the next word is requested before this one executes
     for (int pc = 0; pc < n_instr; ++pc) {
-        const uint2 ins = code[pc];  // wave-uniform -> scalar load
+        const uint2 ins = fetched;
+        fetched = code[min(pc + 1, n_instr - 1)];
         const unsigned op = ins.x & 255u, a = (ins.x >> 8) & 255u, b = (ins.x >> 16) & 255u, c = ins.x >> 24;
         const float* __restrict__ P = prm + ins.y;
         if (op == SDFK_OP_V_FIELD) {   // auxiliary field c at this lane's points (validated: aux != nullptr)
@@ -88,9 +111,9 @@ __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_interp_kernel(const uint2* __
         }
         switch (op) {
 #define SDFK_EXEC_C_C(F) \
-    _Pragma("unroll") for (int v = 0; v < VEC; ++v) C[a][v] = F(C[b][v], P, tab, (int)c)
+    _Pragma("unroll") for (int v = 0; v < VEC; ++v) SDFK_CSET(a, v, F(SDFK_CGET(b, v), P, tab, (int)c))
 #define SDFK_EXEC_V_C(F) \
-    _Pragma("unroll") for (int v = 0; v < VEC; ++v) V[a][v] = F(C[b][v], P, tab)
+    _Pragma("unroll") for (int v = 0; v < VEC; ++v) V[a][v] = F(SDFK_CGET(b, v), P, tab)
 #define SDFK_EXEC_V_V(F) \
     _Pragma("unroll") for (int v = 0; v < VEC; ++v) V[a][v] = F(V[b][v], P)
 #define SDFK_EXEC_V_VV(F) \
@@ -187,6 +210,7 @@ struct sdfk_program {
     std::vector<float> params, tables;
     int result_reg = 0;
     bool interp_ok = true;  // fits the interpreter's register file
+    bool interp_small = false;  // ... and its small instantiation (SDFK_NC_SMALL coordinate / SDFK_NV_SMALL value registers)
     int n_aux = 0;          // auxiliary per-point fields read by V_FIELD instructions
     unsigned long long params_version = 1;
     std::string key;
@@ -359,6 +383,7 @@ static int validate(sdfk_program* p, std::string* why) {
         return 0;
     }
     p->interp_ok = (max_c < SDFK_NC) && (max_v < SDFK_NV) && (p->result_reg < SDFK_NV);
+    p->interp_small = (max_c < SDFK_NC_SMALL) && (max_v < SDFK_NV_SMALL) && (p->result_reg < SDFK_NV_SMALL);
     return 1;
 }
 
@@ -1095,20 +1120,26 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
     // interpreter
     const int n_instr = (int)(p->code.size() / 2);
     const long long zero = 0;
+    auto launch = [&](auto src, int vec, long long off, long long cnt) {
+        using SRC = decltype(src);
+        const dim3 grid(blocks_for(cnt, vec)), block(SDFK_BLOCK);
+#define SDFK_INTERP_GO(VEC, NC, NV) hipLaunchKernelGGL((sdfk_interp_kernel<VEC, NC, NV, SRC>), grid, block, 0, stream, d->d_code, \
+                                                        n_instr, prm, tab, src, off, cnt, d_out, p->result_reg, aux, aux_stride)
+        if (vec == 4) {
+            if (p->interp_small) SDFK_INTERP_GO(4, SDFK_NC_SMALL, SDFK_NV_SMALL);
+            else SDFK_INTERP_GO(4, SDFK_NC, SDFK_NV);
+        } else {
+            if (p->interp_small) SDFK_INTERP_GO(1, SDFK_NC_SMALL, SDFK_NV_SMALL);
+            else SDFK_INTERP_GO(1, SDFK_NC, SDFK_NV);
+        }
+#undef SDFK_INTERP_GO
+    };
     if (arr) {
-        if (n4)
-            hipLaunchKernelGGL((sdfk_interp_kernel<4, SrcArray>), dim3(blocks_for(n4, 4)), dim3(SDFK_BLOCK), 0, stream,
-                               d->d_code, n_instr, prm, tab, *arr, zero, n4, d_out, p->result_reg, aux, aux_stride);
-        if (tail)
-            hipLaunchKernelGGL((sdfk_interp_kernel<1, SrcArray>), dim3(blocks_for(tail, 1)), dim3(SDFK_BLOCK), 0,
-                               stream, d->d_code, n_instr, prm, tab, *arr, n4, tail, d_out, p->result_reg, aux, aux_stride);
+        if (n4) launch(*arr, 4, zero, n4);
+        if (tail) launch(*arr, 1, n4, tail);
     } else {
-        if (n4)
-            hipLaunchKernelGGL((sdfk_interp_kernel<4, SrcGrid>), dim3(blocks_for(n4, 4)), dim3(SDFK_BLOCK), 0, stream,
-                               d->d_code, n_instr, prm, tab, *grid, zero, n4, d_out, p->result_reg, aux, aux_stride);
-        if (tail)
-            hipLaunchKernelGGL((sdfk_interp_kernel<1, SrcGrid>), dim3(blocks_for(tail, 1)), dim3(SDFK_BLOCK), 0,
-                               stream, d->d_code, n_instr, prm, tab, *grid, n4, tail, d_out, p->result_reg, aux, aux_stride);
+        if (n4) launch(*grid, 4, zero, n4);
+        if (tail) launch(*grid, 1, n4, tail);
     }
     HIPCHK(hipGetLastError());
     return 0;
