@@ -614,10 +614,11 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
 #pragma unroll 1
   for (unsigned tt = 0; tt < SDFK_RTILES; ++tt) {
     // Workgroups go round-robin to the 8 XCDs: an XCD takes runs of SDFK_XGROUP consecutive tiles (the grid is a
-    // multiple of 8 * SDFK_XGROUP), i.e. a few whole row blocks at a time, so the window a row shares with the next
-    // one is fetched from HBM once and found in that XCD's L2 the second time, while all XCDs stay in the same
-    // neighbourhood of the arrays. Runs of 1 (plain round-robin): +0.7 to +3 % on the north-star grid depending on the
-    // box, +18 % on the MEDIAN at 513^3; one contiguous eighth of the grid per XCD: +7 % (eight far-apart streams).
+    // multiple of 8 * SDFK_XGROUP) instead of every eighth tile, while all XCDs stay in the same neighbourhood of the
+    // arrays. Measured, not derived: runs of 1 (plain round-robin) are 0.7 to 3 % slower on the north-star grid
+    // depending on the box and 18 % on the MEDIAN at 513^3; runs aligned to whole row blocks (33, 66) are no better than
+    // runs of 8; one contiguous eighth of the grid per XCD costs 7 % (eight far-apart streams). HBM traffic is the same
+    // in all of them (DESIGN 9.1).
     const unsigned xg_t = sdfk_bx() / 8;
     const unsigned tile = (((xg_t / SDFK_XGROUP) * 8 + sdfk_bx() % 8) * SDFK_XGROUP + xg_t % SDFK_XGROUP) * SDFK_RTILES + tt;
     if (tile * SDFK_RNBRICK >= g.nbricks) break;
