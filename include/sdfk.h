@@ -173,9 +173,11 @@ int sdfk_eval_grid_aux(sdfk_program* prog, const float* ax0, int64_t n0, const f
  *                  else boundary = field < sep_min (the smallest grid spacing), scan-line parity along axes 0 and 1,
  *                  2x2x1 average, inner crop + edge pad (crop = 0: signed_old, :163-218, without it),
  *                  field *= (1 - 2*(average > 0.5)). */
-/* d_field: 16-byte aligned (sdfk_field_min and sdfk_grid_signed read it in 16-byte pieces). */
+/* d_field: 16-byte aligned for sdfk_field_min (it reads 16-byte pieces); sdfk_grid_signed takes any float alignment. */
 int sdfk_field_min(const float* d_field, int64_t n, float* out_min, void* stream);
-/* d_scratch: n0*n1*n2*4 bytes of device memory for the operator's work arrays (NULL: allocated and freed inside). */
+/* d_scratch: n0*n1*n2*4 bytes of device memory for the operator's work arrays (NULL: allocated and freed inside).
+ * sdfk_grid_signed keeps its work as bit planes (six arrays of n0*n1*ceil(n2/32) words) inside it and allocates its
+ * own few bytes for grids thinner than 11 points along the last axis. */
 int sdfk_grid_box_average(float* d_field, int64_t n0, int64_t n1, int64_t n2, int k0, int k1, int k2, int iterations,
                           void* d_scratch, void* stream);
 int sdfk_grid_edge_detect(float* d_field, int64_t n0, int64_t n1, int64_t n2, void* d_scratch, void* stream);
