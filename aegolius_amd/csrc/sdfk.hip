@@ -15,6 +15,7 @@
 #include <hip/hiprtc.h>
 
 #include <chrono>
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <condition_variable>
@@ -29,7 +30,9 @@
 #include <thread>
 #include <string>
 #include <vector>
+#include <dirent.h>
 #include <sys/stat.h>
+#include <sys/time.h>
 #include <unistd.h>
 
 #include "../../include/sdfk.h"
@@ -194,6 +197,7 @@ struct CodeObject {
     int state = 0;
     std::vector<char> co;
     std::string error;
+    std::string disk_path;                // non-empty: `co` was read from this file of the on-disk cache
     double build_seconds = 0.0;
     std::chrono::steady_clock::time_point failed_at;
 };
@@ -628,6 +632,17 @@ static std::string rtc_cache_path(const std::string& src, const std::string& opt
     snprintf(name, sizeof name, "/sdfk-%016llx-%zu.co", h, src.size());
     return dir + name;
 }
+// File = code object + 24-byte trailer {magic, payload length, FNV-1a of the payload}: a truncated or foreign file is
+// never handed to hipModuleLoadData (it is deleted instead).
+static const unsigned long long kCacheMagic = 0x53444643'4f424a31ull;           // "SDFCOBJ1"
+static unsigned long long fnv1a(const char* p, size_t n) {
+    unsigned long long h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) {
+        h ^= (unsigned char)p[i];
+        h *= 1099511628211ull;
+    }
+    return h;
+}
 static bool rtc_cache_read(const std::string& path, std::vector<char>* out) {
     if (path.empty()) return false;
     FILE* f = fopen(path.c_str(), "rb");
@@ -635,22 +650,64 @@ static bool rtc_cache_read(const std::string& path, std::vector<char>* out) {
     bool ok = false;
     if (fseek(f, 0, SEEK_END) == 0) {
         const long size = ftell(f);
-        if (size > 0 && fseek(f, 0, SEEK_SET) == 0) {
+        if (size > 24 && fseek(f, 0, SEEK_SET) == 0) {
             out->resize((size_t)size);
             ok = fread(out->data(), 1, (size_t)size, f) == (size_t)size;
+            if (ok) {
+                unsigned long long tr[3];
+                memcpy(tr, out->data() + size - 24, 24);
+                ok = tr[0] == kCacheMagic && tr[1] == (unsigned long long)(size - 24) && tr[2] == fnv1a(out->data(), (size_t)size - 24);
+                out->resize((size_t)size - 24);
+            }
         }
     }
     fclose(f);
+    if (!ok) {
+        out->clear();
+        (void)remove(path.c_str());                            // truncated / corrupt / older format: rebuilt and rewritten
+    } else {
+        (void)utimes(path.c_str(), nullptr);                   // most recently used (the eviction below goes by mtime)
+    }
     return ok;
+}
+// keep the directory below SDFK_CACHE_MAX_MB (default 512): oldest files go first, down to three quarters of the cap
+static void rtc_cache_evict(const std::string& dir) {
+    static const long long cap = [] {
+        const char* e = getenv("SDFK_CACHE_MAX_MB");
+        const long long v = e ? atoll(e) : 512;
+        return (v > 0 ? v : 512) * (1ll << 20);
+    }();
+    DIR* d = opendir(dir.c_str());
+    if (!d) return;
+    std::vector<std::pair<long long, std::pair<std::string, long long>>> files;   // (mtime, (path, size))
+    long long total = 0;
+    while (dirent* e = readdir(d)) {
+        const std::string name = e->d_name;
+        if (name.compare(0, 5, "sdfk-") != 0) continue;
+        struct stat st;
+        const std::string path = dir + "/" + name;
+        if (stat(path.c_str(), &st) != 0) continue;
+        total += (long long)st.st_size;
+        files.push_back({(long long)st.st_mtime, {path, (long long)st.st_size}});
+    }
+    closedir(d);
+    if (total <= cap) return;
+    std::sort(files.begin(), files.end());
+    for (const auto& f : files) {
+        if (total <= cap / 4 * 3) break;
+        if (remove(f.second.first.c_str()) == 0) total -= f.second.second;
+    }
 }
 static void rtc_cache_write(const std::string& path, const std::vector<char>& co) {
     if (path.empty() || co.empty()) return;
     const std::string tmp = path + ".tmp" + std::to_string((long long)getpid());
     FILE* f = fopen(tmp.c_str(), "wb");
     if (!f) return;                                            // a cache that cannot be written is no error
-    const bool ok = fwrite(co.data(), 1, co.size(), f) == co.size();
-    fclose(f);
+    const unsigned long long tr[3] = {kCacheMagic, (unsigned long long)co.size(), fnv1a(co.data(), co.size())};
+    bool ok = fwrite(co.data(), 1, co.size(), f) == co.size() && fwrite(tr, 1, sizeof tr, f) == sizeof tr;
+    ok = (fclose(f) == 0) && ok;                               // (a short write on a full disk may only show here)
     if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());   // atomic: readers never see a partial file
+    else rtc_cache_evict(rtc_cache_dir());
 }
 
 static std::mutex g_rtc_mu;   // hiprtc and hipModuleLoadData: one thread at a time (see BuildWorker)
@@ -738,11 +795,13 @@ static int rtc_compile_uncached(const std::string& src, std::vector<char>* out, 
     return 0;
 }
 // *from_disk (optional): the code object came from the on-disk cache
-static int rtc_compile(const std::string& src, std::vector<char>* out, std::string* log, int rwb, bool* from_disk = nullptr) {
+static int rtc_compile(const std::string& src, std::vector<char>* out, std::string* log, int rwb, bool* from_disk = nullptr,
+                       std::string* disk_path = nullptr) {
     if (from_disk) *from_disk = false;
     const std::string path = rtc_cache_path(src, rtc_option_key(rwb));
     if (rtc_cache_read(path, out)) {
         if (from_disk) *from_disk = true;
+        if (disk_path) *disk_path = path;
         return 0;
     }
     int rc;
@@ -824,7 +883,8 @@ static void code_build(const std::shared_ptr<CodeObject>& e, const std::string& 
     std::vector<char> co;
     std::string log;
     bool from_disk = false;
-    const int rc = rtc_compile(src, &co, &log, rwb, &from_disk);
+    std::string disk_path;
+    const int rc = rtc_compile(src, &co, &log, rwb, &from_disk, &disk_path);
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (!from_disk) {
         g_compile_count++;
@@ -834,6 +894,7 @@ static void code_build(const std::shared_ptr<CodeObject>& e, const std::string& 
     e->build_seconds = dt;
     if (rc == 0) {
         e->co.swap(co);
+        e->disk_path = disk_path;
         e->state = 2;
     } else {
         e->error = log;
@@ -913,38 +974,63 @@ static std::shared_ptr<SpecModule> get_module(sdfk_program* p, int device, int f
     }
     std::lock_guard<std::mutex> lk(m->mu);                     // per (device, flavour): loads never block other devices
     if (m->loaded) return m;
-    std::shared_ptr<CodeObject> e;
-    {
-        std::lock_guard<std::mutex> ce(g_code_mu);
-        auto it = g_code.find(key);
-        if (it != g_code.end()) e = it->second;
-    }
-    int state = 0;
-    if (e) {
-        std::lock_guard<std::mutex> el(e->mu);
-        state = e->state;
-    }
-    if (state != 2) {
-        e = code_get(key, [&] { return flavour_source(p, flavour); }, rwb, wait);
-        std::lock_guard<std::mutex> el(e->mu);
-        state = e->state;
-    }
-    if (state == 1) return nullptr;                            // still building (wait == false)
-    if (state != 2) {
-        std::lock_guard<std::mutex> el(e->mu);
-        *err = e->error;
-        m->failed = true;
-        m->error = e->error;
-        return m;                                              // (not marked loaded: a later call asks code_get again)
-    }
-    hipError_t he;
-    {
-        std::lock_guard<std::mutex> rl(g_rtc_mu);
-        he = hipModuleLoadData(&m->mod, e->co.data());
-    }
-    for (int i = 0; i < 2 && he == hipSuccess; ++i)
-        if (kFlavourFn[flavour][i]) he = hipModuleGetFunction(&m->fn[i], m->mod, kFlavourFn[flavour][i]);
-    if (he != hipSuccess) {
+    for (int attempt = 0;; ++attempt) {
+        std::shared_ptr<CodeObject> e;
+        {
+            std::lock_guard<std::mutex> ce(g_code_mu);
+            auto it = g_code.find(key);
+            if (it != g_code.end()) e = it->second;
+        }
+        int state = 0;
+        if (e) {
+            std::lock_guard<std::mutex> el(e->mu);
+            state = e->state;
+        }
+        if (state != 2) {
+            e = code_get(key, [&] { return flavour_source(p, flavour); }, rwb, wait);
+            std::lock_guard<std::mutex> el(e->mu);
+            state = e->state;
+        }
+        if (state == 1) return nullptr;                            // still building (wait == false)
+        if (state != 2) {
+            std::lock_guard<std::mutex> el(e->mu);
+            *err = e->error;
+            m->failed = true;
+            m->error = e->error;
+            return m;                                              // (not marked loaded: a later call asks code_get again)
+        }
+        hipError_t he;
+        {
+            std::lock_guard<std::mutex> rl(g_rtc_mu);
+            he = hipModuleLoadData(&m->mod, e->co.data());
+        }
+        for (int i = 0; i < 2 && he == hipSuccess; ++i)
+            if (kFlavourFn[flavour][i]) he = hipModuleGetFunction(&m->fn[i], m->mod, kFlavourFn[flavour][i]);
+        if (he == hipSuccess) break;
+        // A code object that came from the on-disk cache and does not load (another driver / compiler generation, a
+        // damaged file that still passed the checksum): delete the file, forget the blob and build from source once.
+        bool retry = false;
+        {
+            std::lock_guard<std::mutex> el(e->mu);
+            if (attempt == 0 && e->state == 2 && !e->disk_path.empty()) {
+                (void)remove(e->disk_path.c_str());
+                fprintf(stderr, "[sdfk] cached code object %s does not load (%s): rebuilding\n", e->disk_path.c_str(),
+                        hipGetErrorString(he));
+                e->disk_path.clear();
+                e->co.clear();
+                e->state = 0;
+                retry = true;
+            }
+        }
+        if (m->mod) {
+            (void)hipModuleUnload(m->mod);
+            m->mod = nullptr;
+        }
+        (void)hipGetLastError();
+        if (retry) {
+            wait = true;                                           // the caller gets the rebuilt kernel, not a second failure
+            continue;
+        }
         m->failed = true;
         m->error = std::string("hipModuleLoadData/GetFunction: ") + hipGetErrorString(he);
         *err = m->error;
@@ -968,9 +1054,13 @@ static int ensure_resident(sdfk_program* p, int device, hipStream_t stream, DevS
             HIPCHK(hipMemcpy(d.d_tables, p->tables.data(), p->tables.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     if (d.params_version != p->params_version) {
-        if (!p->params.empty())
+        // enqueued on the caller's stream (it must not overtake kernels of that stream that still read the old values)
+        // and WAITED for: other streams of the device (the two slots of the host pipeline) launch right after this
+        if (!p->params.empty()) {
             HIPCHK(hipMemcpyAsync(d.d_params, p->params.data(), p->params.size() * sizeof(float),
                                   hipMemcpyHostToDevice, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+        }
         d.params_version = p->params_version;
     }
     *out = &d;
@@ -1460,28 +1550,31 @@ static void parallel_ranges(int64_t count, F fn) {
     fn(0, std::min(count, step));
     for (std::thread& h : helpers) h.join();
 }
-static int stage_for(int device, int64_t want, HostStage** out) {
+static HostStage* stage_of(int device) {
     std::lock_guard<std::mutex> lk(g_stage_mu);
     std::unique_ptr<HostStage>& st = g_stage[device];
     if (!st) st.reset(new HostStage);
-    if (st->chunk < want) {
-        for (HostSlot& sl : st->slot) {
-            if (sl.h_co) (void)hipHostFree(sl.h_co);
-            if (sl.h_out) (void)hipHostFree(sl.h_out);
-            if (sl.d_co) (void)hipFree(sl.d_co);
-            if (sl.d_out) (void)hipFree(sl.d_out);
-            sl.h_co = sl.h_out = sl.d_co = sl.d_out = nullptr;
-            if (!sl.stream) HIPCHK(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
-            if (!sl.done) HIPCHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-            st->chunk = 0;
-            HIPCHK(hipHostMalloc((void**)&sl.h_co, (size_t)want * 3 * sizeof(float), hipHostMallocDefault));
-            HIPCHK(hipHostMalloc((void**)&sl.h_out, (size_t)want * sizeof(float), hipHostMallocDefault));
-            HIPCHK(hipMalloc(&sl.d_co, (size_t)want * 3 * sizeof(float)));
-            HIPCHK(hipMalloc(&sl.d_out, (size_t)want * sizeof(float)));
-        }
-        st->chunk = want;
+    return st.get();
+}
+// the caller holds st->mu: no other call of this device has anything in flight in the slots being replaced
+static int stage_grow(HostStage* st, int64_t want) {
+    if (st->chunk >= want) return 0;
+    for (HostSlot& sl : st->slot) {
+        if (sl.stream) HIPCHK(hipStreamSynchronize(sl.stream));
+        if (sl.h_co) (void)hipHostFree(sl.h_co);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        if (sl.d_co) (void)hipFree(sl.d_co);
+        if (sl.d_out) (void)hipFree(sl.d_out);
+        sl.h_co = sl.h_out = sl.d_co = sl.d_out = nullptr;
+        if (!sl.stream) HIPCHK(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        if (!sl.done) HIPCHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        st->chunk = 0;
+        HIPCHK(hipHostMalloc((void**)&sl.h_co, (size_t)want * 3 * sizeof(float), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void**)&sl.h_out, (size_t)want * sizeof(float), hipHostMallocDefault));
+        HIPCHK(hipMalloc(&sl.d_co, (size_t)want * 3 * sizeof(float)));
+        HIPCHK(hipMalloc(&sl.d_out, (size_t)want * sizeof(float)));
     }
-    *out = st.get();
+    st->chunk = want;
     return 0;
 }
 
@@ -1506,10 +1599,10 @@ static int eval_host_impl(sdfk_program* p, const void* co, int co_dtype, int64_t
                                             : detect_row_len(static_cast<const double*>(co), n, row_stride, &flat);
     if (row_len > 0 && chunk > row_len) chunk = chunk / row_len * row_len;   // whole rows per chunk
     const int64_t stride = (chunk + 63) & ~(int64_t)63;
-    HostStage* st = nullptr;
-    int rc = stage_for(device, stride, &st);
+    HostStage* st = stage_of(device);
+    std::lock_guard<std::mutex> lk(st->mu);                  // one host-path call per device at a time, growth included
+    int rc = stage_grow(st, stride);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(st->mu);
     // the first call of a program builds its kernel: do that before anything is in flight (the build may take seconds)
     auto hand_over = [&](HostSlot& sl) -> int {             // wait for the slot's chunk and give its field to the caller
         if (sl.pending_start < 0) return 0;

@@ -87,7 +87,12 @@ def evaluate_gathered_overlapped(evaluate_chunk, full, n_total, unit=1, chunks=4
                           W - 1 times over one link pair. No staging buffer, no padding for the uneven last slab.
     schedule "collective" all_gather_into_tensor per piece into a (W, piece) staging buffer + one strided copy into
                           the field; the last rank's surplus rows travel by one broadcast.
-    Works on CPU tensors with gloo (no streams: the same calls in program order) — how the tests run it."""
+
+    Transports: device tensors over RCCL (backend "nccl") go as they are; CPU tensors over gloo (the tests) issue the
+    same calls in program order; DEVICE tensors over gloo (several ranks rehearsing on one GPU: gloo's TCP transport
+    reads host memory only — handing it device pointers is what stalled the round-2 rehearsal) are staged through host
+    copies piece by piece, with the same control flow, streams and events around them.
+    Ranks are GROUP-local throughout (`group_peer` / `group_src`), so a sub-group works."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -104,6 +109,7 @@ def evaluate_gathered_overlapped(evaluate_chunk, full, n_total, unit=1, chunks=4
     if local.numel() < count:
         raise ValueError("`local` is smaller than the rank's slab")
     cuda = full.is_cuda
+    via_host = cuda and world > 1 and dist.get_backend(group) == "gloo"
     comm = torch.cuda.Stream(device=full.device) if cuda else None
     works = []
 
@@ -126,24 +132,57 @@ def evaluate_gathered_overlapped(evaluate_chunk, full, n_total, unit=1, chunks=4
         if world == 1:
             return
         if schedule == "direct":
-            ops = []
+            ops, landed = [], []
+            send = None
+            if mine is not None:
+                send = local[mine[0]:mine[0] + mine[1]]
+                if via_host:
+                    comm.synchronize()                         # (this piece is complete: we run on `comm`)
+                    send = send.cpu()
             for peer in range(world):
                 if peer == rank:
                     continue
-                if mine is not None:
-                    ops.append(dist.P2POp(dist.isend, local[mine[0]:mine[0] + mine[1]], peer, group))
+                if send is not None:
+                    ops.append(dist.P2POp(dist.isend, send, group=group, group_peer=peer))
                 if i < len(pieces[peer]):
                     o, c = pieces[peer][i]
                     ps = spans[peer][0]
-                    ops.append(dist.P2POp(dist.irecv, full[ps + o:ps + o + c], peer, group))
+                    into = full[ps + o:ps + o + c]
+                    if via_host:
+                        host = torch.empty(c, dtype=full.dtype)
+                        landed.append((into, host))
+                        into = host
+                    ops.append(dist.P2POp(dist.irecv, into, group=group, group_peer=peer))
             if ops:
-                works.extend(dist.batch_isend_irecv(ops))
+                reqs = dist.batch_isend_irecv(ops)
+                if via_host:
+                    for w in reqs:
+                        w.wait()
+                    for into, host in landed:
+                        into.copy_(host)
+                else:
+                    works.extend(reqs)
         else:
             o, c = pieces[0][i]                                # the common part: the same piece on every rank
-            stage = torch.empty((world, c), dtype=full.dtype, device=full.device)
-            dist.all_gather_into_tensor(stage.view(-1), local[o:o + c], group=group)
             per = spans[0][1]
+            if via_host:
+                comm.synchronize()
+                host = torch.empty((world, c), dtype=full.dtype)
+                dist.all_gather_into_tensor(host.view(-1), local[o:o + c].cpu(), group=group)
+                stage = host.to(full.device)
+            else:
+                stage = torch.empty((world, c), dtype=full.dtype, device=full.device)
+                dist.all_gather_into_tensor(stage.view(-1), local[o:o + c], group=group)
             full[:world * per].view(world, per)[:, o:o + c].copy_(stage)
+
+    def surplus(lo, hi):                                       # the last slab's rows beyond the common part
+        if via_host:
+            comm.synchronize()
+            host = full[lo:hi].cpu()
+            dist.broadcast(host, group=group, group_src=world - 1)
+            full[lo:hi].copy_(host)
+        else:
+            dist.broadcast(full[lo:hi], group=group, group_src=world - 1)
 
     if schedule == "direct" or world == 1:
         pieces = [chunk_bounds(c, chunks, chunk_unit) for _, c in spans]
@@ -165,7 +204,7 @@ def evaluate_gathered_overlapped(evaluate_chunk, full, n_total, unit=1, chunks=4
             if rank == world - 1:
                 evaluate_chunk(ls + per, lc - per, local[per:lc])
                 on_comm(lambda: full[ls + per:ls + lc].copy_(local[per:lc]))
-            on_comm(lambda: dist.broadcast(full[ls + per:ls + lc], world - 1, group=group))
+            on_comm(lambda: surplus(ls + per, ls + lc))
     for w in works:
         w.wait()
     if cuda:

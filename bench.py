@@ -32,11 +32,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 BYTES_PER_POINT = 16            # 3 x fp32 coordinate loads + 1 x fp32 store
-PMC_RECORD = os.path.join("profiles", "r02_pmc_traffic.json")   # static: counters cannot be read from inside a run
+PMC_RECORDS = [os.path.join("profiles", "r03_pmc_traffic.json"),   # static: counters cannot be read from inside a run
+               os.path.join("profiles", "r02_pmc_traffic.json")]
 
 
 def parse():
@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the field-consumer extras (selection, gradient)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the other BASELINE configs (N = 1 extra)")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host_path extra (it launches the "
                     "same kernel on a small array, which skews per-kernel averages under rocprofv3)")
     ap.add_argument("--no-rows", action="store_true", help="do not pass the row-length layout hint (flat 128-point bricks)")
@@ -59,19 +60,12 @@ def parse():
     return ap.parse_args()
 
 
-def build_workload(name, ns, scenes):
-    if name == "cfg1":
-        return ns.Sphere(0.5), (2, 2, 2), "cfg1: Sphere(0.5)"
-    if name == "cfg2":
-        return scenes.cfg2_tree(ns), (2, 2, 2), "cfg2: 10-primitive left-deep SMOOTH_UNION2(0.1) chain, rng 1234"
-    if name == "cfg3":
-        return scenes.cfg3_chain(ns), (4, 4, 4), "cfg3: Box + elongation/twist/bend/infinite_repetition"
-    if name == "cfg4":
-        return scenes.cfg4_scene2d(ns), (10, 10), "cfg4: 2-D n-ary UNION of 50 onion/rounded primitives, rng 7"
-    return scenes.cfg5_tree(ns), (3, 3, 3), "cfg5: 20-primitive 3-level tree, rng 2049"
+def build_workload(name, ns):
+    from aegolius_amd import workloads
+    return workloads.build(name, ns)
 
 
-def cpu_baseline(scenes, workload, axes, budget_s):
+def cpu_baseline(workload, axes, budget_s):
     """Oracle (float64 NumPy restatement of the reference, same operation order and temporaries)
     on whole x-planes of the same grid, default NumPy/BLAS threading."""
     import aegolius_amd.cores as ns
@@ -81,7 +75,7 @@ def cpu_baseline(scenes, workload, axes, budget_s):
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:  # noqa: BLE001
         threads = os.cpu_count() or 1
-    tree, _size, _desc = build_workload(workload, ns, scenes)
+    tree, _size, _desc = build_workload(workload, ns)
     ny, nz = axes[1].size, axes[2].size
     plane = np.empty((3, ny * nz))
     plane[1] = np.repeat(axes[1].astype(np.float64), nz)
@@ -104,13 +98,13 @@ def cpu_baseline(scenes, workload, axes, budget_s):
             "host_cpus": os.cpu_count()}
 
 
-def verify_sample(scenes, workload, axes, start, out, count, samples=20000, seed=11):
+def verify_sample(workload, axes, start, out, count, samples=20000, seed=11):
     """The field the timed region left in `out`, at `samples` random points of this rank's slab, against the oracle
     (float64 on the fp32-rounded coordinates: "identical grids"); tolerance of the parity tests, 1e-6 * max(1, |ref|)."""
     import torch
     import aegolius_amd.cores as ns
     from oracle import sdf_oracle
-    tree, _size, _desc = build_workload(workload, ns, scenes)
+    tree, _size, _desc = build_workload(workload, ns)
     rng = np.random.default_rng(seed)
     idx = np.sort(rng.choice(count, size=min(samples, count), replace=False))
     got = out[torch.from_numpy(idx).to(out.device)].cpu().numpy().astype(np.float64)
@@ -128,16 +122,16 @@ def verify_sample(scenes, workload, axes, start, out, count, samples=20000, seed
 _FIRST_CALL = r"""
 import json, sys, time
 t_import = time.perf_counter()
-sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+sys.path.insert(0, {root!r})
 import numpy as np
-import scenes, bench
+import bench
 import aegolius_amd.cores as ns
 from aegolius_amd import _engine
 _engine.require_gpu()
 co, _ = ns.generate_grid((2, 2, 2), (128, 128, 128))       # configs[0] size: where the reference needs 2.6 s per call
 ns.Sphere(0.25).create(co[:, :4096].copy())                  # device context, allocator: not part of the tree's latency
 t0 = time.perf_counter()
-tree, _size, _desc = bench.build_workload({workload!r}, ns, scenes)
+tree, _size, _desc = bench.build_workload({workload!r}, ns)
 first = tree.create(co)
 t1 = time.perf_counter()
 second = tree.create(co)
@@ -206,7 +200,7 @@ class Run:
         self.torch.cuda.synchronize()
 
     def timed(self, steps, warmup):
-        """-> (elapsed seconds over `steps`, kernel ms per step, sorted per-step ms): MAX over ranks for the first two."""
+        """-> (elapsed seconds over `steps`, kernel ms per step, median, min of the per-step ms): MAX over ranks."""
         for _ in range(warmup):
             self.step()
         ev = [self.engine.Event() for _ in range(steps + 1)]
@@ -227,6 +221,81 @@ class Run:
         return float(t[0]), float(t[1]), float(t[2]), float(t[3])
 
 
+def reassembly_legs(torch, dist, sdist, local, n_total, start, count, row_len, evaluate_chunk, fence, red_dev,
+                    compute_s, chunks=8, chunk_rows=32):
+    """The three ways of putting the whole field on every rank, each warmed up once and timed once (MAX over ranks),
+    never part of `value`: the plain all-gather after the evaluation and the two schedules of
+    distributed.evaluate_gathered_overlapped, with a check that the rank's own slab arrived intact.
+    `local`: this rank's slab (a view of its field buffer); `evaluate_chunk(start, count, out)` re-evaluates a piece.
+    Module-level so that the CPU test (gloo, CPU tensors) walks the very sequence the GPU run walks."""
+    res = {"bytes_per_rank": int(count * 4), "compute_ms_per_step": compute_s * 1e3}
+
+    def max_over_ranks(seconds):
+        t = torch.tensor([seconds], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
+
+    full = sdist.gather_slabs(local, n_total, unit=row_len)           # warm-up (communicators, buffers)
+    fence()
+    g0 = time.perf_counter()
+    full = sdist.gather_slabs(local, n_total, unit=row_len)
+    fence()
+    gt = max_over_ranks(time.perf_counter() - g0)
+    intact = bool(torch.equal(full[start:start + count], local))
+    res["after_compute"] = {"gather_ms": gt * 1e3, "schedule": "all_gather_into_tensor after the evaluation",
+                            "mpoints_per_s_with_gather": n_total / (compute_s + gt) / 1e6, "own_slab_intact": intact}
+    del full
+    full = torch.empty(n_total, dtype=local.dtype, device=local.device)
+    for schedule in ("direct", "collective"):
+        try:
+            def once():
+                sdist.evaluate_gathered_overlapped(evaluate_chunk, full, n_total, unit=row_len, chunks=chunks,
+                                                   schedule=schedule, chunk_unit=chunk_rows * row_len, local=local)
+            full.fill_(float("nan"))
+            once()                                                    # warm-up
+            fence()
+            full.fill_(float("nan"))
+            fence()
+            o0 = time.perf_counter()
+            once()
+            fence()
+            ot = max_over_ranks(time.perf_counter() - o0)
+            # the whole field arrived (no NaN left) and this rank's part of it is the slab it computed
+            same = torch.tensor([1.0], dtype=torch.float64, device=red_dev)
+            if bool(torch.isnan(full).any()) or not torch.equal(full[start:start + count], local[:count]):
+                same[0] = 0.0
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            res["overlapped_" + schedule] = {"evaluate_and_gather_ms": ot * 1e3, "chunks": chunks,
+                                             "mpoints_per_s_with_gather": n_total / ot / 1e6,
+                                             "own_slab_intact": bool(same[0] > 0)}
+        except Exception as exc:  # noqa: BLE001
+            res["overlapped_" + schedule] = {"error": repr(exc)}
+    return res
+
+
+class Extras:
+    """Everything outside the timed region: a failure is reported in the line, never raised; the line records how
+    long each extra took and — should the watchdog fire — which one was in flight."""
+
+    def __init__(self, line):
+        self.line, self.in_flight, self.seconds = line, None, {}
+
+    def __call__(self, name, fn):
+        self.in_flight = name
+        t0 = time.perf_counter()
+        try:
+            val = fn()
+        except Exception as exc:  # noqa: BLE001
+            val = {"error": repr(exc)}
+        self.seconds[name] = round(time.perf_counter() - t0, 3)
+        self.in_flight = None
+        if self.line is not None:
+            if val is not None:
+                self.line[name] = val
+            self.line["extras_s"] = self.seconds
+        return val
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -242,8 +311,9 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU path")
-    # SDFK_BENCH_REHEARSE=1: every rank on device 0 with gloo (reductions on the CPU) — to walk the N > 1 control
-    # flow on a one-GPU box; RCCL refuses several ranks on one device. Never set by the driver.
+    # SDFK_BENCH_REHEARSE=1: every rank on device 0 with gloo (reductions on the CPU, transfers staged through host
+    # memory) — walks the whole N > 1 control flow on a one-GPU box; RCCL refuses several ranks on one device.
+    # Never set by the driver.
     rehearse = world > 1 and os.environ.get("SDFK_BENCH_REHEARSE") == "1"
     torch.cuda.set_device(0 if rehearse else local_rank)
     dev = torch.device("cuda", 0 if rehearse else local_rank)
@@ -260,7 +330,6 @@ def main():
         __graft_entry__.build()                               # no-op when libsdfk.so is current
     if world > 1:
         dist.barrier()
-    import scenes
     import aegolius_amd.cores as ns
     from aegolius_amd import _engine
     from aegolius_amd import distributed as sdist
@@ -268,10 +337,10 @@ def main():
     from aegolius_amd.cores.helper_functions import grid_axes
     _engine.lib()  # fail loudly if the HIP extension is missing
 
-    tree, size, desc = build_workload(args.workload, ns, scenes)
+    tree, size, desc = build_workload(args.workload, ns)
 
-    def fp32_axes(request):
-        axes64, _res = grid_axes(size, (request,) * len(size))
+    def fp32_axes(request, gsize=size):
+        axes64, _res = grid_axes(gsize, (request,) * len(gsize))
         return [a.astype(np.float32) for a in axes64]       # fp32-rounded float64 linspace ("identical grids")
     axes = fp32_axes(args.grid)
 
@@ -280,6 +349,14 @@ def main():
     # the timed region always waits for the specialised kernel (AUTO would serve the first calls from the interpreter
     # while hiprtc builds in the background: measured separately under "first_call")
     mode = {"interpret": _engine.MODE_INTERPRET, "nocull": _engine.MODE_NOCULL}.get(args.mode, _engine.MODE_SPECIALIZED)
+
+    def kernel_name(lowered, rows):
+        if mode == _engine.MODE_INTERPRET:
+            return "sdfk_interp_kernel"
+        if mode == _engine.MODE_SPECIALIZED and len(lowered.cull_sites) > 0:
+            return ("sdfk_spec_r (hiprtc, topology-specialised, exact culling on 32x16-point row blocks)" if rows else
+                    "sdfk_spec_t (hiprtc, topology-specialised, exact culling on 128-point bricks)")
+        return "sdfk_spec_v4 (hiprtc, topology-specialised)"
     culled = mode == _engine.MODE_SPECIALIZED and len(low.cull_sites) > 0
 
     run = Run(torch, dist, _engine, prog, axes, world, rank, dev, red_dev, mode, not args.no_rows)
@@ -296,15 +373,18 @@ def main():
         value = n_total * args.steps / elapsed / 1e6
         achieved = BYTES_PER_POINT * count / (kernel_ms_max * 1e-3) / 1e9
         traffic = valu_busy = traffic_source = None
-        pmc = os.path.join(ROOT, PMC_RECORD)
-        if os.path.exists(pmc):
+        for record in PMC_RECORDS:
+            pmc = os.path.join(ROOT, record)
+            if not os.path.exists(pmc):
+                continue
             try:
                 rec = json.load(open(pmc))
                 if rec.get("points_per_launch") == count and rec.get("workload") == args.workload:
                     traffic = rec.get("hbm_bytes_per_launch")
                     valu_busy = rec.get("valu_active_frac")
                     traffic_source = "%s (static record of a separate rocprofv3 --pmc run of this kernel, commit %s; not " \
-                                     "measured by this run)" % (PMC_RECORD, rec.get("commit", "?"))
+                                     "measured by this run)" % (record, rec.get("commit", "?"))
+                    break
             except Exception:  # noqa: BLE001
                 traffic = None
         line = {
@@ -316,11 +396,7 @@ def main():
             "config": {"workload": desc, "grid": "%dx%dx%d (request %d per axis), size %s" % (
                 axes[0].size, axes[1].size, axes[2].size, args.grid, tuple(size)),
                        "points": n_total, "points_per_gpu": count, "sharding": "contiguous x-slabs, no collective",
-                       "kernel": (("sdfk_spec_t (hiprtc, topology-specialised, exact culling on 128-point bricks)" if args.no_rows else
-                                   "sdfk_spec_r (hiprtc, topology-specialised, exact culling on 32x16-point row blocks)")
-                                  if culled else
-                                  "sdfk_spec_v4 (hiprtc, topology-specialised)") if mode != _engine.MODE_INTERPRET
-                       else "sdfk_interp_kernel", "instructions": int(low.code.shape[0]),
+                       "kernel": kernel_name(low, not args.no_rows), "instructions": int(low.code.shape[0]),
                        "cull_sites": int(len(low.cull_sites)) if culled else 0},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
@@ -329,8 +405,11 @@ def main():
             "first_kernel_build_s": t_build,
         }
 
-    # N > 1: whatever happens in the collective extras, rank 0 prints the headline line and every rank leaves
+    # N > 1: whatever happens in the collective extras, rank 0 prints the headline line and every rank leaves — with a
+    # NON-ZERO exit code: a collective that does not return is a failure of the run, and a process that holds a GPU
+    # never reports success from a watchdog. The line says which extra was in flight.
     printed = threading.Event()
+    extra = Extras(line)
 
     def emit():
         if rank == 0 and not printed.is_set():
@@ -339,28 +418,23 @@ def main():
 
     def watchdog():
         if rank == 0:
-            line["extras_timeout"] = True
+            line["extras_timeout"] = {"in_flight": extra.in_flight, "after_s": args.extras_timeout,
+                                      "finished": dict(extra.seconds)}
         emit()
         sys.stdout.flush()
-        os._exit(0)
+        sys.stderr.write("[bench] rank %d: extras did not return within %.0f s (in flight: %s)\n"
+                         % (rank, args.extras_timeout, extra.in_flight))
+        sys.stderr.flush()
+        os._exit(3)
     timer = None
     if world > 1 and not args.no_extras:
         timer = threading.Timer(args.extras_timeout, watchdog)
         timer.daemon = True
         timer.start()
 
-    def extra(name, fn):
-        """an extra outside the timed region: a failure is reported in the line, never raised"""
-        try:
-            val = fn()
-        except Exception as exc:  # noqa: BLE001
-            val = {"error": repr(exc)}
-        if line is not None and val is not None:
-            line[name] = val
-
     # ---- the field the timed steps wrote, against the oracle (every rank checks its slab; rank 0 reports) ----
     def verified():
-        v = verify_sample(scenes, args.workload, axes, start, run.out, count)
+        v = verify_sample(args.workload, axes, start, run.out, count)
         if world > 1:
             t = torch.tensor([v["max_rel_err"], float(v["violations"])], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -395,9 +469,9 @@ def main():
         def grid_512():
             ax = fp32_axes(512)
             r2 = Run(torch, dist, _engine, prog, ax, world, rank, dev, red_dev, mode, not args.no_rows)
-            e2, k2, med2, min2 = r2.timed(max(10, args.steps), 3)
             steps2 = max(10, args.steps)
-            v = verify_sample(scenes, args.workload, ax, r2.start, r2.out, r2.count, samples=5000)
+            e2, k2, med2, min2 = r2.timed(steps2, 3)
+            v = verify_sample(args.workload, ax, r2.start, r2.out, r2.count, samples=5000)
             return {"grid": "%dx%dx%d" % (ax[0].size, ax[1].size, ax[2].size), "points": r2.n_total, "steps": steps2,
                     "value": r2.n_total * steps2 / e2 / 1e6, "unit": "Mpoints/s", "ms_per_step": e2 / steps2 * 1e3,
                     "kernel_ms": k2, "kernel_ms_median": med2, "kernel_ms_min": min2,
@@ -407,6 +481,53 @@ def main():
             extra("grid_512", grid_512)
 
     if not args.no_extras and rank == 0 and world == 1:
+        # ---- every other BASELINE config on this box, each with its own verification sample (N = 1 only) ----
+        def other_configs():
+            from aegolius_amd import workloads
+            res = {}
+            plan = [("cfg1", 1024, "1024^3 request (the config's own 128^3 grid is 2 M points: launch-bound)"),
+                    ("cfg3", 1024, None), ("cfg4", 16384, None), ("cfg5", 1024, "1024^3 request"),
+                    ("cfg5", 2048, "the config's own 2048^3 request on ONE GPU (137 GB resident)")]
+            for name, request, note in plan:
+                if name == args.workload and request == args.grid:
+                    continue
+                key = name if request != 2048 else name + "_2049"
+                try:
+                    t_tree, t_size, t_desc = workloads.build(name, ns)
+                    ax = fp32_axes(request, t_size)
+                    pts = int(ax[0].size) * int(ax[1].size) * int(ax[2].size)
+                    free_b, _total_b = torch.cuda.mem_get_info()
+                    if 16.0 * pts * 1.02 > free_b:
+                        res[key] = {"skipped": "needs %.0f GB, %.0f GB free" % (16e-9 * pts, free_b * 1e-9)}
+                        continue
+                    t_low = lower_geometry(t_tree)
+                    t_prog = _engine.Program.from_lowered(t_low)
+                    r = Run(torch, dist, _engine, t_prog, ax, 1, 0, dev, red_dev, mode, not args.no_rows)
+                    t0 = time.perf_counter()
+                    r.step()
+                    torch.cuda.synchronize()
+                    build_s = time.perf_counter() - t0
+                    steps_o = 5
+                    e, k, med, mn = r.timed(steps_o, 2)
+                    v = verify_sample(name, ax, 0, r.out, r.count, samples=5000)
+                    res[key] = {"workload": t_desc, "grid": "%dx%dx%d" % (ax[0].size, ax[1].size, ax[2].size),
+                                "points": pts, "steps": steps_o, "value": pts * steps_o / e / 1e6, "unit": "Mpoints/s",
+                                "ms_per_step": e / steps_o * 1e3, "kernel_ms": k, "kernel_ms_median": med,
+                                "kernel_ms_min": mn, "kernel": kernel_name(t_low, not args.no_rows),
+                                "roofline_frac": BYTES_PER_POINT * pts / (k * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                "first_kernel_build_s": build_s,
+                                "verified": {"points": v["points"], "max_rel_err": v["max_rel_err"],
+                                             "violations": v["violations"]}}
+                    if note:
+                        res[key]["note"] = note
+                    del r, t_prog
+                    torch.cuda.empty_cache()
+                except Exception as exc:  # noqa: BLE001
+                    res[key] = {"error": repr(exc)}
+            return res
+        if not args.no_other_configs:
+            extra("other_configs", other_configs)
+
         # the same evaluation straight from the per-axis tables (no coordinate array: 4 B/point) -- a separate line
         def grid_path():
             scratch = torch.empty_like(run.out)
@@ -510,60 +631,23 @@ def main():
         if not args.no_next_rows:
             extra("next_rows", next_rows)
 
-    # ---- reassembling the field on every rank (RCCL over xGMI): never part of `value` ----
-    if world > 1 and not args.no_allgather and not args.no_extras and not rehearse:
-        def allgather():
-            res = {"bytes_per_rank": int(count * 4), "compute_ms_per_step": elapsed / args.steps * 1e3}
-            local = run.out[:count]
-            full = sdist.gather_slabs(local, n_total, unit=row_len)          # warm-up (RCCL communicators, buffers)
-            run.fence()
-            g0 = time.perf_counter()
-            full = sdist.gather_slabs(local, n_total, unit=row_len)
-            run.fence()
-            gt = torch.tensor([time.perf_counter() - g0], dtype=torch.float64, device=dev)
-            dist.all_reduce(gt, op=dist.ReduceOp.MAX)
-            res["after_compute"] = {"gather_ms": float(gt[0]) * 1e3, "schedule": "all_gather_into_tensor after the evaluation",
-                                    "mpoints_per_s_with_gather": n_total / (elapsed / args.steps + float(gt[0])) / 1e6}
-            del full
-            full = torch.empty(n_total, dtype=torch.float32, device=dev)
-
-            def evaluate_chunk(cstart, ccount, out_view):
-                off = cstart - start
-                prog.eval_device(run.co.data_ptr() + 4 * off, ccount, stride, out_view.data_ptr(), stream=stream, mode=mode,
-                                 row_len=row_len if not args.no_rows else None, flat=axes[2].size == 1)
-            for schedule in ("direct", "collective"):
-                try:
-                    def once():
-                        sdist.evaluate_gathered_overlapped(evaluate_chunk, full, n_total, unit=row_len, chunks=8, schedule=schedule,
-                                                           chunk_unit=32 * row_len, local=run.out)
-                    once()                                                    # warm-up
-                    run.fence()
-                    o0 = time.perf_counter()
-                    once()
-                    run.fence()
-                    ot = torch.tensor([time.perf_counter() - o0], dtype=torch.float64, device=dev)
-                    dist.all_reduce(ot, op=dist.ReduceOp.MAX)
-                    idx = torch.randint(0, n_total, (4096,), device=dev)
-                    same = torch.tensor([1.0], device=dev)
-                    mine = (idx >= start) & (idx < start + count)
-                    if not torch.equal(full[idx[mine]], run.out[idx[mine] - start]):
-                        same[0] = 0.0
-                    dist.all_reduce(same, op=dist.ReduceOp.MIN)
-                    res["overlapped_" + schedule] = {"evaluate_and_gather_ms": float(ot[0]) * 1e3, "chunks": 8,
-                                                     "mpoints_per_s_with_gather": n_total / float(ot[0]) / 1e6,
-                                                     "own_slab_intact": bool(same[0] > 0)}
-                except Exception as exc:  # noqa: BLE001
-                    res["overlapped_" + schedule] = {"error": repr(exc)}
-            return res
-        extra("allgather", allgather)
+    # ---- reassembling the field on every rank (RCCL over xGMI; rehearsal: gloo through host copies): never `value` ----
+    if world > 1 and not args.no_allgather and not args.no_extras:
+        def evaluate_chunk(cstart, ccount, out_view):
+            off = cstart - start
+            prog.eval_device(run.co.data_ptr() + 4 * off, ccount, stride, out_view.data_ptr(), stream=stream, mode=mode,
+                             row_len=row_len if not args.no_rows else None, flat=axes[2].size == 1)
+        extra("allgather", lambda: reassembly_legs(torch, dist, sdist, run.out[:count], n_total, start, count, row_len,
+                                                   evaluate_chunk, run.fence, red_dev, elapsed / args.steps))
 
     if timer is not None:
         timer.cancel()
     if rank == 0:
-        if world == 1 and not args.no_extras:
+        # rank 0 alone from here on (the other ranks wait in the closing barrier): no collectives below
+        if not args.no_extras:
             extra("first_call", lambda: first_call_latency(args.workload))
-        if world == 1 and args.cpu_seconds > 0:
-            extra("cpu_baseline", lambda: cpu_baseline(scenes, args.workload, axes, args.cpu_seconds))
+        if args.cpu_seconds > 0:
+            extra("cpu_baseline", lambda: cpu_baseline(args.workload, axes, args.cpu_seconds))
         emit()
 
     if world > 1:

@@ -289,3 +289,56 @@ def test_overlapped_gather_reassembles_the_field(world, shape, chunks):
         for schedule, (ok, full) in res.items():
             assert ok, schedule
             np.testing.assert_array_equal(full, want, err_msg=schedule)
+
+
+# ---- bench.py's N > 1 extras, walked over gloo (the exact call sequence of the GPU run) ---------------------------------
+def _bench_legs_worker(rank, world, port, shape, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from aegolius_amd import distributed as sdist
+        n, row_len = shape[0] * shape[1] * shape[2], shape[2]
+        start, count = sdist.slab_bounds(n, world, rank, row_len)
+
+        def field(s, c):
+            return torch.arange(s, s + c, dtype=torch.float32) * 0.25 - 3.0
+        out = torch.empty(count + 5)                              # the rank's field buffer (padded like bench.Run.out)
+        out[:count] = field(start, count)
+        calls = []
+
+        def evaluate_chunk(cstart, ccount, out_view):
+            calls.append((cstart, ccount))
+            out_view.copy_(field(cstart, ccount))
+        res = bench.reassembly_legs(torch, dist, sdist, out[:count], n, start, count, row_len, evaluate_chunk, dist.barrier,
+                                    torch.device("cpu"), 1e-3, chunks=3, chunk_rows=2)
+        # every re-evaluation stayed inside the rank's slab; 2 schedules x (warm-up + timed) passes over the slab
+        inside = all(start <= a and a + k <= start + count for a, k in calls)
+        q.put((rank, res, inside, sum(k for _a, k in calls), count))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape", [(2, (7, 5, 33)), (3, (5, 3, 9)), (3, (2, 1, 5))])
+def test_bench_reassembly_legs_over_gloo(world, shape):
+    """bench.reassembly_legs — warm-up + timed gather, both overlapped schedules with their warm-up, the NaN-fill /
+    own-slab check — on CPU tensors over gloo with uneven (and, for the last case, empty) slabs."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_legs_worker, args=(r, world, port, shape, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for _rank, res, inside, evaluated, count in got:
+        assert inside and evaluated == 4 * count
+        assert res["after_compute"]["own_slab_intact"] is True
+        for leg in ("overlapped_direct", "overlapped_collective"):
+            assert "error" not in res[leg], res[leg]
+            assert res[leg]["own_slab_intact"] is True
+            assert res[leg]["evaluate_and_gather_ms"] > 0

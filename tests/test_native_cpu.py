@@ -255,9 +255,37 @@ def test_code_objects_are_built_once_per_process_and_cached_on_disk(built, tmp_p
     cold = run(str(tmp_path))
     files = list(tmp_path.iterdir())
     assert cold["builds"] == 1 and cold["again"] < 0.05 and cold["other"] < 0.05
-    assert len(files) == 1 and files[0].suffix == ".co" and files[0].stat().st_size == cold["size"]
+    # the file is the code object + a 24-byte trailer (magic, length, checksum)
+    assert len(files) == 1 and files[0].suffix == ".co" and files[0].stat().st_size == cold["size"] + 24
     warm = run(str(tmp_path))
     assert warm["builds"] == 0 and warm["size"] == cold["size"] and warm["seconds"] < 0.05
     assert len(list(tmp_path.iterdir())) == 1
     off = run("off")
     assert off["builds"] == 1 and len(list(tmp_path.iterdir())) == 1
+    # a damaged file (truncated by a full disk, a flipped byte) is never handed to the loader: it is deleted, the
+    # kernel is rebuilt and the cache rewritten
+    blob = files[0].read_bytes()
+    for damaged in (blob[:len(blob) // 2], blob[:100] + bytes([blob[100] ^ 0xFF]) + blob[101:], b"", blob[:-24]):
+        files[0].write_bytes(damaged)
+        again = run(str(tmp_path))
+        assert again["builds"] == 1 and again["size"] == cold["size"]
+        assert files[0].read_bytes() == blob
+
+
+def test_on_disk_cache_is_size_capped(built, tmp_path):
+    """SDFK_CACHE_MAX_MB bounds the directory: the oldest code objects go when a new one is written."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for k in range(6):                                             # 6 x 300 KB of stale entries, oldest first
+        f = tmp_path / ("sdfk-%016x-1.co" % k)
+        f.write_bytes(b"x" * 300_000)
+        os.utime(f, (1_000_000 + k, 1_000_000 + k))
+    env = dict(os.environ, SDFK_CACHE_DIR=str(tmp_path), SDFK_CACHE_MAX_MB="1")
+    res = subprocess.run([sys.executable, "-c", _CACHE_SCRIPT.format(root=root)], env=env, capture_output=True, text=True,
+                         check=True)
+    assert json.loads(res.stdout.strip().splitlines()[-1])["builds"] == 1
+    left = sorted(p.name for p in tmp_path.iterdir())
+    total = sum(p.stat().st_size for p in tmp_path.iterdir())
+    assert total <= (1 << 20) and any(not n.endswith("-1.co") for n in left)          # the new object stayed
+    assert "sdfk-%016x-1.co" % 0 not in left                                         # the oldest went first
