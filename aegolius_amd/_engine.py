@@ -35,12 +35,14 @@ SIGNATURES = {
     "sdfk_program_source": (_c.c_char_p, [_vp]),
     "sdfk_program_compile_check": (_int, [_vp, _c.POINTER(_sz)]),
     "sdfk_program_compile_flavour": (_int, [_vp, _int, _c.POINTER(_sz), _c.POINTER(_c.c_double)]),
+    "sdfk_debug_compile_external": (_int, [_vp, _int, _c.POINTER(_sz)]),
     "sdfk_debug_jit_stats": (None, [_c.POINTER(_i64), _c.POINTER(_c.c_double)]),
     "sdfk_jit_drain": (None, []),
     "sdfk_debug_set_rtc_defs": (None, [_c.c_char_p]),
     "sdfk_eval_device": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _int]),
     "sdfk_eval_device_rows": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int]),
     "sdfk_eval_device_rows2d": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int]),
+    "sdfk_eval_device_rows3d": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int]),
     "sdfk_debug_row_masks": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _c.POINTER(_i64), _c.POINTER(_int), _vp]),
     "sdfk_eval_grid_sharded": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _int, _vp, _vp, _int]),
     "sdfk_eval_device_aux": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _i64, _vp, _vp, _int]),
@@ -233,11 +235,19 @@ class Program:
                                    mode), "sdfk_eval_host")
         return out
 
-    def eval_device(self, d_co, n, row_stride, d_out, stream=None, mode=MODE_AUTO, row_len=None, flat=False):
+    def eval_device(self, d_co, n, row_stride, d_out, stream=None, mode=MODE_AUTO, row_len=None, flat=False,
+                    plane_rows=None, first_row_in_plane=0):
         """Device pointers (ints). Asynchronous on `stream` (a hipStream_t as int, None = default).
         `row_len`: layout hint — the points are consecutive rows of that many points (the last grid
         dimension of a generate_grid array); speeds up brick culling, never changes the field.
-        `flat`: the rows are those of a flat (two-size) grid: z = 0, rows along y."""
+        `flat`: the rows are those of a flat (two-size) grid: z = 0, rows along y.
+        `plane_rows`, `first_row_in_plane`: 3-D grids — rows per plane (the second grid dimension) and where in its
+        plane the array starts (x-slabs of whole rows): row blocks then never straddle two planes."""
+        if row_len and plane_rows and not flat:
+            check(lib().sdfk_eval_device_rows3d(self._h, _vp(d_co), n, row_stride, int(row_len), int(plane_rows),
+                                                int(first_row_in_plane), _vp(d_out), _vp(stream or 0), mode),
+                  "sdfk_eval_device_rows3d")
+            return
         if row_len and flat:
             check(lib().sdfk_eval_device_rows2d(self._h, _vp(d_co), n, row_stride, int(row_len), _vp(d_out),
                                                 _vp(stream or 0), mode), "sdfk_eval_device_rows2d")

@@ -31,6 +31,9 @@
 #include <string>
 #include <vector>
 #include <dirent.h>
+#include <dlfcn.h>
+#include <spawn.h>
+#include <sys/wait.h>
 #include <sys/stat.h>
 #include <sys/time.h>
 #include <unistd.h>
@@ -572,14 +575,29 @@ struct RowGeom {           // mirrors sdfk_rowgeom of the generated source
     long long R;
     long long row0;
     int yrows;
+    // row blocks never straddle a PLANE of the grid (rows of one x): the slab's rows are the rest of a first plane
+    // (seg0 rows, nb0 blocks), then planes of prow rows (bpp blocks each; the last block of a plane may be partial)
+    unsigned prow, seg0, nb0, bpp;
 };
 // can the row-block kernel take n points in rows of row_len? (brick ids are 32-bit)
-static bool rows_geometry(long long n, long long row_len, RowGeom* g) {
+// plane_rows: rows per grid plane (0 / >= R: one plane — blocks of 16 consecutive rows throughout);
+// plane_phase: index within its plane of the first row. Both are layout hints like row_len: they only decide which
+// 16 rows form a block (a block of rows from two planes has a bounding sphere as wide as the grid and culls nothing).
+static bool rows_geometry(long long n, long long row_len, RowGeom* g, long long plane_rows = 0, long long plane_phase = 0) {
     if (row_len < 32 || row_len > 0x7fffffffLL || n <= 0 || n % row_len != 0) return false;
     const long long R = n / row_len, brows = 16;
     // windows of 32 points aligned in the flat array: one more than ceil(L / 32) can overlap a row
     const long long nchunk = (row_len % 32 == 0) ? row_len / 32 : (row_len + 62) / 32;
-    const long long nb = nchunk * ((R + brows - 1) / brows);
+    long long prow = plane_rows, seg0 = 0;
+    if (prow <= 0 || prow >= R || prow > 0x7fffffffLL) {
+        prow = R > 0x7fffffffLL ? 0 : R;                       // one plane
+        if (prow == 0) return false;
+    } else if (plane_phase > 0) {
+        seg0 = std::min(R, (prow - plane_phase % prow) % prow);
+    }
+    const long long nb0 = (seg0 + brows - 1) / brows, bpp = (prow + brows - 1) / brows;
+    const long long planes = (R - seg0 + prow - 1) / prow;
+    const long long nb = nchunk * (nb0 + planes * bpp);
     if (nb > 0x7fffffffLL - 1024) return false;
     g->L = (unsigned)row_len;
     g->nchunk = (unsigned)nchunk;
@@ -587,6 +605,10 @@ static bool rows_geometry(long long n, long long row_len, RowGeom* g) {
     g->R = R;
     g->row0 = 0;
     g->yrows = 0;
+    g->prow = (unsigned)prow;
+    g->seg0 = (unsigned)seg0;
+    g->nb0 = (unsigned)nb0;
+    g->bpp = (unsigned)bpp;
     return true;
 }
 static int tile_threads() { return 64 * tile_waves(); }
@@ -794,9 +816,110 @@ static int rtc_compile_uncached(const std::string& src, std::vector<char>* out, 
     hiprtcDestroyProgram(&prog);
     return 0;
 }
+// ---- hiprtc in a child process (background builds) -------------------------------------------------------------------
+// hiprtcCompileProgram holds comgr's process-wide mutex for the whole build; a dlopen of any library with HIP fat
+// binaries on another thread of the same process (`import torch`) deadlocks against it — loader lock -> comgr mutex there,
+// comgr mutex -> loader lock here (profiles/r03_hang_import_during_build.txt). Builds that run BESIDE the caller
+// therefore run in aegolius_amd/sdfk_rtc_helper (csrc/sdfk_rtc_helper.c): no GPU, no shared lock. Builds the caller
+// waits for stay in-process (the caller cannot dlopen while it waits). No helper next to the library: no background
+// builds — the call waits.
+extern char** environ;
+static std::string rtc_helper_path() {
+    static const std::string path = [] {
+        if (const char* e = getenv("SDFK_RTC_HELPER")) return std::string(strcmp(e, "off") && strcmp(e, "0") ? e : "");
+        Dl_info info;
+        if (!dladdr((void*)&sdfk_abi_version, &info) || !info.dli_fname) return std::string();
+        std::string p = info.dli_fname;
+        const size_t slash = p.rfind('/');
+        p = (slash == std::string::npos ? std::string(".") : p.substr(0, slash)) + "/sdfk_rtc_helper";
+        return access(p.c_str(), X_OK) == 0 ? p : std::string();
+    }();
+    return path;
+}
+static std::string rtc_library_path() {                        // the hiprtc THIS process uses (torch's or the system's)
+    Dl_info info;
+    if (!dladdr((void*)&hiprtcCompileProgram, &info) || !info.dli_fname) return std::string();
+    return info.dli_fname;
+}
+static bool rtc_helper_available() { return !rtc_helper_path().empty() && !rtc_library_path().empty(); }
+static int rtc_compile_external(const std::string& src, std::vector<char>* out, std::string* log, int rwb) {
+    static std::atomic<unsigned> serial{0};
+    const std::string helper = rtc_helper_path(), lib = rtc_library_path();
+    if (helper.empty() || lib.empty()) {
+        *log = "sdfk_rtc_helper is not available";
+        return -2;
+    }
+    std::string dir = rtc_cache_dir();
+    if (dir.empty()) {
+        const char* t = getenv("TMPDIR");
+        dir = (t && *t) ? t : "/tmp";
+    }
+    char stem[128];
+    snprintf(stem, sizeof stem, "/sdfk-rtc-%ld-%u", (long)getpid(), serial.fetch_add(1));
+    const std::string srcf = dir + stem + ".hip", outf = dir + stem + ".co";
+    auto cleanup = [&] {
+        (void)remove(srcf.c_str());
+        (void)remove(outf.c_str());
+        (void)remove((outf + ".tmp").c_str());
+        (void)remove((outf + ".log").c_str());
+    };
+    {
+        FILE* f = fopen(srcf.c_str(), "wb");
+        const bool ok = f && fwrite(src.data(), 1, src.size(), f) == src.size();
+        if (!f || fclose(f) != 0 || !ok) {
+            cleanup();
+            *log = "cannot write " + srcf;
+            return -2;
+        }
+    }
+    const std::vector<std::string> o = rtc_options(rwb);
+    std::vector<char*> argv = {const_cast<char*>(helper.c_str()), const_cast<char*>(lib.c_str()), const_cast<char*>(srcf.c_str()),
+                               const_cast<char*>(outf.c_str())};
+    for (const std::string& x : o) argv.push_back(const_cast<char*>(x.c_str()));
+    argv.push_back(nullptr);
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_addclosefrom_np(&fa, 3);          // the child inherits nothing of the GPU runtime's
+    pid_t pid = 0;
+    const int rc = posix_spawn(&pid, helper.c_str(), &fa, nullptr, argv.data(), environ);
+    posix_spawn_file_actions_destroy(&fa);
+    if (rc != 0) {
+        cleanup();
+        *log = std::string("posix_spawn of sdfk_rtc_helper: ") + strerror(rc);
+        return -2;
+    }
+    int status = 0;
+    while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {
+    }
+    int result = -1;
+    if (WIFEXITED(status) && WEXITSTATUS(status) == 0) {
+        FILE* f = fopen(outf.c_str(), "rb");
+        if (f && fseek(f, 0, SEEK_END) == 0) {
+            const long size = ftell(f);
+            if (size > 0 && fseek(f, 0, SEEK_SET) == 0) {
+                out->resize((size_t)size);
+                if (fread(out->data(), 1, (size_t)size, f) == (size_t)size) result = 0;
+            }
+        }
+        if (f) fclose(f);
+        if (result) *log = "sdfk_rtc_helper left no code object";
+    } else {
+        *log = "sdfk_rtc_helper failed (status " + std::to_string(status) + ")";
+        if (FILE* f = fopen((outf + ".log").c_str(), "rb")) {
+            char buf[8192];
+            const size_t n = fread(buf, 1, sizeof buf - 1, f);
+            buf[n] = 0;
+            *log += std::string(": ") + buf;
+            fclose(f);
+        }
+    }
+    cleanup();
+    return result;
+}
+
 // *from_disk (optional): the code object came from the on-disk cache
 static int rtc_compile(const std::string& src, std::vector<char>* out, std::string* log, int rwb, bool* from_disk = nullptr,
-                       std::string* disk_path = nullptr) {
+                       std::string* disk_path = nullptr, bool external = false) {
     if (from_disk) *from_disk = false;
     const std::string path = rtc_cache_path(src, rtc_option_key(rwb));
     if (rtc_cache_read(path, out)) {
@@ -805,7 +928,9 @@ static int rtc_compile(const std::string& src, std::vector<char>* out, std::stri
         return 0;
     }
     int rc;
-    {
+    if (external) {
+        rc = rtc_compile_external(src, out, log, rwb);         // (a background build: never hiprtc inside this process)
+    } else {
         std::lock_guard<std::mutex> lk(g_rtc_mu);
         rc = rtc_compile_uncached(src, out, log, rwb);
     }
@@ -823,15 +948,18 @@ static const char* const kFlavourFn[SDFK_FL_COUNT][2] = {
 // g_rtc_mu. Background builds are queued to one worker thread, which is drained before the interpreter / the
 // library's statics (and with them hiprtc) go away: sdfk_jit_drain (Python: atexit) and the destructor below.
 struct BuildWorker {
+    static constexpr int kThreads = 2;                       // compiler processes that may run side by side
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::function<void()>> jobs;
-    std::thread thread;
-    bool stop = false, busy = false;
+    std::vector<std::thread> threads;
+    bool stop = false;
+    int busy = 0;
     void post(std::function<void()> job) {
         std::lock_guard<std::mutex> lk(mu);
         jobs.push_back(std::move(job));
-        if (!thread.joinable()) thread = std::thread([this] { loop(); });
+        if ((int)threads.size() < kThreads && (int)threads.size() < busy + (int)jobs.size())
+            threads.emplace_back([this] { loop(); });
         cv.notify_all();
     }
     void loop() {
@@ -841,17 +969,17 @@ struct BuildWorker {
             if (jobs.empty()) return;                        // (stop: the queue is finished first)
             std::function<void()> job = std::move(jobs.front());
             jobs.pop_front();
-            busy = true;
+            ++busy;
             lk.unlock();
             job();
             lk.lock();
-            busy = false;
+            --busy;
             cv.notify_all();
         }
     }
     void drain() {                                           // wait until nothing is queued or running
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [this] { return jobs.empty() && !busy; });
+        cv.wait(lk, [this] { return jobs.empty() && busy == 0; });
     }
     ~BuildWorker() {
         {
@@ -859,7 +987,8 @@ struct BuildWorker {
             stop = true;
             cv.notify_all();
         }
-        if (thread.joinable()) thread.join();
+        for (std::thread& t : threads)
+            if (t.joinable()) t.join();
     }
 };
 static BuildWorker g_builds;
@@ -878,13 +1007,13 @@ static std::shared_ptr<CodeObject> code_entry(const std::string& key) {
     return e;
 }
 // run one build; the caller has moved the entry to state 1
-static void code_build(const std::shared_ptr<CodeObject>& e, const std::string& src, int rwb) {
+static void code_build(const std::shared_ptr<CodeObject>& e, const std::string& src, int rwb, bool external = false) {
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<char> co;
     std::string log;
     bool from_disk = false;
     std::string disk_path;
-    const int rc = rtc_compile(src, &co, &log, rwb, &from_disk, &disk_path);
+    const int rc = rtc_compile(src, &co, &log, rwb, &from_disk, &disk_path, external);
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (!from_disk) {
         g_compile_count++;
@@ -914,10 +1043,10 @@ static std::shared_ptr<CodeObject> code_get(const std::string& key, MakeSource m
         e->state = 1;
         lk.unlock();
         const std::string src = make_source();                 // (the program may be gone before a background build ends)
-        if (wait) {
+        if (wait || !rtc_helper_available()) {                 // no compiler process to hand the build to: the caller waits
             code_build(e, src, rwb);
         } else {
-            g_builds.post([e, src, rwb] { code_build(e, src, rwb); });
+            g_builds.post([e, src, rwb] { code_build(e, src, rwb, true); });
         }
         return e;
     }
@@ -957,6 +1086,20 @@ extern "C" int sdfk_program_compile_flavour(sdfk_program* p, int flavour, size_t
     if (e->state != 2) return fail(-3, e->error);
     if (code_size) *code_size = e->co.size();
     if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+/* Test aid: build one flavour in the compiler child process (what a background build does), GPU or not. */
+extern "C" int sdfk_debug_compile_external(sdfk_program* p, int flavour, size_t* code_size) {
+    if (!p) return fail(-1, "null program");
+    if (flavour < 0 || flavour >= SDFK_FL_COUNT) return fail(-1, "sdfk_debug_compile_external: unknown flavour");
+    if (p->sites.empty() && flavour != SDFK_FL_PLAIN_ARRAY && flavour != SDFK_FL_PLAIN_GRID)
+        return fail(-2, "sdfk_debug_compile_external: the program has no cull sites");
+    if (!rtc_helper_available()) return fail(-9, "sdfk_rtc_helper is not next to libsdfk.so (or hiprtc cannot be located)");
+    std::vector<char> co;
+    std::string log;
+    if (rtc_compile_external(flavour_source(p, flavour), &co, &log, rows_geo(p)) != 0) return fail(-3, log);
+    if (code_size) *code_size = co.size();
     return 0;
 }
 
@@ -1074,7 +1217,7 @@ static inline unsigned blocks_for(long long n, int vec) {
 // flat: the caller states that the rows of the array are rows of a flat grid (z = 0, rows along y); grids know it
 static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long long n, float* d_out, void* stream_,
                int mode, bool vec_ok, long long row_len = 0, const float* aux = nullptr, long long aux_stride = 0,
-               bool flat = false) {
+               bool flat = false, long long plane_rows = 0, long long plane_phase = 0) {
     if (!p) return fail(-1, "null program");
     if (n < 0) return fail(-1, "negative point count");
     if (p->n_aux > 0 && (!aux || aux_stride < n))
@@ -1107,9 +1250,12 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
     int flavour = arr ? SDFK_FL_PLAIN_ARRAY : SDFK_FL_PLAIN_GRID;
     const long long grow = grid ? (grid->n2 > 1 ? (long long)grid->n2 : (long long)grid->n1) : 0;
     if (!p->sites.empty() && mode != SDFK_MODE_NOCULL && mode != SDFK_MODE_INTERPRET) {
-        if (arr && rows_geometry(n, row_len, &rg)) flavour = flat ? SDFK_FL_ROWS2D_ARRAY : SDFK_FL_ROWS_ARRAY;   // rows need no alignment beyond 4 bytes
+        if (arr && rows_geometry(n, row_len, &rg, flat ? 0 : plane_rows, plane_phase))
+            flavour = flat ? SDFK_FL_ROWS2D_ARRAY : SDFK_FL_ROWS_ARRAY;   // rows need no alignment beyond 4 bytes
         else if (arr && vec_ok) flavour = SDFK_FL_TILE_ARRAY;
-        else if (grid && grid->start % grow == 0 && rows_geometry(n, grow, &rg))
+        else if (grid && grid->start % grow == 0 &&
+                 rows_geometry(n, grow, &rg, grid->n2 > 1 ? (long long)grid->n1 : 0,
+                               grid->n2 > 1 ? (grid->start / grow) % (long long)grid->n1 : 0))
             flavour = grid->n2 > 1 ? SDFK_FL_ROWS_GRID : SDFK_FL_ROWS2D_GRID;
         else if (grid && vec_ok) flavour = SDFK_FL_TILE_GRID;
     }
@@ -1255,6 +1401,19 @@ extern "C" int sdfk_eval_device_rows(sdfk_program* p, const float* d_co, int64_t
     SrcArray a = {d_co, (long long)row_stride};
     bool vec_ok = aligned16(d_co) && aligned16(d_out) && (row_stride % 4 == 0);
     return run(p, &a, nullptr, n, d_out, stream, mode, vec_ok, row_len);
+}
+
+extern "C" int sdfk_eval_device_rows3d(sdfk_program* p, const float* d_co, int64_t n, int64_t row_stride, int64_t row_len,
+                                       int64_t plane_rows, int64_t first_row_in_plane, float* d_out, void* stream, int mode) {
+    if (!d_co || !d_out) return fail(-1, "sdfk_eval_device_rows3d: null device pointer");
+    if (row_stride < n) return fail(-1, "sdfk_eval_device_rows3d: row stride smaller than the point count");
+    if (row_len < 1 || (n > 0 && n % row_len != 0))
+        return fail(-1, "sdfk_eval_device_rows3d: the point count is not a multiple of the row length");
+    if (plane_rows < 0 || first_row_in_plane < 0 || (plane_rows > 0 && first_row_in_plane >= plane_rows))
+        return fail(-1, "sdfk_eval_device_rows3d: plane_rows >= 0 and 0 <= first_row_in_plane < plane_rows");
+    SrcArray a = {d_co, (long long)row_stride};
+    bool vec_ok = aligned16(d_co) && aligned16(d_out) && (row_stride % 4 == 0);
+    return run(p, &a, nullptr, n, d_out, stream, mode, vec_ok, row_len, nullptr, 0, false, plane_rows, first_row_in_plane);
 }
 
 extern "C" int sdfk_eval_device_rows2d(sdfk_program* p, const float* d_co, int64_t n, int64_t row_stride, int64_t row_len,
@@ -1491,16 +1650,20 @@ extern "C" int sdfk_grid_fill(float* d_co, int64_t row_stride, const float* ax0,
 // changes (3-D grids: rows along z) or, failing that, at which x first changes (2-D grids: rows along y).
 // Only a layout hint for the row-block kernel — a wrong guess costs speed, never correctness.
 template <typename T>
-static int64_t detect_row_len(const T* co, int64_t n, int64_t stride, bool* flat) {
+static int64_t detect_row_len(const T* co, int64_t n, int64_t stride, bool* flat, int64_t* plane_rows) {
     const int64_t scan = std::min<int64_t>(n, (int64_t)1 << 22);
     const T *x = co, *y = co + stride, *z = co + 2 * stride;
     int64_t a = 0, b = 0;
     *flat = false;
+    *plane_rows = 0;
     for (int64_t i = 1; i < scan && (!a || !b); ++i) {
         if (!b && x[i] != x[0]) b = i;
         if (!a && (x[i] != x[0] || y[i] != y[0])) a = i;
     }
-    if (a >= 32 && n % a == 0) return a;
+    if (a >= 32 && n % a == 0) {
+        if (b > a && b % a == 0) *plane_rows = b / a;            // x first changes after b / a rows: one grid plane
+        return a;
+    }
     if (b >= 32 && n % b == 0) {
         *flat = z[0] == (T)0 && z[b - 1] == (T)0 && z[n - 1] == (T)0;   // (a hint: the kernel checks every point it reads)
         return b;
@@ -1594,9 +1757,10 @@ static int eval_host_impl(sdfk_program* p, const void* co, int co_dtype, int64_t
     }();
     int64_t chunk = std::min<int64_t>(n, max_chunk);
     bool flat = false;
+    int64_t plane_rows = 0;
     const int64_t row_len = p->sites.empty() ? 0
-                            : co_dtype == 0 ? detect_row_len(static_cast<const float*>(co), n, row_stride, &flat)
-                                            : detect_row_len(static_cast<const double*>(co), n, row_stride, &flat);
+                            : co_dtype == 0 ? detect_row_len(static_cast<const float*>(co), n, row_stride, &flat, &plane_rows)
+                                            : detect_row_len(static_cast<const double*>(co), n, row_stride, &flat, &plane_rows);
     if (row_len > 0 && chunk > row_len) chunk = chunk / row_len * row_len;   // whole rows per chunk
     const int64_t stride = (chunk + 63) & ~(int64_t)63;
     HostStage* st = stage_of(device);
@@ -1643,7 +1807,8 @@ static int eval_host_impl(sdfk_program* p, const void* co, int co_dtype, int64_t
         if (rc == 0)
             rc = !(row_len > 0 && m % row_len == 0) ? sdfk_eval_device(p, sl.d_co, m, stride, sl.d_out, sl.stream, mode)
                  : flat                             ? sdfk_eval_device_rows2d(p, sl.d_co, m, stride, row_len, sl.d_out, sl.stream, mode)
-                                                    : sdfk_eval_device_rows(p, sl.d_co, m, stride, row_len, sl.d_out, sl.stream, mode);
+                 : sdfk_eval_device_rows3d(p, sl.d_co, m, stride, row_len, plane_rows,
+                                           plane_rows > 0 ? (s / row_len) % plane_rows : 0, sl.d_out, sl.stream, mode);
         if (rc == 0) {
             const hipError_t e = out_on_device
                                      ? hipMemcpyAsync(out + s, sl.d_out, (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, sl.stream)

@@ -404,7 +404,21 @@ struct sdfk_rowgeom {
     long long R;                                // rows
     long long row0;                             // grid flavour: global row index of the first row of the slab
     int yrows;                                  // grid flavour, 2-D grid (n2 == 1): rows run along the second axis
-};
+    unsigned prow, seg0, nb0, bpp;              // planes of prow rows after a first partial plane of seg0 rows (nb0 blocks);
+};                                              // bpp blocks per plane: a block never holds rows of two planes
+// rows [r0, rend) of row block rb (wave-uniform): 16 consecutive rows of ONE plane, fewer at the end of a plane
+static __device__ __forceinline__ void sdfk_block_rows(const sdfk_rowgeom& g, unsigned rb, long long& r0, long long& rend) {
+    if (rb < g.nb0) {
+        r0 = (long long)rb * SDFK_RROWS;
+        rend = g.seg0;
+    } else {
+        const unsigned k = rb - g.nb0;
+        const unsigned pl = __builtin_amdgcn_readfirstlane(k / g.bpp);
+        const long long base = (long long)g.seg0 + (long long)pl * g.prow;
+        r0 = base + (long long)(k - pl * g.bpp) * SDFK_RROWS;
+        rend = base + g.prow < g.R ? base + g.prow : g.R;
+    }
+}
 
 // Rows are cut into WINDOWS of 32 points that are aligned in the flat array (128-byte lines when the array is):
 // window k of a row starts at flat index 32 * (floor(row * L / 32) + k), i.e. up to 31 points before the row
@@ -469,8 +483,8 @@ struct sdfk_rowregs {
     float4 X[SDFK_RLOADS], Y[SDFK_RLOADS], Z[SDFK_RLOADS];
 };
 template <typename SRC>
-static __device__ __forceinline__ void sdfk_rows_load(const SRC& s, const sdfk_rowgeom& g, long long r0, unsigned k, int lane,
-                                                      sdfk_rowregs& r) {
+static __device__ __forceinline__ void sdfk_rows_load(const SRC& s, const sdfk_rowgeom& g, long long r0, long long rend,
+                                                      unsigned k, int lane, sdfk_rowregs& r) {
     // SDFK_FLAT (flat grids: rows run along y, z = 0 everywhere): the roles of y and z are swapped from here to the
     // end of phase A — r.Y holds z (the coordinate a row shares, which must be exactly 0) and r.Z holds y (the one
     // that varies along the row) — so that "uniform", the staging and the bounding sphere work unchanged
@@ -478,7 +492,7 @@ static __device__ __forceinline__ void sdfk_rows_load(const SRC& s, const sdfk_r
 #pragma unroll
     for (int t = 0; t < SDFK_RLOADS; ++t) {
         int dr = 8 * t + (lane >> 3);
-        if (r0 + dr >= g.R) dr = (int)(g.R - 1 - r0);
+        if (r0 + dr >= rend) dr = (int)(rend - 1 - r0);
         long long flat;
         const int z = sdfk_win_z(r0 + dr, g.L, k, 4 * (lane & 7), &flat);
         #ifdef SDFK_FLAT
@@ -558,25 +572,35 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
     // two bricks per wave: all of the wave's loads are in flight before the first one is used (-0.8 % together with
     // two-wave workgroups on the north-star grid; with four bricks per wave the registers this takes cost more)
     sdfk_rowregs hregs[SDFK_RWBRICKS];
+    bool live[SDFK_RWBRICKS];
 #pragma unroll
     for (int j = 0; j < SDFK_RWBRICKS; ++j) {
-        if (q0 + j < g.nbricks) sdfk_rows_load(s, g, (long long)rb * SDFK_RROWS, c, lane, hregs[j]);
+        long long r0, rend;
+        sdfk_block_rows(g, rb, r0, rend);
+        live[j] = q0 + j < g.nbricks && r0 < rend;               // (blocks of the last plane beyond the slab: nothing)
+        if (live[j]) sdfk_rows_load(s, g, r0, rend, c, lane, hregs[j]);
         if (++c == g.nchunk) { c = 0; ++rb; }
     }
 #pragma unroll
     for (int j = 0; j < SDFK_RWBRICKS; ++j)
-        if (q0 + j < g.nbricks) sdfk_rows_bounds(hregs[j], lane, meta, wave * SDFK_RWBRICKS + j);
+        if (live[j]) sdfk_rows_bounds(hregs[j], lane, meta, wave * SDFK_RWBRICKS + j);
+        else if (lane == 0) { meta->bound[wave * SDFK_RWBRICKS + j] = make_float4(0.0f, 0.0f, 0.0f, 1.0f); meta->uniform[wave * SDFK_RWBRICKS + j] = 0u; }
 #else
 #pragma unroll
     for (int j = 0; j < SDFK_RWBRICKS; ++j) {
+        long long r0, rend;
+        sdfk_block_rows(g, rb, r0, rend);
 #ifdef SDFK_ABLATE_EDGE
-        if (q0 + j < g.nbricks && sdfk_interior(g.L, c)) {
+        if (q0 + j < g.nbricks && r0 < rend && sdfk_interior(g.L, c)) {
 #else
-        if (q0 + j < g.nbricks) {
+        if (q0 + j < g.nbricks && r0 < rend) {
 #endif
             sdfk_rowregs regs;
-            sdfk_rows_load(s, g, (long long)rb * SDFK_RROWS, c, lane, regs);
+            sdfk_rows_load(s, g, r0, rend, c, lane, regs);
             sdfk_rows_bounds(regs, lane, meta, wave * SDFK_RWBRICKS + j);
+        } else if (lane == 0) {                                   // a dead brick still meets a probe lane: harmless values
+            meta->bound[wave * SDFK_RWBRICKS + j] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+            meta->uniform[wave * SDFK_RWBRICKS + j] = 0u;
         }
         if (++c == g.nchunk) { c = 0; ++rb; }
     }
@@ -631,8 +655,10 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
         if (q0 + j >= g.nbricks) break;
         const int b = wave * SDFK_RWBRICKS + j;
         const unsigned k = c;
-        const long long r0 = (long long)rb * SDFK_RROWS;
+        long long r0, rend;
+        sdfk_block_rows(g, rb, r0, rend);
         if (++c == g.nchunk) { c = 0; ++rb; }
+        if (r0 >= rend) continue;
         const unsigned long long m0 = meta.mask0[b], m1 = meta.mask1[b];
         const unsigned w0 = __builtin_amdgcn_readfirstlane((unsigned)m0), w1 = __builtin_amdgcn_readfirstlane((unsigned)(m0 >> 32));
         const unsigned w2 = __builtin_amdgcn_readfirstlane((unsigned)m1), w3 = __builtin_amdgcn_readfirstlane((unsigned)(m1 >> 32));
@@ -641,8 +667,8 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
 #ifdef SDFK_ABLATE_EDGE
         if (!interior) continue;
 #endif
-        const bool live_row = r0 + lr < g.R;
-        const int dr = live_row ? lr : (int)(g.R - 1 - r0);
+        const bool live_row = r0 + lr < rend;
+        const int dr = live_row ? lr : (int)(rend - 1 - r0);
         long long f;                                              // flat index of this lane's first point
         const int z = sdfk_win_z(r0 + dr, g.L, k, zq, &f);        // its index in the row (edge chunks: may lie outside)
         const int last = (int)g.L - 1;

@@ -186,12 +186,15 @@ class Run:
         self.out = torch.empty((self.stride,), dtype=torch.float32, device=dev)
         self.stream = torch.cuda.current_stream().cuda_stream
         self.use_rows = use_rows
+        self.no_planes = os.environ.get("SDFK_BENCH_NO_PLANES") == "1"      # A/B: blocks of 16 rows regardless of planes
         engine.grid_fill(self.co.data_ptr(), self.stride, axes, self.start, self.count, stream=self.stream)
 
     def step(self):
+        flat = self.axes[2].size == 1
         self.prog.eval_device(self.co.data_ptr(), self.count, self.stride, self.out.data_ptr(), stream=self.stream,
-                              mode=self.mode, row_len=self.row_len if self.use_rows else None,
-                              flat=self.axes[2].size == 1)
+                              mode=self.mode, row_len=self.row_len if self.use_rows else None, flat=flat,
+                              plane_rows=None if flat or self.no_planes else int(self.axes[1].size),
+                              first_row_in_plane=0 if flat else (self.start // self.row_len) % int(self.axes[1].size))
 
     def fence(self):
         self.torch.cuda.synchronize()
@@ -635,8 +638,11 @@ def main():
     if world > 1 and not args.no_allgather and not args.no_extras:
         def evaluate_chunk(cstart, ccount, out_view):
             off = cstart - start
+            flat = axes[2].size == 1
             prog.eval_device(run.co.data_ptr() + 4 * off, ccount, stride, out_view.data_ptr(), stream=stream, mode=mode,
-                             row_len=row_len if not args.no_rows else None, flat=axes[2].size == 1)
+                             row_len=row_len if not args.no_rows else None, flat=flat,
+                             plane_rows=None if flat else int(axes[1].size),
+                             first_row_in_plane=0 if flat else (cstart // row_len) % int(axes[1].size))
         extra("allgather", lambda: reassembly_legs(torch, dist, sdist, run.out[:count], n_total, start, count, row_len,
                                                    evaluate_chunk, run.fence, red_dev, elapsed / args.steps))
 

@@ -84,6 +84,12 @@ int sdfk_program_compile_check(sdfk_program* prog, size_t* code_size);
 #define SDFK_FLAVOUR_ROWS2D_GRID 9
 /* Build (or fetch from the caches) ONE flavour, GPU or not: its code-object size and the seconds this call took. */
 int sdfk_program_compile_flavour(sdfk_program* prog, int flavour, size_t* code_size, double* seconds);
+/* Test aid: build one flavour the way BACKGROUND builds are run — in a child process (aegolius_amd/sdfk_rtc_helper,
+ * csrc/sdfk_rtc_helper.c) — and return the code-object size; nothing is cached. While the interpreter kernel serves the
+ * first calls of a new tree shape (SDFK_MODE_AUTO) the compiler never runs inside the calling process: hiprtc holds a
+ * process-wide lock of its compiler library for the whole build, against which a dlopen of any HIP library on another
+ * thread deadlocks. Without the helper next to the library there are no background builds: the first call waits. */
+int sdfk_debug_compile_external(sdfk_program* prog, int flavour, size_t* code_size);
 /* Wait until no background kernel build is queued or running (call before the process tears hiprtc down: the Python
  * layer registers it with atexit). */
 void sdfk_jit_drain(void);
@@ -108,6 +114,13 @@ int sdfk_eval_device(sdfk_program* prog, const float* d_co, int64_t n, int64_t r
  * one y per row" test and every skip decision are derived from the coordinates actually read). */
 int sdfk_eval_device_rows(sdfk_program* prog, const float* d_co, int64_t n, int64_t row_stride, int64_t row_len,
                           float* d_out, void* stream, int mode);
+/* The same with the second layout hint of a 3-D grid: the rows come in PLANES of plane_rows rows (the second grid
+ * dimension; rows of one plane share x) and the first row of the array is row first_row_in_plane of its plane
+ * (0 for a whole grid, anything for an x-slab of whole rows). Row blocks then never straddle two planes — such a
+ * block spans the whole y extent of the grid and culls nothing (1 block in 32 at 513^3). plane_rows = 0: unknown
+ * (= sdfk_eval_device_rows). Hints only: the field is bit-identical for any values. */
+int sdfk_eval_device_rows3d(sdfk_program* prog, const float* d_co, int64_t n, int64_t row_stride, int64_t row_len,
+                            int64_t plane_rows, int64_t first_row_in_plane, float* d_out, void* stream, int mode);
 /* The same for the array of a FLAT grid (generate_grid with two sizes, cores/helper_functions.py:63-75: rows run
  * along y, row_len = the second grid dimension, the z row is all zeros): the kernel is built so that the x part of
  * every root transform is computed once per row. Again a hint only — bricks whose z is not exactly 0 or whose x

@@ -190,7 +190,8 @@ def test_empty_and_ragged_inputs(engine):
         tree.create(np.zeros((2, 10)))
 
 
-def _device_eval(engine, prog, co32, n, stride, misalign=0, mode=None, row_len=None, flat=False):
+def _device_eval(engine, prog, co32, n, stride, misalign=0, mode=None, row_len=None, flat=False, plane_rows=None,
+                 first_row_in_plane=0):
     """eval_device on raw HIP buffers (optionally shifted by `misalign` floats to defeat 16-B alignment)."""
     lib = engine.lib()
     d_co = lib.sdfk_malloc((3 * stride + misalign + 4) * 4)
@@ -201,7 +202,8 @@ def _device_eval(engine, prog, co32, n, stride, misalign=0, mode=None, row_len=N
         engine.check(lib.sdfk_memcpy_h2d(ctypes.c_void_p(d_co + 4 * misalign), host.ctypes.data_as(ctypes.c_void_p),
                                          host.nbytes), "h2d")
         prog.eval_device(d_co + 4 * misalign, n, stride, d_out + 4 * misalign,
-                         mode=engine.MODE_SPECIALIZED if mode is None else mode, row_len=row_len, flat=flat)
+                         mode=engine.MODE_SPECIALIZED if mode is None else mode, row_len=row_len, flat=flat,
+                         plane_rows=plane_rows, first_row_in_plane=first_row_in_plane)
         engine.check(lib.sdfk_sync(None), "sync")
         out = np.empty(n, dtype=np.float32)
         engine.check(lib.sdfk_memcpy_d2h(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_out + 4 * misalign),
@@ -455,6 +457,20 @@ def test_row_block_culling_is_bit_exact(name, engine):
         plain = _device_eval(engine, prog, co32, n, stride, mis, engine.MODE_NOCULL)
         rows = _device_eval(engine, prog, co32, n, stride, mis, engine.MODE_SPECIALIZED, row_len=row_len)
         np.testing.assert_array_equal(rows, plain)
+        if "2d" not in name:
+            # the plane hint (row blocks never straddle two x-planes): the true plane height, slabs that start
+            # anywhere inside a plane, and values that have nothing to do with the data
+            p_rows = shape[1]
+            for plane_rows, first in ((p_rows, 0), (7, 3), (1, 0), (16, 15), (10 ** 6, 5)):
+                got = _device_eval(engine, prog, co32, n, stride, mis, engine.MODE_SPECIALIZED, row_len=row_len,
+                                   plane_rows=plane_rows, first_row_in_plane=first)
+                np.testing.assert_array_equal(got, plain)
+            r_first = p_rows + 3 if shape[0] > 2 else 1                   # a slab of whole rows from mid-plane
+            sl = slice(r_first * row_len, n - 2 * row_len)
+            m = sl.stop - sl.start
+            got = _device_eval(engine, prog, co32[:, sl], m, m + 3, mis, engine.MODE_SPECIALIZED, row_len=row_len,
+                               plane_rows=p_rows, first_row_in_plane=r_first % p_rows)
+            np.testing.assert_array_equal(got, plain[sl])
         # the kernel built for flat grids (x shared by a row, z = 0): on the 2-D scenes its fast path, on the 3-D
         # ones (z is not 0, x and y change along "rows") every brick must fall back to the general path
         flat = _device_eval(engine, prog, co32, n, stride, mis, engine.MODE_SPECIALIZED, row_len=row_len, flat=True)
@@ -1044,3 +1060,34 @@ def test_concurrent_first_use_of_new_tree_shapes(engine, golden_inputs):
     aegolius_amd.config.mode = engine.MODE_SPECIALIZED
     for k, tree in enumerate(trees):
         np.testing.assert_array_equal(tree.create(co), first[k])
+
+
+_IMPORT_DURING_BUILD = """
+import os, sys, time
+sys.path.insert(0, {root!r})
+import aegolius_amd.cores as ns
+from aegolius_amd import _engine, workloads
+co, _ = ns.generate_grid((3, 3, 3), (64, 64, 64))
+tree = workloads.cfg5_tree(ns)
+first = tree.create(co)                       # AUTO: interpreter kernel now, the specialised kernel builds beside us
+assert "torch" not in sys.modules
+import torch                                  # dlopen of a dozen HIP libraries while the build is in flight
+_engine.lib().sdfk_jit_drain()
+import numpy as np
+assert np.array_equal(tree.create(co), first)
+print("builds", _engine.jit_stats()[0])
+"""
+
+
+def test_importing_a_hip_library_during_a_background_build_does_not_deadlock(engine, tmp_path):
+    """The round-2 "hang inside ROCm", reproduced 6 times out of 6 in round 3 (profiles/r03_hang_import_during_build.txt):
+    hiprtc inside the process holds comgr's global mutex while `import torch` on the main thread runs HIP fat-binary
+    registration under the loader lock. Background builds now run in a child process; this is the reproducer."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SDFK_CACHE_DIR="off")
+    res = subprocess.run([sys.executable, "-c", _IMPORT_DURING_BUILD.format(root=root)], env=env, capture_output=True,
+                         text=True, timeout=240)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "builds 1" in res.stdout

@@ -289,3 +289,22 @@ def test_on_disk_cache_is_size_capped(built, tmp_path):
     total = sum(p.stat().st_size for p in tmp_path.iterdir())
     assert total <= (1 << 20) and any(not n.endswith("-1.co") for n in left)          # the new object stayed
     assert "sdfk-%016x-1.co" % 0 not in left                                         # the oldest went first
+
+
+def test_background_builds_run_in_a_compiler_process(built):
+    """What a background build does (sdfk_rtc_helper: hiprtc in a child process, never inside the caller — see
+    profiles/r03_hang_import_during_build.txt) yields the same code object as the in-process build."""
+    import ctypes
+    import aegolius_amd.cores as ns
+    from aegolius_amd import workloads
+    from aegolius_amd._lower import lower_geometry
+    assert os.access(os.path.join(os.path.dirname(built.LIB_PATH), "sdfk_rtc_helper"), os.X_OK)
+    prog = built.Program.from_lowered(lower_geometry(workloads.cfg2_tree(ns, seed=77)))
+    n = ctypes.c_size_t(0)
+    built.check(built.lib().sdfk_debug_compile_external(prog.handle, built.FLAVOUR_ROWS_ARRAY, ctypes.byref(n)), "external")
+    inproc, _seconds = prog.compile_flavour(built.FLAVOUR_ROWS_ARRAY)
+    assert n.value == inproc > 10000
+    # a source that does not compile: the helper's log comes back as the error
+    bad = built.Program.from_lowered(lower_geometry(ns.Sphere(0.5)))
+    rc = built.lib().sdfk_debug_compile_external(bad.handle, built.FLAVOUR_ROWS_ARRAY, ctypes.byref(n))
+    assert rc == -2 and "no cull sites" in built.last_error()

@@ -20,7 +20,7 @@ def main(workload="cfg4", grid="4096"):
     from aegolius_amd.cores.helper_functions import grid_axes
     lib = _engine.lib()
     _engine.require_gpu()
-    geo, size, desc = bench.build_workload(workload, ns, scenes)
+    geo, size, desc = bench.build_workload(workload, ns)
     low = lower_geometry(geo)
     prog = _engine.Program.from_lowered(low)
     axes = [a.astype(np.float32) for a in grid_axes(size, (int(grid),) * len(size))[0]]

@@ -3,7 +3,7 @@
     python tools/rows_ab.py [--workload cfg2] [--grid 1024] [--reps 10] VARIANT [VARIANT ...]
 
 A VARIANT is a string of -D switches for the generated source ("" = the shipped kernel), optionally prefixed by
-`mode=nocull:` / `mode=interpret:` / `norows:`; every variant is built as its own code object
+`mode=nocull:` / `mode=interpret:` / `norows:` / `noplanes:`; every variant is built as its own code object
 (sdfk_debug_set_rtc_defs), timed with HIP events on the launch stream, and — unless it contains ABLATE — compared
 bit for bit with the un-culled kernel's field."""
 import argparse
@@ -34,7 +34,7 @@ def main():
     from aegolius_amd._lower import lower_geometry
     from aegolius_amd.cores.helper_functions import grid_axes
     lib = _engine.lib()
-    tree, size, desc = bench.build_workload(args.workload, ns, scenes)
+    tree, size, desc = bench.build_workload(args.workload, ns)
     axes64, _res = grid_axes(size, (args.grid,) * len(size))
     axes = [a.astype(np.float32) for a in axes64]
     n = int(axes[0].size) * int(axes[1].size) * int(axes[2].size)
@@ -52,11 +52,13 @@ def main():
     torch.cuda.synchronize()
     results = []
     for var in args.variants:
-        mode, rows, defs = _engine.MODE_SPECIALIZED, True, var
+        mode, rows, planes, defs = _engine.MODE_SPECIALIZED, True, True, var
         while ":" in defs:
             head, defs = defs.split(":", 1)
             if head == "norows":
                 rows = False
+            elif head == "noplanes":
+                planes = False
             elif head.startswith("mode="):
                 mode = {"nocull": _engine.MODE_NOCULL, "interpret": _engine.MODE_INTERPRET}[head[5:]]
         defs = " ".join("-DSDFK_" + t for t in defs.split("+") if t and t != "base")
@@ -65,7 +67,7 @@ def main():
 
         def step():
             p.eval_device(co.data_ptr(), n, stride, out.data_ptr(), stream=stream, mode=mode, row_len=row_len if rows else None,
-                          flat=axes[2].size == 1)
+                          flat=axes[2].size == 1, plane_rows=int(axes[1].size) if planes and axes[2].size > 1 else None)
         out.zero_()
         try:
             step()
