@@ -578,6 +578,7 @@ struct RowGeom {           // mirrors sdfk_rowgeom of the generated source
     // row blocks never straddle a PLANE of the grid (rows of one x): the slab's rows are the rest of a first plane
     // (seg0 rows, nb0 blocks), then planes of prow rows (bpp blocks each; the last block of a plane may be partial)
     unsigned prow, seg0, nb0, bpp;
+    unsigned inv_nchunk, inv_bpp;                              // floor(2^32 / nchunk), floor(2^32 / bpp) (sdfk_udiv)
 };
 // can the row-block kernel take n points in rows of row_len? (brick ids are 32-bit)
 // plane_rows: rows per grid plane (0 / >= R: one plane — blocks of 16 consecutive rows throughout);
@@ -609,6 +610,8 @@ static bool rows_geometry(long long n, long long row_len, RowGeom* g, long long 
     g->seg0 = (unsigned)seg0;
     g->nb0 = (unsigned)nb0;
     g->bpp = (unsigned)bpp;
+    g->inv_nchunk = (unsigned)std::min<unsigned long long>(0xffffffffull, (1ull << 32) / (unsigned long long)nchunk);
+    g->inv_bpp = (unsigned)std::min<unsigned long long>(0xffffffffull, (1ull << 32) / (unsigned long long)bpp);
     return true;
 }
 static int tile_threads() { return 64 * tile_waves(); }

@@ -359,6 +359,22 @@ extern "C" __global__ __launch_bounds__(SDFK_TTHREADS) void sdfk_spec_tmask(
 )SDFKT";
 
 
+// Geometry of the lane-parallel probe (emitted in front of the generated leaf functions).
+static const char kSimtGeometry[] = R"SDFKR(
+#ifndef SDFK_RWBRICKS
+#define SDFK_RWBRICKS 2
+#endif
+#ifndef SDFK_RWAVES
+#define SDFK_RWAVES 2
+#endif
+#ifndef SDFK_NSUB                        // sub-bricks (probe centres) per brick: 16 = 4 rows x 8 points, 8 = 8 rows x 8 points
+#define SDFK_NSUB ((SDFK_NLEAF <= 12 && 16 * SDFK_RWBRICKS <= 64) ? 16 : ((SDFK_NLEAF <= 24 && 8 * SDFK_RWBRICKS <= 64) ? 8 : 1))
+#endif
+#define SDFK_NCEN (SDFK_RWAVES * SDFK_RWBRICKS * SDFK_NSUB)
+static_assert(SDFK_NSUB == 1 || SDFK_NSUB == 8 || SDFK_NSUB == 16, "1, 8 or 16 probe centres per brick");
+static_assert(SDFK_NCEN <= 64 * SDFK_RWAVES, "one fold lane per probe centre");
+)SDFKR";
+
 // Row-block culling kernel (only emitted when the program has cull sites). The caller states that the
 // points come as consecutive ROWS of L points (the last axis of a generate_grid meshgrid; any L dividing
 // n is valid). A brick = SDFK_RZ (32) consecutive points of SDFK_RROWS (16) consecutive rows: on a
@@ -395,6 +411,10 @@ struct sdfk_rowmeta {
     float4 bound[SDFK_RNBRICK];
     unsigned long long mask0[SDFK_RNBRICK], mask1[SDFK_RNBRICK];
     unsigned uniform[SDFK_RNBRICK];
+#ifdef SDFK_SIMT
+    float4 cen[SDFK_NCEN];                      // probe centres (x, y, z, radius): SDFK_NSUB per brick
+    float leafval[SDFK_NLEAF * SDFK_NCEN];      // [leaf][centre]: every leaf of the tree at every centre
+#endif
 #ifdef SDFK_LDSPAD
     float pad[SDFK_LDSPAD / 4];                 // experiment: a larger LDS footprint per workgroup
 #endif
@@ -405,7 +425,17 @@ struct sdfk_rowgeom {
     long long row0;                             // grid flavour: global row index of the first row of the slab
     int yrows;                                  // grid flavour, 2-D grid (n2 == 1): rows run along the second axis
     unsigned prow, seg0, nb0, bpp;              // planes of prow rows after a first partial plane of seg0 rows (nb0 blocks);
-};                                              // bpp blocks per plane: a block never holds rows of two planes
+                                                // bpp blocks per plane: a block never holds rows of two planes
+    unsigned inv_nchunk, inv_bpp;               // floor(2^32 / nchunk), floor(2^32 / bpp): divisions as one v_mul_hi
+};
+// a / d for wave-uniform a, with inv = floor(2^32 / d) from the host: the estimate is never too large and at most a few
+// units too small (a * (2^32 - inv * d) < 2^32 * d for every brick count the host accepts), the loop repairs it.
+// (A plain 32-bit division is ~35 vector instructions; this kernel has two per brick.)
+static __device__ __forceinline__ unsigned sdfk_udiv(unsigned a, unsigned d, unsigned inv) {
+    unsigned q = __umulhi(a, inv);
+    while (a - q * d >= d) ++q;
+    return __builtin_amdgcn_readfirstlane(q);
+}
 // rows [r0, rend) of row block rb (wave-uniform): 16 consecutive rows of ONE plane, fewer at the end of a plane
 static __device__ __forceinline__ void sdfk_block_rows(const sdfk_rowgeom& g, unsigned rb, long long& r0, long long& rend) {
     if (rb < g.nb0) {
@@ -413,7 +443,7 @@ static __device__ __forceinline__ void sdfk_block_rows(const sdfk_rowgeom& g, un
         rend = g.seg0;
     } else {
         const unsigned k = rb - g.nb0;
-        const unsigned pl = __builtin_amdgcn_readfirstlane(k / g.bpp);
+        const unsigned pl = sdfk_udiv(k, g.bpp, g.inv_bpp);
         const long long base = (long long)g.seg0 + (long long)pl * g.prow;
         r0 = base + (long long)(k - pl * g.bpp) * SDFK_RROWS;
         rend = base + g.prow < g.R ? base + g.prow : g.R;
@@ -525,6 +555,18 @@ static __device__ __forceinline__ void sdfk_rows_bounds(const sdfk_rowregs& r, i
         if (head) meta->xy[b][8 * t + (lane >> 3)] = make_float2(r.X[t].x, r.Y[t].x);
     }
     const bool uniform = __ballot(uni) == ~0ull;
+#if defined(SDFK_SIMT) && SDFK_NSUB > 1
+    // bricks of whole row segments are bounded per SUB-brick by the probe lanes (sdfk_sub_centre, from the staged
+    // coordinates): the sphere around the whole brick is only needed for the others
+    if (uniform) {
+        if (lane == 0) {
+            meta->uniform[b] = 1u;
+            meta->mask0[b] = ~0ull;
+            meta->mask1[b] = ~0ull;
+        }
+        return;
+    }
+#endif
     const float cx = 0.5f * (sdfk_lane(r.X[0].x, 0) + sdfk_lane(r.X[SDFK_RLOADS - 1].w, 63));
     const float cy = 0.5f * (sdfk_lane(r.Y[0].x, 0) + sdfk_lane(r.Y[SDFK_RLOADS - 1].w, 63));
     const float cz = 0.5f * (sdfk_lane(r.Z[0].x, 0) + sdfk_lane(r.Z[SDFK_RLOADS - 1].w, 63));
@@ -555,8 +597,45 @@ static __device__ __forceinline__ void sdfk_rows_bounds(const sdfk_rowregs& r, i
         meta->bound[b] = make_float4(cx, cy, cz, 1.00001f * sqrtf(r2) + 1e-30f);
 #endif
         meta->uniform[b] = uniform ? 1u : 0u;
+#ifdef SDFK_SIMT
+        meta->mask0[b] = ~0ull;                                   // the fold lanes AND their decisions into these
+        meta->mask1[b] = ~0ull;
+#endif
     }
 }
+#if defined(SDFK_SIMT) && SDFK_NSUB > 1
+// Probe centre `sb` of brick b whose rows each have one x and one y: the sub-brick is rows [r0, r0 + RPS) x points
+// [i0, i0 + ZPS) of the window; sphere around the midpoint of its first and last point, radius = the exact maximum
+// over its points (read back from the staged coordinates), so any input is bounded correctly — on a regular grid
+// 4 rows x 8 points have a quarter of the brick's radius.
+static __device__ __forceinline__ float4 sdfk_sub_centre(const sdfk_rowmeta* meta, unsigned b, unsigned sb) {
+    constexpr int NZP = 4, NRP = SDFK_NSUB / NZP, RPS = SDFK_RROWS / NRP, ZPS = SDFK_RZ / NZP;
+    static_assert(ZPS % 4 == 0 && RPS >= 1, "sub-brick shape");
+    const int r0 = (int)(sb / NZP) * RPS, i0 = (int)(sb % NZP) * ZPS;
+    const float2 pa = meta->xy[b][r0], pe = meta->xy[b][r0 + RPS - 1];
+    const float za = meta->z[b][r0 * SDFK_RZ + i0], ze = meta->z[b][(r0 + RPS - 1) * SDFK_RZ + i0 + ZPS - 1];
+    const float cx = 0.5f * (pa.x + pe.x), cy = 0.5f * (pa.y + pe.y), cz = 0.5f * (za + ze);
+    float r2 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < RPS; ++r) {
+        const float2 p = meta->xy[b][r0 + r];
+        const float dx = p.x - cx, dy = p.y - cy;
+        float zm = 0.0f;
+#pragma unroll
+        for (int i = 0; i < ZPS; i += 4) {
+            const float4 q = *reinterpret_cast<const float4*>(&meta->z[b][(r0 + r) * SDFK_RZ + i0 + i]);
+            zm = sd_rawmax(sd_rawmax(zm, sd_abs(q.x - cz)), sd_rawmax(sd_abs(q.y - cz), sd_rawmax(sd_abs(q.z - cz), sd_abs(q.w - cz))));
+        }
+        r2 = sd_rawmax(r2, sd_fma(zm, zm, sd_fma(dx, dx, dy * dy)));
+    }
+    const float rho = 1.00001f * sqrtf(r2) + 1e-30f;
+#ifdef SDFK_FLAT
+    return make_float4(cx, cz, cy, rho);                         // (the staged coordinate is y, xy holds (x, z = 0))
+#else
+    return make_float4(cx, cy, cz, rho);
+#endif
+}
+#endif
 
 // phases A and B of the tile of this workgroup; returns this wave's first brick (row block, window)
 template <typename SRC>
@@ -565,8 +644,8 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
                                                          unsigned tile, unsigned& rb0, unsigned& c0) {
     const int lane = sdfk_tx() & 63, wave = __builtin_amdgcn_readfirstlane(sdfk_tx() >> 6);
     const unsigned q0 = tile * SDFK_RNBRICK + wave * SDFK_RWBRICKS;            // first brick of this wave
-    rb0 = __builtin_amdgcn_readfirstlane(q0 / g.nchunk);        // (the division runs on the vector unit: back to an SGPR,
-    c0 = q0 - rb0 * g.nchunk;                                    //  so that what is derived from it stays scalar)
+    rb0 = sdfk_udiv(q0, g.nchunk, g.inv_nchunk);                // (back in an SGPR: what is derived from it stays scalar)
+    c0 = q0 - rb0 * g.nchunk;
     unsigned rb = rb0, c = c0;
 #if SDFK_RWBRICKS <= 2 && !defined(SDFK_NOHOIST)
     // two bricks per wave: all of the wave's loads are in flight before the first one is used (-0.8 % together with
@@ -584,7 +663,7 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
 #pragma unroll
     for (int j = 0; j < SDFK_RWBRICKS; ++j)
         if (live[j]) sdfk_rows_bounds(hregs[j], lane, meta, wave * SDFK_RWBRICKS + j);
-        else if (lane == 0) { meta->bound[wave * SDFK_RWBRICKS + j] = make_float4(0.0f, 0.0f, 0.0f, 1.0f); meta->uniform[wave * SDFK_RWBRICKS + j] = 0u; }
+        else if (lane == 0) { meta->bound[wave * SDFK_RWBRICKS + j] = make_float4(0.0f, 0.0f, 0.0f, 1.0f); meta->uniform[wave * SDFK_RWBRICKS + j] = 0u; }   // (masks: never read)
 #else
 #pragma unroll
     for (int j = 0; j < SDFK_RWBRICKS; ++j) {
@@ -606,6 +685,37 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
     }
 #endif
     __syncthreads();
+#ifdef SDFK_SIMT
+    // lane-parallel probe: probe centres -> every leaf at every centre (all lanes) -> one fold lane per centre ANDs its
+    // skip decisions into the brick's mask (a subtree is skipped only if every sub-brick allows it)
+    if (sdfk_tx() < SDFK_NCEN) {
+        const unsigned b = sdfk_tx() / SDFK_NSUB, sb = sdfk_tx() % SDFK_NSUB;
+        float4 cc = meta->bound[b];
+#if SDFK_NSUB > 1
+        if (meta->uniform[b]) cc = sdfk_sub_centre(meta, b, sb);
+#else
+        (void)sb;
+#endif
+        meta->cen[sdfk_tx()] = cc;
+    }
+    __syncthreads();
+#ifndef SDFK_ABLATE_PROBE
+    sdfk_probe_leaves(meta->cen, meta->leafval, PRM, TAB);
+    __syncthreads();
+    if (sdfk_tx() < SDFK_NCEN && tile * SDFK_RNBRICK + sdfk_tx() / SDFK_NSUB < g.nbricks) {
+        const float4 cc = meta->cen[sdfk_tx()];
+        V3T<float> ctr = {cc.x, cc.y, cc.z};
+        unsigned long long m0, m1;
+        sdfk_probe_fold(meta->leafval, sdfk_tx(), ctr, cc.w, PRM, m0, m1);
+        __hip_atomic_fetch_and(&meta->mask0[sdfk_tx() / SDFK_NSUB], m0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_and(&meta->mask1[sdfk_tx() / SDFK_NSUB], m1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#else
+    if (sdfk_tx() < SDFK_RNBRICK) { meta->mask0[sdfk_tx()] = 0ull; meta->mask1[sdfk_tx()] = 0ull; }
+#endif
+    __syncthreads();
+    return;
+#endif
     if (sdfk_tx() < SDFK_RNBRICK && tile * SDFK_RNBRICK + sdfk_tx() < g.nbricks) {
         const float4 bb = meta->bound[sdfk_tx()];
         V3T<float> ctr = {bb.x, bb.y, bb.z};
@@ -932,6 +1042,253 @@ struct Gen {
         if (name[0] == 'S') snprintf(wexpr, cap, "PRM[%u]", poff);
     }
 
+    // ---- leaves: operand ranges without a site inside (the children of an n-ary UNION, the primitives of a chain) ----
+    // When every instruction outside the combiners lives in such a range and a range reads nothing but the input
+    // point, the probe needs no sequential walk of the tree: the leaves are evaluated by ALL lanes of the workgroup —
+    // one (leaf, centre) pair per lane — and one lane per centre then folds the combiners over the stored leaf values.
+    // Leaves with the same operation sequence (children built the same way with other numbers) share one function
+    // that takes a table of parameter offsets, so 50 children of 4 kinds cost 4 functions, not 50 inlined bodies.
+    struct Leaf {
+        size_t lo, hi;
+        int group, member;
+        unsigned out;            // value register the range leaves its result in
+    };
+    struct Group {
+        std::vector<uint32_t> sig;   // canonical instruction words
+        std::vector<int> members;    // leaf indices
+        unsigned n_c = 1, n_v = 0;   // canonical registers used
+        unsigned out = 0;            // canonical result register
+    };
+    std::vector<Leaf> leaves;
+    std::vector<Group> groups;
+    std::vector<int> leaf_at;        // instruction -> leaf (or -1)
+    bool simt = false;
+
+    bool analyse_leaves() {
+        leaves.clear();
+        groups.clear();
+        leaf_at.assign(n_instr, -1);
+        if (sites->empty()) return false;
+        auto holds_site = [&](size_t lo, size_t hi) {
+            for (const sdfk_cullsite& t : *sites)
+                if (t.comb >= lo && t.comb <= hi) return true;
+            return false;
+        };
+        std::vector<std::pair<size_t, size_t>> rs;
+        for (const sdfk_cullsite& t : *sites) {
+            if (!holds_site(t.a0, t.a1)) {
+                if (!t.skip_a_ok) return false;
+                rs.push_back({t.a0, t.a1});
+            }
+            if (!holds_site(t.b0, t.b1)) {
+                if (!t.skip_b_ok) return false;
+                rs.push_back({t.b0, t.b1});
+            }
+        }
+        std::sort(rs.begin(), rs.end());
+        rs.erase(std::unique(rs.begin(), rs.end()), rs.end());
+        for (size_t k = 1; k < rs.size(); ++k)
+            if (rs[k].first <= rs[k - 1].second) return false;
+        for (size_t k = 0; k < rs.size(); ++k)
+            for (size_t i = rs[k].first; i <= rs[k].second; ++i) leaf_at[i] = (int)k;
+        int c0_writer = -1;                                              // leaf that has overwritten C_0 (-1: nobody yet)
+        for (size_t i = 0; i < n_instr; ++i) {
+            const uint32_t w = code[2 * i];
+            const unsigned op = w & 255u, a = (w >> 8) & 255u;
+            if ((int)op >= n_ops) return false;
+            const int kind = ops[op].kind;
+            if (!strcmp(ops[op].name, "V_FIELD")) return false;
+            if (leaf_at[i] < 0 && kind != SDFK_KIND_V_V && kind != SDFK_KIND_V_VV) return false;
+            // a leaf may rewrite the input point for itself (the last child of a combiner reuses C_0: inside the leaf's
+            // function that is a local copy) — but nobody else may read it afterwards
+            const unsigned b = (w >> 16) & 255u;
+            if ((kind == SDFK_KIND_C_C || kind == SDFK_KIND_V_C) && b == 0 && c0_writer != -1 && c0_writer != leaf_at[i]) return false;
+            if (kind == SDFK_KIND_C_C && a == 0) c0_writer = leaf_at[i];
+        }
+        for (size_t k = 0; k < rs.size(); ++k) {
+            Leaf lf{rs[k].first, rs[k].second, -1, -1, 0};
+            std::vector<int> cmap(256, -1), vmap(256, -1);
+            cmap[0] = 0;
+            unsigned nc = 1, nv = 0;
+            std::vector<uint32_t> sig;
+            for (size_t i = lf.lo; i <= lf.hi; ++i) {
+                const uint32_t w = code[2 * i];
+                const unsigned op = w & 255u, a = (w >> 8) & 255u, b = (w >> 16) & 255u, c = w >> 24;
+                const int kind = ops[op].kind;
+                unsigned ca = 0, cb = 0, cc = c;
+                if (kind == SDFK_KIND_C_C || kind == SDFK_KIND_V_C) {
+                    if (cmap[b] < 0) return false;                       // reads a coordinate register from outside
+                    cb = (unsigned)cmap[b];
+                } else {
+                    if (vmap[b] < 0) return false;
+                    cb = (unsigned)vmap[b];
+                    if (kind == SDFK_KIND_V_VV) {
+                        if (vmap[c] < 0) return false;
+                        cc = (unsigned)vmap[c];
+                    }
+                }
+                if (kind == SDFK_KIND_C_C) {
+                    if (cmap[a] < 0) cmap[a] = (int)nc++;
+                    ca = (unsigned)cmap[a];
+                } else {
+                    if (vmap[a] < 0) vmap[a] = (int)nv++;
+                    ca = (unsigned)vmap[a];
+                }
+                if (nc > 255 || nv > 255) return false;
+                sig.push_back(op | (ca << 8) | (cb << 16) | (cc << 24));
+            }
+            const uint32_t wl = code[2 * lf.hi];
+            if (ops[wl & 255u].kind == SDFK_KIND_C_C) return false;
+            lf.out = (wl >> 8) & 255u;
+            int g = -1;
+            for (size_t q = 0; q < groups.size(); ++q)
+                if (groups[q].sig == sig) g = (int)q;
+            if (g < 0) {
+                Group ng;
+                ng.sig = sig;
+                ng.n_c = nc;
+                ng.n_v = nv;
+                ng.out = (unsigned)vmap[lf.out];
+                groups.push_back(ng);
+                g = (int)groups.size() - 1;
+            }
+            lf.group = g;
+            lf.member = (int)groups[g].members.size();
+            groups[g].members.push_back((int)k);
+            leaves.push_back(lf);
+        }
+        return !leaves.empty();
+    }
+
+    // one function per group of equal leaves + its tables (parameter offsets per member and instruction, leaf ids)
+    void emit_groups() {
+        char buf[512];
+        for (size_t g = 0; g < groups.size(); ++g) {
+            const Group& G = groups[g];
+            snprintf(buf, sizeof buf,
+                     "\ntemplate <typename T> static __device__ __forceinline__ T sdfk_grp%zu(V3T<T> C_0, const unsigned* __restrict__ OFF, "
+                     "const float* __restrict__ PRM, const float* __restrict__ TAB) {\n",
+                     g);
+            s += buf;
+            for (unsigned c = 1; c < G.n_c; ++c) {
+                snprintf(buf, sizeof buf, "    V3T<T> C_%u;\n", c);
+                s += buf;
+            }
+            for (unsigned v = 0; v < G.n_v; ++v) {
+                snprintf(buf, sizeof buf, "    T V_%u;\n", v);
+                s += buf;
+            }
+            for (size_t j = 0; j < G.sig.size(); ++j) {
+                const uint32_t w = G.sig[j];
+                const unsigned op = w & 255u, a = (w >> 8) & 255u, b = (w >> 16) & 255u, c = w >> 24;
+                const sdfk_opinfo& o = ops[op];
+                switch (o.kind) {
+                    case SDFK_KIND_C_C:
+                        snprintf(buf, sizeof buf, "    C_%u = %s(C_%u, PRM + OFF[%zu], TAB, %u);\n", a, o.func, b, j, c);
+                        break;
+                    case SDFK_KIND_V_C:
+                        snprintf(buf, sizeof buf, "    V_%u = %s(C_%u, PRM + OFF[%zu], TAB);\n", a, o.func, b, j);
+                        break;
+                    case SDFK_KIND_V_V:
+                        snprintf(buf, sizeof buf, "    V_%u = %s(V_%u, PRM + OFF[%zu]);\n", a, o.func, b, j);
+                        break;
+                    default:
+                        snprintf(buf, sizeof buf, "    V_%u = %s(V_%u, V_%u, PRM + OFF[%zu]);\n", a, o.func, b, c, j);
+                        break;
+                }
+                s += buf;
+            }
+            snprintf(buf, sizeof buf, "    return V_%u;\n}\n", G.out);
+            s += buf;
+            snprintf(buf, sizeof buf, "static __constant__ const unsigned sdfk_grp%zu_off[%zu][%zu] = {\n", g, G.members.size(),
+                     G.sig.size());
+            s += buf;
+            for (int m : G.members) {
+                s += "    {";
+                for (size_t i = leaves[m].lo; i <= leaves[m].hi; ++i) {
+                    snprintf(buf, sizeof buf, "%uu,", code[2 * i + 1]);
+                    s += buf;
+                }
+                s += "},\n";
+            }
+            s += "};\n";
+            snprintf(buf, sizeof buf, "static __constant__ const unsigned short sdfk_grp%zu_leaf[%zu] = {", g, G.members.size());
+            s += buf;
+            for (int m : G.members) {
+                snprintf(buf, sizeof buf, "%d,", m);
+                s += buf;
+            }
+            s += "};\n";
+        }
+    }
+
+    // every (leaf, centre) pair on a lane of its own: leafval[leaf][centre] = leaf(centre)
+    void emit_probe_leaves() {
+        char buf[640];
+        s += "\nstatic __device__ __forceinline__ void sdfk_probe_leaves(const float4* __restrict__ cen, float* __restrict__ leafval, "
+             "const float* __restrict__ PRM, const float* __restrict__ TAB) {\n";
+        for (size_t g = 0; g < groups.size(); ++g) {
+            snprintf(buf, sizeof buf,
+                     "    _Pragma(\"unroll 1\") for (unsigned item = sdfk_tx(); item < %zuu * SDFK_NCEN; item += 64u * SDFK_RWAVES) {\n"
+                     "        unsigned m = item / SDFK_NCEN;\n"
+                     "        if (SDFK_NCEN %% 64 == 0) m = __builtin_amdgcn_readfirstlane(m);   // one member per wave: scalar parameter loads\n"
+                     "        const unsigned c = item - m * SDFK_NCEN;\n"
+                     "        const float4 cc = cen[c];\n"
+                     "        const V3T<float> p = {cc.x, cc.y, cc.z};\n"
+                     "        leafval[sdfk_grp%zu_leaf[m] * SDFK_NCEN + c] = sdfk_grp%zu<float>(p, sdfk_grp%zu_off[m], PRM, TAB);\n"
+                     "    }\n",
+                     groups[g].members.size(), g, g, g);
+            s += buf;
+        }
+        s += "}\n";
+    }
+
+    // one lane per centre: the combiners (and whatever else lies outside the leaves) over the stored leaf values,
+    // with the skip decision of every site exactly as in the sequential probe below
+    void emit_probe_fold() {
+        s += "\nstatic __device__ __forceinline__ void sdfk_probe_fold(const float* __restrict__ leafval, unsigned cen, V3T<float> C_0, "
+             "float rho, const float* __restrict__ PRM, unsigned long long& mask, unsigned long long& mask1) {\n";
+        std::set<unsigned> vregs;
+        for (size_t i = 0; i < n_instr; ++i)
+            if (leaf_at[i] < 0) vregs.insert((code[2 * i] >> 8) & 255u);
+        for (const Leaf& lf : leaves) vregs.insert(lf.out);
+        char buf[512], gB[64], gA[64], wx[32];
+        for (unsigned v : vregs) {
+            snprintf(buf, sizeof buf, "    float V_%u;\n", v);
+            s += buf;
+        }
+        s += "    mask = 0ull; mask1 = 0ull;\n";
+        s += "    const float cmag = 1e-6f * (fabsf(C_0.x) + fabsf(C_0.y) + fabsf(C_0.z) + rho);\n";
+        for (size_t i = 0; i < n_instr; ++i) {
+            if (leaf_at[i] >= 0) {
+                const Leaf& lf = leaves[leaf_at[i]];
+                snprintf(buf, sizeof buf, "    V_%u = leafval[%d * SDFK_NCEN + cen];\n", lf.out, leaf_at[i]);
+                s += buf;
+                i = lf.hi;
+                continue;
+            }
+            for (size_t k = 0; k < sites->size(); ++k) {
+                const sdfk_cullsite& t = (*sites)[k];
+                if (t.comb != i) continue;
+                bool neg;
+                site_ops(t, gB, gA, wx, &neg, sizeof gB);
+                const uint32_t w = code[2 * i];
+                const unsigned b = (w >> 16) & 255u, c = w >> 24;
+                const char* mv = k < 32 ? "mask" : "mask1";
+                const unsigned sh = 2 * (unsigned)(k & 31);
+                snprintf(buf, sizeof buf,
+                         "    { const float thr = %s + %.9ef * rho + %.9ef * cmag + 1e-6f * (1.0f + fabsf(V_%u) + fabsf(V_%u));\n"
+                         "      if (%d && %s >= thr) %s |= %lluull;\n"
+                         "      else if (%d && %s >= thr) %s |= %lluull; }\n",
+                         wx, (double)t.k * 1.0001, (double)t.k, b, c, t.skip_b_ok, gB, mv, 2ull << sh, t.skip_a_ok, gA, mv,
+                         1ull << sh);
+                s += buf;
+            }
+            instr(i, "    ");
+        }
+        s += "}\n";
+    }
+
     // ---- probe: full evaluation at a brick centre + skip decisions ----
     // For a brick of radius rho around the centre c and a combiner with operand fields a, b of
     // Lipschitz constants L_a, L_b (k = L_a + L_b): gap(c) >= w + k*rho  =>  gap(p) >= w for every p
@@ -1054,6 +1411,26 @@ struct Gen {
                 i = t.comb + 1;
                 continue;
             }
+            // Long chains (an n-ary UNION of 50 children is a chain of 49 sites): walking every level's two mask bits
+            // costs more scalar instructions than the one or two surviving children cost vector instructions. When the
+            // sites of the chain are numbered consecutively and every level combines in place (what the lowering of
+            // CombineGeometry produces), the levels that must run are a BITSET computed with a dozen scalar operations
+            // — st = highest level whose first operand is irrelevant, alive = levels >= st whose second operand is
+            // not skipped — and a loop visits exactly those: ctz, clear the bit, jump to the level's code.
+            bool loopable = rows && m >= 4 && m <= 64;
+            for (size_t idx = 1; idx <= m && loopable; ++idx) {
+                const sdfk_cullsite& t = (*sites)[chain[m - idx]];
+                const uint32_t w = code[2 * t.comb];
+                if (chain[m - idx] != chain[m - 1] + (int)idx - 1) loopable = false;            // consecutive site numbers
+                if (((w >> 8) & 255u) != ((w >> 16) & 255u)) loopable = false;                 // V_a = op(V_a, V_c)
+            }
+            if (loopable) {
+                char hd[256];
+                snprintf(hd, sizeof hd, "#if SDFK_CHAIN_LOOP_MIN <= %zu\n", m);
+                s += hd;
+                emit_chain_loop(chain, ind, depth);
+                s += "#else\n";
+            }
             char st[32];
             snprintf(st, sizeof st, "st_%d", k);
             s += ind + "{ unsigned " + st + " = 0u;\n";
@@ -1075,8 +1452,55 @@ struct Gen {
                 s += ind + "  }\n";
             }
             s += ind + "}\n";
+            if (loopable) s += "#endif\n";
             i = (*sites)[k].comb + 1;
         }
+    }
+
+    void emit_chain_loop(const std::vector<int>& chain, const std::string& ind, int depth) {
+        const size_t m = chain.size();
+        const int k0 = chain[m - 1];                              // site of level 1; level idx = site k0 + idx - 1
+        const sdfk_cullsite& first = (*sites)[k0];
+        char buf[512];
+        s += ind + "{ const unsigned long long cm0 = (unsigned long long)mw0 | ((unsigned long long)mw1 << 32), "
+                   "cm1 = (unsigned long long)mw2 | ((unsigned long long)mw3 << 32);\n";
+        // bit k of sa / sb = "skip the first / the second operand" of site k (sites 0..63)
+        s += ind + "  unsigned long long sa = sdfk_even_bits(cm0) | (sdfk_even_bits(cm1) << 32), "
+                   "sb = sdfk_even_bits(cm0 >> 1) | (sdfk_even_bits(cm1 >> 1) << 32);\n";
+        snprintf(buf, sizeof buf, "  const unsigned long long lm = %lluull;\n", m >= 64 ? ~0ull : ((1ull << m) - 1ull));
+        s += ind + buf;
+        snprintf(buf, sizeof buf, "  sa = (sa >> %d) & lm; sb = (sb >> %d) & lm;\n", k0, k0);
+        s += ind + buf;
+        s += ind + "  const unsigned st = sa ? 64u - (unsigned)__builtin_clzll(sa) : 0u;\n";
+        s += ind + "  unsigned long long alive = ~sb & lm & (st ? ~((1ull << (st - 1u)) - 1ull) : ~0ull);\n";
+        s += ind + "  if (st == 0u) {\n";
+        emit_span(first.a0, first.a1, depth + 1);
+        s += ind + "  }\n";
+        s += ind + "  while (alive) {\n";
+        s += ind + "    const unsigned lvl = (unsigned)__builtin_ctzll(alive) + 1u;\n";
+        s += ind + "    alive &= alive - 1ull;\n";
+        s += ind + "    switch (lvl) {\n";
+        for (size_t idx = 1; idx <= m; ++idx) {
+            const sdfk_cullsite& t = (*sites)[chain[m - idx]];
+            const uint32_t w = code[2 * t.comb];
+            const unsigned a = (w >> 8) & 255u, c = w >> 24;
+            char gB[64], gA[64], wx[32];
+            bool neg;
+            site_ops(t, gB, gA, wx, &neg, sizeof gB);
+            snprintf(buf, sizeof buf, "      case %zuu: {\n", idx);
+            s += ind + buf;
+            emit_span(t.b0, t.b1, depth + 2);
+            snprintf(buf, sizeof buf, "        if (lvl == st) { SDFK_EACH V_%u[q] = %sV_%u[q]; }\n", a, neg ? "-" : "", c);
+            s += ind + buf;
+            s += ind + "        else {\n";
+            instr(t.comb, (ind + "          ").c_str(), true);
+            s += ind + "        }\n";
+            s += ind + "      } break;\n";
+        }
+        s += ind + "      default: break;\n";
+        s += ind + "    }\n";
+        s += ind + "  }\n";
+        s += ind + "}\n";
     }
 
     void emit_rows_culled(int result_reg) {
@@ -1165,6 +1589,28 @@ std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32
         g.find_roots();
         if (flat) g.s += "\n#define SDFK_FLAT 1\n";
         g.s += "\n#define SDFK_NP 4\n#define SDFK_EACH _Pragma(\"unroll\") for (int q = 0; q < SDFK_NP; ++q)\n";
+        g.s += "#ifndef SDFK_CHAIN_LOOP_MIN\n#define SDFK_CHAIN_LOOP_MIN 12   // chains of at least this many sites run as a loop over the levels that survive\n#endif\n"
+               "// the even bits of x, packed into the low 32 bits (wave-uniform: scalar unit)\n"
+               "static __device__ __forceinline__ unsigned long long sdfk_even_bits(unsigned long long x) {\n"
+               "    x &= 0x5555555555555555ull;\n"
+               "    x = (x | (x >> 1)) & 0x3333333333333333ull;\n"
+               "    x = (x | (x >> 2)) & 0x0f0f0f0f0f0f0f0full;\n"
+               "    x = (x | (x >> 4)) & 0x00ff00ff00ff00ffull;\n"
+               "    x = (x | (x >> 8)) & 0x0000ffff0000ffffull;\n"
+               "    x = (x | (x >> 16)) & 0x00000000ffffffffull;\n"
+               "    return x;\n}\n";
+        g.simt = g.analyse_leaves();
+        if (g.simt) {
+            // sub-bricks per brick (every one gets a probe centre of its own): as many as the lanes of the workgroup
+            // pay for — the leaf evaluations are the cost: (leaves x centres) / lanes rounds of one leaf each
+            char def[160];
+            snprintf(def, sizeof def, "\n#ifndef SDFK_NOSIMT\n#define SDFK_SIMT 1\n#endif\n#define SDFK_NLEAF %zu\n", g.leaves.size());
+            g.s += def;
+            g.s += kSimtGeometry;
+            g.emit_groups();
+            g.emit_probe_leaves();
+            g.emit_probe_fold();
+        }
         g.emit_probe();
         g.emit_rows_culled(result_reg);
         g.s += kRowsKernel;
