@@ -590,7 +590,11 @@ static bool rows_geometry(long long n, long long row_len, RowGeom* g, long long 
     // windows of 32 points aligned in the flat array: one more than ceil(L / 32) can overlap a row
     const long long nchunk = (row_len % 32 == 0) ? row_len / 32 : (row_len + 62) / 32;
     long long prow = plane_rows, seg0 = 0;
-    if (prow <= 0 || prow >= R || prow > 0x7fffffffLL) {
+    // Measured on 513^3 / 1025^3 (tools/rows_ab.py `noplanes:`): the partial block that ends every plane of 2^k + 1 rows
+    // costs as much as the one straddling block it replaces saves (513^3: 0.413 vs 0.401 ms, 1025^3 equal) — so the hint
+    // is honoured only on request (SDFK_PLANE_BLOCKS=1); the default is blocks of 16 consecutive rows throughout.
+    static const bool plane_blocks = [] { const char* e = getenv("SDFK_PLANE_BLOCKS"); return e && e[0] == '1'; }();
+    if (!plane_blocks || prow <= 0 || prow >= R || prow > 0x7fffffffLL) {
         prow = R > 0x7fffffffLL ? 0 : R;                       // one plane
         if (prow == 0) return false;
     } else if (plane_phase > 0) {

@@ -118,7 +118,9 @@ int sdfk_eval_device_rows(sdfk_program* prog, const float* d_co, int64_t n, int6
  * dimension; rows of one plane share x) and the first row of the array is row first_row_in_plane of its plane
  * (0 for a whole grid, anything for an x-slab of whole rows). Row blocks then never straddle two planes — such a
  * block spans the whole y extent of the grid and culls nothing (1 block in 32 at 513^3). plane_rows = 0: unknown
- * (= sdfk_eval_device_rows). Hints only: the field is bit-identical for any values. */
+ * (= sdfk_eval_device_rows). Hints only: the field is bit-identical for any values. Honoured when the environment
+ * sets SDFK_PLANE_BLOCKS=1: measured on 2^k + 1 grids the partial block that then ends every plane costs what the
+ * straddling block saved, so by default the call equals sdfk_eval_device_rows. */
 int sdfk_eval_device_rows3d(sdfk_program* prog, const float* d_co, int64_t n, int64_t row_stride, int64_t row_len,
                             int64_t plane_rows, int64_t first_row_in_plane, float* d_out, void* stream, int mode);
 /* The same for the array of a FLAT grid (generate_grid with two sizes, cores/helper_functions.py:63-75: rows run

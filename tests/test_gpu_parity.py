@@ -190,6 +190,9 @@ def test_empty_and_ragged_inputs(engine):
         tree.create(np.zeros((2, 10)))
 
 
+os.environ.setdefault("SDFK_PLANE_BLOCKS", "1")      # the tests exercise the plane hint of sdfk_eval_device_rows3d
+
+
 def _device_eval(engine, prog, co32, n, stride, misalign=0, mode=None, row_len=None, flat=False, plane_rows=None,
                  first_row_in_plane=0):
     """eval_device on raw HIP buffers (optionally shifted by `misalign` floats to defeat 16-B alignment)."""

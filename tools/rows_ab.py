@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("variants", nargs="*", default=[""])
     args = ap.parse_args()
+    os.environ.setdefault("SDFK_PLANE_BLOCKS", "1")        # (`noplanes:` variants simply pass no plane hint)
     import torch
     import bench
     import scenes
