@@ -222,7 +222,9 @@ struct sdfk_program {
     unsigned long long params_version = 1;
     std::string key;
     std::string source;
-    std::vector<sdfk_cullsite> sites;  // brick-culling sites (sdfk_program_set_cull)
+    std::vector<sdfk_cullsite> sites;  // brick-culling sites the mask kernels use: the 64 widest (sdfk_program_set_cull)
+    std::vector<sdfk_cullsite> sites_all;  // every site that was passed in
+    bool chain_mode = false;           // long n-ary min / max chain: table-driven kernels (sdfk_codegen.cpp)
     std::mutex mu;
     std::map<int, DevState> dev;
 };
@@ -491,7 +493,7 @@ static bool is_cullable_op(unsigned op) {
 
 extern "C" int sdfk_program_set_cull(sdfk_program* p, const uint32_t* rows, size_t n_sites, const float* k) {
     if (!p) return fail(-1, "null program");
-    if (n_sites > 64) return fail(-2, "sdfk_program_set_cull: at most 64 sites");
+    if (n_sites > 4095) return fail(-2, "sdfk_program_set_cull: at most 4095 sites");
     if (n_sites && (!rows || !k)) return fail(-1, "sdfk_program_set_cull: null arrays");
     std::lock_guard<std::mutex> lk(p->mu);
     if (!p->source.empty() || !p->dev.empty())
@@ -517,9 +519,24 @@ extern "C" int sdfk_program_set_cull(sdfk_program* p, const uint32_t* rows, size
         t.skip_b_ok = range_skippable(p, t.b0, t.b1, t.comb, c) ? 1 : 0;
         sites.push_back(t);
     }
+    // the kernels that carry two mask bits per site in two 64-bit words take the 64 widest sites, in program order
+    p->sites_all = sites;
+    if (sites.size() > 64) {
+        std::vector<size_t> order(sites.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+            return (sites[x].a1 - sites[x].a0) + (sites[x].b1 - sites[x].b0) > (sites[y].a1 - sites[y].a0) + (sites[y].b1 - sites[y].b0);
+        });
+        order.resize(64);
+        std::sort(order.begin(), order.end());
+        std::vector<sdfk_cullsite> widest;
+        for (size_t i : order) widest.push_back(sites[i]);
+        sites.swap(widest);
+    }
     p->sites = sites;
+    p->chain_mode = sdfk_chain_mode(g_ops, SDFK_OP_COUNT, p->code.data(), p->code.size() / 2, p->result_reg, p->sites_all);
     p->key.append("|cull");
-    for (const sdfk_cullsite& t : sites) {
+    for (const sdfk_cullsite& t : p->sites_all) {
         p->key.append(reinterpret_cast<const char*>(&t), sizeof t);
     }
     return 0;
@@ -530,7 +547,7 @@ extern "C" const char* sdfk_program_source(sdfk_program* p) {
     std::lock_guard<std::mutex> lk(p->mu);
     if (p->source.empty())
         p->source = sdfk_generate_source(g_ops, SDFK_OP_COUNT, p->code.data(), p->code.size() / 2, p->result_reg,
-                                         p->sites, SDFK_FL_ALL);
+                                         p->sites, SDFK_FL_ALL, &p->sites_all);
     return p->source.c_str();
 }
 
@@ -1064,7 +1081,8 @@ static std::string flavour_key(const sdfk_program* p, int flavour, int rwb) {
     return p->key + "|f" + std::to_string(flavour) + "|" + rtc_option_key(rwb);
 }
 static std::string flavour_source(const sdfk_program* p, int flavour) {
-    return sdfk_generate_source(g_ops, SDFK_OP_COUNT, p->code.data(), p->code.size() / 2, p->result_reg, p->sites, flavour);
+    return sdfk_generate_source(g_ops, SDFK_OP_COUNT, p->code.data(), p->code.size() / 2, p->result_reg, p->sites, flavour,
+                                &p->sites_all);
 }
 
 extern "C" int sdfk_program_compile_check(sdfk_program* p, size_t* code_size) {
@@ -1074,6 +1092,7 @@ extern "C" int sdfk_program_compile_check(sdfk_program* p, size_t* code_size) {
     const int rwb = rows_geo(p);
     for (int f = 0; f < SDFK_FL_COUNT; ++f) {
         if (p->sites.empty() && f != SDFK_FL_PLAIN_ARRAY && f != SDFK_FL_PLAIN_GRID) continue;
+        if (p->chain_mode && (f == SDFK_FL_TILE_ARRAY || f == SDFK_FL_TILE_GRID || f == SDFK_FL_TILE_MASK || f == SDFK_FL_ROWS_MASK)) continue;
         std::shared_ptr<CodeObject> e = code_get(flavour_key(p, f, rwb), [&] { return flavour_source(p, f); }, rwb, true);
         if (e->state != 2) return fail(-3, e->error);
         total += e->co.size();
@@ -1250,7 +1269,8 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
         const long long v = e ? atoll(e) : 1200;
         return v > 0 ? v : 1200;
     }();
-    if (mode == SDFK_MODE_AUTO && (long long)(p->code.size() / 2) > spec_limit && p->interp_ok) mode = SDFK_MODE_INTERPRET;
+    if (mode == SDFK_MODE_AUTO && (long long)(p->code.size() / 2) > spec_limit && p->interp_ok && !p->chain_mode)
+        mode = SDFK_MODE_INTERPRET;
 
     // Which flavour does this call launch? (row blocks > line bricks > plain; NOCULL and programs without sites: plain)
     RowGeom rg;
@@ -1259,12 +1279,12 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
     if (!p->sites.empty() && mode != SDFK_MODE_NOCULL && mode != SDFK_MODE_INTERPRET) {
         if (arr && rows_geometry(n, row_len, &rg, flat ? 0 : plane_rows, plane_phase))
             flavour = flat ? SDFK_FL_ROWS2D_ARRAY : SDFK_FL_ROWS_ARRAY;   // rows need no alignment beyond 4 bytes
-        else if (arr && vec_ok) flavour = SDFK_FL_TILE_ARRAY;
+        else if (arr && vec_ok && !p->chain_mode) flavour = SDFK_FL_TILE_ARRAY;
         else if (grid && grid->start % grow == 0 &&
                  rows_geometry(n, grow, &rg, grid->n2 > 1 ? (long long)grid->n1 : 0,
                                grid->n2 > 1 ? (grid->start / grow) % (long long)grid->n1 : 0))
             flavour = grid->n2 > 1 ? SDFK_FL_ROWS_GRID : SDFK_FL_ROWS2D_GRID;
-        else if (grid && vec_ok) flavour = SDFK_FL_TILE_GRID;
+        else if (grid && vec_ok && !p->chain_mode) flavour = SDFK_FL_TILE_GRID;
     }
     std::shared_ptr<SpecModule> sk;
     if (mode != SDFK_MODE_INTERPRET) {
@@ -1448,6 +1468,7 @@ extern "C" int sdfk_debug_row_masks(sdfk_program* p, const float* d_co, int64_t 
                                     uint64_t* d_masks, int64_t* n_bricks, int* brick_rows, void* stream_) {
     if (!p || !d_co) return fail(-1, "sdfk_debug_row_masks: null argument");
     if (p->sites.empty()) return fail(-2, "sdfk_debug_row_masks: program has no cull sites");
+    if (p->chain_mode) return fail(-2, "sdfk_debug_row_masks: a chain-mode program keeps lists of surviving children, not mask words");
     RowGeom rg;
     if (row_stride < n || !rows_geometry(n, row_len, &rg))
         return fail(-1, "sdfk_debug_row_masks: the row-block kernel does not take this shape");
@@ -1479,6 +1500,7 @@ extern "C" int sdfk_debug_brick_masks(sdfk_program* p, const float* d_co, int64_
     if (!(aligned16(d_co) && row_stride % 4 == 0 && row_stride >= n && n > 0))
         return fail(-1, "sdfk_debug_brick_masks: needs 16-byte aligned rows");
     if (p->sites.empty()) return fail(-2, "sdfk_debug_brick_masks: program has no cull sites");
+    if (p->chain_mode) return fail(-2, "sdfk_debug_brick_masks: chain-mode programs have no line-brick flavour");
     hipStream_t stream = (hipStream_t)stream_;
     int device = 0;
     HIPCHK(hipGetDevice(&device));

@@ -417,6 +417,11 @@ struct sdfk_rowmeta {
     float4 cen[SDFK_NCEN];                      // probe centres (x, y, z, radius): SDFK_NSUB per brick
     float leafval[SDFK_NLEAF * SDFK_NCEN];      // [leaf][centre]: every leaf of the tree at every centre
 #endif
+#ifdef SDFK_CHAIN
+    unsigned long long cbits[SDFK_RNBRICK][(SDFK_NLEAF + 63) / 64];   // level k: its child is irrelevant on this brick
+    unsigned short alist[SDFK_RNBRICK][SDFK_NLEAF];                    // the levels that run, in order
+    unsigned nalive[SDFK_RNBRICK];
+#endif
 #ifdef SDFK_LDSPAD
     float pad[SDFK_LDSPAD / 4];                 // experiment: a larger LDS footprint per workgroup
 #endif
@@ -639,6 +644,59 @@ static __device__ __forceinline__ float4 sdfk_sub_centre(const sdfk_rowmeta* met
 }
 #endif
 
+#ifdef SDFK_CHAIN
+// Chain mode, one WAVE per brick: the skip decision of every level from the leaf values at the brick's centre, 64
+// levels at a time. With e_k = +-d_k (min form) the accumulator before level k is the prefix minimum of e_0..e_{k-1}
+// (exact for a hard min / max): the child of level k is irrelevant on the brick if e_k - acc >= thr, everything before
+// level k is irrelevant if acc - e_k >= thr (thr as in the sequential probe, without a smoothing width). What runs:
+// the last level that makes its predecessors irrelevant (level 0 if there is none) and every later level whose child
+// matters — written as a LIST, so that the evaluation never looks at the levels it skips.
+static __device__ __forceinline__ void sdfk_chain_fold(sdfk_rowmeta* meta, int b, int lane) {
+    const float4 cc = meta->bound[b];
+    const float rho = cc.w, cmag = 1e-6f * (fabsf(cc.x) + fabsf(cc.y) + fabsf(cc.z) + rho);
+    constexpr int NW = (SDFK_NLEAF + 63) / 64;
+    const float big = 3.0e38f;
+    float carry = big;
+    int st = 0;
+#pragma unroll 1
+    for (int j = 0; j < NW; ++j) {
+        const int k = 64 * j + lane;
+        const bool in = k < SDFK_NLEAF;
+        const float e = in ? SDFK_CHAIN_SGN * meta->leafval[k * SDFK_NCEN + b] : big;
+        float pm = e;                                               // inclusive prefix minimum over the lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float t = __shfl_up(pm, o);
+            if (lane >= o) pm = fminf(pm, t);
+        }
+        float ex = __shfl_up(pm, 1);
+        if (lane == 0) ex = big;
+        const float acc = fminf(carry, ex);
+        const float K = in ? sdfk_chain_k[k] : 0.0f;
+        const float thr = 1.0001f * K * rho + K * cmag + 1e-6f * (1.0f + fabsf(acc) + fabsf(e));
+        const bool sb = in && k > 0 && (e - acc >= thr);
+        const bool sa = in && k > 0 && !sb && (acc - e >= thr);
+        const unsigned long long bsb = __ballot(sb), bsa = __ballot(sa);
+        // EVERY lane stores the (wave-uniform) word it will read back below: written by lane 0 alone, the compiler is free to
+        // let the other lanes' loads overtake that store — no lane but 0 has a store of its own in front of its load —, and
+        // with a single word (fewer than 64 children) it did: stale lists, wild parameter offsets, a memory fault
+        meta->cbits[b][j] = bsb;
+        if (bsa) st = 64 * j + 63 - __builtin_clzll(bsa);
+        carry = fminf(carry, __shfl(pm, 63));
+    }
+    int n_out = 0;
+#pragma unroll 1
+    for (int j = st >> 6; j < NW; ++j) {
+        unsigned long long run = ~meta->cbits[b][j];
+        if (j == (st >> 6)) run &= ~((1ull << (st & 63)) - 1ull);
+        if (j == NW - 1 && (SDFK_NLEAF & 63)) run &= (1ull << (SDFK_NLEAF & 63)) - 1ull;
+        if ((run >> lane) & 1ull) meta->alist[b][n_out + __builtin_popcountll(run & ((1ull << lane) - 1ull))] = (unsigned short)(64 * j + lane);
+        n_out += __builtin_popcountll(run);
+    }
+    if (lane == 0) meta->nalive[b] = (unsigned)n_out;
+}
+#endif
+
 // phases A and B of the tile of this workgroup; returns this wave's first brick (row block, window)
 template <typename SRC>
 static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict__ PRM, const float* __restrict__ TAB,
@@ -704,6 +762,13 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
 #ifndef SDFK_ABLATE_PROBE
     sdfk_probe_leaves(meta->cen, meta->leafval, PRM, TAB);
     __syncthreads();
+#ifdef SDFK_CHAIN
+#pragma unroll 1
+    for (int j = 0; j < SDFK_RWBRICKS; ++j)
+        if (q0 + j < g.nbricks) sdfk_chain_fold(meta, wave * SDFK_RWBRICKS + j, lane);
+    __syncthreads();
+    return;
+#else
     if (sdfk_tx() < SDFK_NCEN && tile * SDFK_RNBRICK + sdfk_tx() / SDFK_NSUB < g.nbricks) {
         const float4 cc = meta->cen[sdfk_tx()];
         V3T<float> ctr = {cc.x, cc.y, cc.z};
@@ -712,6 +777,7 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
         __hip_atomic_fetch_and(&meta->mask0[sdfk_tx() / SDFK_NSUB], m0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_and(&meta->mask1[sdfk_tx() / SDFK_NSUB], m1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+#endif
 #else
     if (sdfk_tx() < SDFK_RNBRICK) { meta->mask0[sdfk_tx()] = 0ull; meta->mask1[sdfk_tx()] = 0ull; }
 #endif
@@ -722,7 +788,7 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
         const float4 bb = meta->bound[sdfk_tx()];
         V3T<float> ctr = {bb.x, bb.y, bb.z};
         unsigned long long m0 = 0ull, m1 = 0ull;
-#ifndef SDFK_ABLATE_PROBE
+#if !defined(SDFK_ABLATE_PROBE) && !defined(SDFK_CHAIN)
         sdfk_probe_r(ctr, bb.w, PRM, TAB, m0, m1);
 #endif
         meta->mask0[sdfk_tx()] = m0;
@@ -808,7 +874,9 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
 #else
             SDFK_EACH { P[q].x = sp<f2>(xy.x); P[q].y = sp<f2>(xy.y); }
 #endif
+#ifndef SDFK_CHAIN
             sdfk_rows_culled<true>(xy.x, xy.y, P, w0, w1, w2, w3, PRM, TAB, res);
+#endif
         } else {                                                  // the other coordinates of every point again (L2-resident)
 #pragma unroll
             for (int q = 0; q < SDFK_NP; q += 2) {
@@ -824,8 +892,25 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
                 P[q + 1].y = {Y.z, Y.w};
 #endif
             }
+#ifndef SDFK_CHAIN
             sdfk_rows_culled<false>(0.0f, 0.0f, P, w0, w1, w2, w3, PRM, TAB, res);
+#endif
         }
+#ifdef SDFK_CHAIN
+        {   // the levels on the brick's list, in order; the first one starts the accumulator
+            const unsigned cnt = __builtin_amdgcn_readfirstlane(meta.nalive[b]);
+            f2 acc[SDFK_NP];
+#pragma unroll 1
+            for (unsigned i = 0; i < cnt; ++i) {
+                const unsigned kk = __builtin_amdgcn_readfirstlane((unsigned)meta.alist[b][i]);
+                f2 val[SDFK_NP];
+                SDFK_EACH val[q] = sdfk_leaf<f2>(kk, P[q], PRM, TAB);
+                if (i == 0u) { SDFK_EACH acc[q] = val[q]; }
+                else { SDFK_EACH acc[q] = SDFK_CHAIN_CMB(acc[q], val[q], PRM); }
+            }
+            SDFK_EACH res[q] = sdfk_chain_tail<f2>(acc[q], PRM);
+        }
+#endif
         if (live_row) {
             float* po = out + f;
             if (interior) {
@@ -1291,6 +1376,106 @@ struct Gen {
         s += "}\n";
     }
 
+    // ---- chain mode: one long n-ary hard min / max over leaves (CombineGeometry("UNION").combine(*many)) ----
+    // leaves[k] (k = 0..n-1) in program order, combined by `V_acc = OP(V_acc, V_k)` right after each leaf k >= 1, optionally
+    // followed by value modifications of the result. Requires analyse_leaves() over ALL sites of the program.
+    struct Chain {
+        bool ok = false;
+        unsigned acc = 0;           // accumulator register
+        bool is_max = false;        // VMAX (INTERSECT) instead of VMIN (UNION)
+        size_t tail = 0;            // first instruction after the last combiner
+        std::vector<float> k;       // Lipschitz sum of level k (site k - 1)
+    } chain;
+
+    bool analyse_chain(int result_reg) {
+        chain = Chain();
+        const size_t n = leaves.size();
+        if (n < 2 || sites->size() != n - 1) return false;
+        const uint32_t w0 = code[2 * (*sites)[0].comb];
+        const char* name = ops[w0 & 255u].name;
+        if (strcmp(name, "VMIN") && strcmp(name, "VMAX")) return false;
+        chain.is_max = !strcmp(name, "VMAX");
+        chain.acc = (w0 >> 8) & 255u;
+        chain.k.assign(n, 0.0f);
+        for (size_t j = 0; j + 1 < n; ++j) {
+            const sdfk_cullsite& t = (*sites)[j];
+            const uint32_t w = code[2 * t.comb];
+            if ((w & 255u) != (w0 & 255u)) return false;
+            const unsigned a = (w >> 8) & 255u, b = (w >> 16) & 255u, c = w >> 24;
+            if (a != chain.acc || b != chain.acc) return false;
+            if (t.a0 != leaves[0].lo || t.b0 != leaves[j + 1].lo || t.b1 != leaves[j + 1].hi || t.comb != t.b1 + 1) return false;
+            if (leaves[j + 1].out != c || c == chain.acc) return false;
+            if (j == 0 && (t.a1 != leaves[0].hi || leaves[0].out != chain.acc)) return false;
+            if (j > 0 && t.a1 != (*sites)[j - 1].comb) return false;
+            chain.k[j + 1] = t.k;
+        }
+        chain.tail = (*sites)[n - 2].comb + 1;
+        for (size_t i = chain.tail; i < n_instr; ++i) {              // value modifications of the result, in place
+            const uint32_t w = code[2 * i];
+            if (ops[w & 255u].kind != SDFK_KIND_V_V) return false;
+            if (((w >> 8) & 255u) != chain.acc || ((w >> 16) & 255u) != chain.acc) return false;
+        }
+        if ((unsigned)result_reg != chain.acc) return false;
+        chain.ok = true;
+        return true;
+    }
+
+    // tables + dispatcher shared by the chain-mode kernels
+    void emit_chain_common() {
+        char buf[768];
+        const size_t n = leaves.size();
+        snprintf(buf, sizeof buf, "\n#define SDFK_CHAIN 1\n#define SDFK_NLEAF %zu\n#define SDFK_CHAIN_SGN %s\n", n,
+                 chain.is_max ? "(-1.0f)" : "1.0f");
+        s += buf;
+        emit_groups();
+        s += "static __constant__ const unsigned short sdfk_leaf_grp[SDFK_NLEAF] = {";
+        for (const Leaf& lf : leaves) {
+            snprintf(buf, sizeof buf, "%d,", lf.group);
+            s += buf;
+        }
+        s += "};\nstatic __constant__ const unsigned short sdfk_leaf_mem[SDFK_NLEAF] = {";
+        for (const Leaf& lf : leaves) {
+            snprintf(buf, sizeof buf, "%d,", lf.member);
+            s += buf;
+        }
+        s += "};\nstatic __constant__ const float sdfk_chain_k[SDFK_NLEAF] = {";
+        for (float k : chain.k) {
+            snprintf(buf, sizeof buf, "%.9ef,", (double)k);
+            s += buf;
+        }
+        s += "};\n";
+        // leaf k (wave-uniform) at the lane's points
+        s += "template <typename T> static __device__ __forceinline__ T sdfk_leaf(unsigned k, V3T<T> C_0, const float* __restrict__ PRM, "
+             "const float* __restrict__ TAB) {\n    const unsigned m = sdfk_leaf_mem[k];\n    switch (sdfk_leaf_grp[k]) {\n";
+        for (size_t g = 0; g < groups.size(); ++g) {
+            snprintf(buf, sizeof buf, "        case %zuu: return sdfk_grp%zu<T>(C_0, sdfk_grp%zu_off[m], PRM, TAB);\n", g, g, g);
+            s += buf;
+        }
+        s += "        default: return sp<T>(0.0f);\n    }\n}\n";
+        const char* cmb = chain.is_max ? "cmb_max" : "cmb_min";
+        // the result modifications, applied to an accumulator of type T
+        s += "template <typename T> static __device__ __forceinline__ T sdfk_chain_tail(T V_acc, const float* __restrict__ PRM) {\n";
+        for (size_t i = chain.tail; i < n_instr; ++i) {
+            const uint32_t w = code[2 * i], poff = code[2 * i + 1];
+            snprintf(buf, sizeof buf, "    V_acc = %s(V_acc, PRM + %u);\n", ops[w & 255u].func, poff);
+            s += buf;
+        }
+        s += "    return V_acc;\n}\n";
+        // plain evaluation: every leaf in order
+        snprintf(buf, sizeof buf,
+                 "template <typename T> static __device__ __forceinline__ T sdfk_point(V3T<T> C_0, const float* __restrict__ PRM, "
+                 "const float* __restrict__ TAB, const float* __restrict__, long long) {\n"
+                 "    T acc = sdfk_leaf<T>(0u, C_0, PRM, TAB);\n"
+                 "    _Pragma(\"unroll 1\") for (unsigned k = 1u; k < SDFK_NLEAF; ++k) acc = %s(acc, sdfk_leaf<T>(k, C_0, PRM, TAB), PRM);\n"
+                 "    return sdfk_chain_tail<T>(acc, PRM);\n}\n",
+                 cmb);
+        s += buf;
+        // culled evaluation of one row-block brick: the levels on the brick's list, in order
+        snprintf(buf, sizeof buf,
+                 "#define SDFK_CHAIN_CMB %s\n", cmb);
+        s += buf;
+    }
+
     // ---- probe: full evaluation at a brick centre + skip decisions ----
     // For a brick of radius rho around the centre c and a combiner with operand fields a, b of
     // Lipschitz constants L_a, L_b (k = L_a + L_b): gap(c) >= w + k*rho  =>  gap(p) >= w for every p
@@ -1531,8 +1716,33 @@ struct Gen {
 
 }  // namespace
 
+// leaves beyond which an n-ary min / max chain is generated table-driven (SDFK_CHAIN_MIN overrides: tests)
+static size_t chain_min_leaves() {
+    static const size_t v = [] {
+        const char* e = getenv("SDFK_CHAIN_MIN");
+        const long t = e ? atol(e) : 0;
+        return (size_t)(t >= 2 ? t : 65);
+    }();
+    return v;
+}
+static bool chain_analyse(Gen& g, int result_reg, const std::vector<sdfk_cullsite>* sites_all) {
+    // (at most 2048 leaves: 24 bytes of LDS per leaf and workgroup for the leaf values and the lists)
+    if (!sites_all || sites_all->size() + 1 < chain_min_leaves() || sites_all->size() + 1 > 2048) return false;
+    const std::vector<sdfk_cullsite>* keep = g.sites;
+    g.sites = sites_all;
+    const bool ok = g.analyse_leaves() && g.analyse_chain(result_reg);
+    if (!ok) g.sites = keep;
+    return ok;
+}
+bool sdfk_chain_mode(const sdfk_opinfo* ops, int n_ops, const uint32_t* code, size_t n_instr, int result_reg,
+                     const std::vector<sdfk_cullsite>& sites_all) {
+    Gen g{ops, n_ops, code, n_instr, &sites_all, std::string()};
+    return chain_analyse(g, result_reg, &sites_all);
+}
+
 std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32_t* code, size_t n_instr,
-                                 int result_reg, const std::vector<sdfk_cullsite>& sites, int flavour) {
+                                 int result_reg, const std::vector<sdfk_cullsite>& sites, int flavour,
+                                 const std::vector<sdfk_cullsite>* sites_all) {
     const bool all = flavour == SDFK_FL_ALL;
     const bool plain = all || flavour == SDFK_FL_PLAIN_ARRAY || flavour == SDFK_FL_PLAIN_GRID;
     const bool tile = !sites.empty() && (all || flavour == SDFK_FL_TILE_ARRAY || flavour == SDFK_FL_TILE_GRID ||
@@ -1547,6 +1757,28 @@ std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32
     g.s += "\n";
     g.s += kEmbeddedAccess;
     char buf[64];
+    if (chain_analyse(g, result_reg, sites_all)) {
+        // chain mode: table-driven plain kernels and row-block kernels (no line-brick flavour)
+        const bool flat2 = flavour == SDFK_FL_ROWS2D_ARRAY || flavour == SDFK_FL_ROWS2D_GRID;
+        g.emit_chain_common();
+        if (plain) {
+            g.s += kWrappers;
+            if (all || flavour == SDFK_FL_PLAIN_ARRAY) g.s += kWrappersArray;
+            if (all || flavour == SDFK_FL_PLAIN_GRID) g.s += kWrappersGrid;
+        }
+        if (all || flat2 || flavour == SDFK_FL_ROWS_ARRAY || flavour == SDFK_FL_ROWS_GRID || flavour == SDFK_FL_ROWS_MASK) {
+            g.s += kWaveHelpers;
+            if (flat2) g.s += "\n#define SDFK_FLAT 1\n";
+            g.s += "\n#define SDFK_NP 4\n#define SDFK_EACH _Pragma(\"unroll\") for (int q = 0; q < SDFK_NP; ++q)\n"
+                   "#define SDFK_SIMT 1\n#define SDFK_NSUB 1\n";
+            g.s += kSimtGeometry;
+            g.emit_probe_leaves();
+            g.s += kRowsKernel;
+            if (all || flavour == SDFK_FL_ROWS_ARRAY || flavour == SDFK_FL_ROWS2D_ARRAY) g.s += kRowsArray;
+            if (all || flavour == SDFK_FL_ROWS_GRID || flavour == SDFK_FL_ROWS2D_GRID) g.s += kRowsGrid;
+        }
+        return g.s;
+    }
     if (plain) {
         g.s += "\ntemplate <typename T> static __device__ __forceinline__ T sdfk_point(V3T<T> C_0, "
                "const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ AUX, "

@@ -44,8 +44,17 @@ enum sdfk_flavour {
     SDFK_FL_COUNT,
     SDFK_FL_ALL = SDFK_FL_COUNT   // everything in one unit (sdfk_program_source, developer tools)
 };
+// sites: what the mask kernels use (at most 64); sites_all (optional): every site of the program — a long n-ary
+// min / max chain whose children read nothing but the input point is generated TABLE-DRIVEN from them ("chain mode":
+// one function per kind of child, loops over tables of parameter offsets; compile time and code size no longer grow
+// with the number of children, culling keeps a LIST of surviving children per brick instead of mask bits).
 std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32_t* code, size_t n_instr,
-                                 int result_reg, const std::vector<sdfk_cullsite>& sites, int flavour);
+                                 int result_reg, const std::vector<sdfk_cullsite>& sites, int flavour,
+                                 const std::vector<sdfk_cullsite>* sites_all = nullptr);
+// does the program run in chain mode? (the launcher then has no line-brick flavour and never falls back to the interpreter
+// for size)
+bool sdfk_chain_mode(const sdfk_opinfo* ops, int n_ops, const uint32_t* code, size_t n_instr, int result_reg,
+                     const std::vector<sdfk_cullsite>& sites_all);
 
 // Text every chain-specialised vector kernel starts with: sdfk_device.h followed by sdfk_vecdev.h.
 std::string sdfk_vector_prelude();

@@ -1094,3 +1094,112 @@ def test_importing_a_hip_library_during_a_background_build_does_not_deadlock(eng
                          text=True, timeout=240)
     assert res.returncode == 0, res.stderr[-2000:]
     assert "builds 1" in res.stdout
+
+
+def _chain_trees():
+    from aegolius_amd import workloads
+    rng = np.random.default_rng(5)
+
+    def boxes(n):
+        objs = []
+        for _ in range(n):
+            o = ns.Box(*rng.uniform(0.8, 1.6, 3))
+            o.rotate(float(rng.uniform(0, np.pi)), rng.normal(0, 1, 3))
+            o.move(rng.uniform(-0.2, 0.2, 3))
+            objs.append(o)
+        return ns.CombineGeometry("INTERSECT").combine(*objs)
+
+    def modified_union(n, rescale):
+        u = workloads.sphere_union(ns, n, seed=9, radius=0.08)
+        u.onion(0.01)                                             # value modifications of the result stay in the chain
+        if rescale:
+            u.rescale(1.3)                                        # the children read transformed coordinates: no chain mode
+        return u
+    return {"union_150_spheres": (workloads.sphere_union(ns, 150), False, True), "intersect_80_boxes": (boxes(80), False, True),
+            "union_130_mixed_2d": (workloads.cfg4_scene2d(ns, seed=3, count=130), True, True),
+            "union_70_onion": (modified_union(70, False), False, True),
+            "union_70_onion_rescaled": (modified_union(70, True), False, False)}
+
+
+@pytest.mark.parametrize("name", ["union_150_spheres", "intersect_80_boxes", "union_130_mixed_2d", "union_70_onion",
+                                  "union_70_onion_rescaled"])
+def test_chain_mode_is_bit_exact(name, engine):
+    """n-ary UNION / INTERSECT of more than 64 children run TABLE-DRIVEN (one function per kind of child, loops over
+    parameter-offset tables, a list of surviving children per brick instead of mask bits): the culled row-block kernel,
+    the un-culled chain kernel and the interpreter give the same bits on awkward shapes, from arrays and from axis
+    tables, and agree with the oracle."""
+    tree, flat, chain = _chain_trees()[name]
+    low = lower_geometry(tree)
+    assert len(low.cull_sites) > 64
+    prog = engine.Program.from_lowered(low)
+    # (the last tree is the fallback: more than 64 sites but no chain — the mask kernels take the 64 widest sites)
+    assert ("#define SDFK_CHAIN 1" in prog.source()) == chain
+    for shape, mis in ROW_SHAPES[:4]:
+        if flat:
+            co, _ = ns.generate_grid((10, 10), (shape[0] * shape[1] - 1, shape[2] - 1))
+        else:
+            co, _ = ns.generate_grid((2.2, 2.2, 2.2), tuple(r - 1 for r in shape))
+        co32 = co.astype(np.float32)
+        n = co32.shape[1]
+        slower = co32[0] if flat else co32[1]
+        row_len = int(np.flatnonzero(slower != slower[0])[0])
+        stride = n + 5
+        interp = _device_eval(engine, prog, co32, n, stride, mis, engine.MODE_INTERPRET)
+        plain = _device_eval(engine, prog, co32, n, stride, mis, engine.MODE_NOCULL)
+        rows = _device_eval(engine, prog, co32, n, stride, mis, engine.MODE_SPECIALIZED, row_len=row_len, flat=flat)
+        norows = _device_eval(engine, prog, co32, n, stride, mis, engine.MODE_SPECIALIZED)      # no line-brick flavour: plain
+        np.testing.assert_array_equal(plain, interp)
+        np.testing.assert_array_equal(rows, plain)
+        np.testing.assert_array_equal(norows, plain)
+        axes = [a.astype(np.float32) for a in co.grid_axes]
+        np.testing.assert_array_equal(prog.eval_grid_host(axes), plain)
+        with np.errstate(all="ignore"):
+            ref = sdf_oracle.evaluate(tree, co32.astype(np.float64))
+        err, bad = violations(rows, ref)
+        assert not bad.any(), (name, shape, float(np.nanmax(err)))
+    # scattered points under a row hint
+    rng = np.random.default_rng(12)
+    pts = rng.uniform(-1.2, 1.2, (3, 48 * 64)).astype(np.float32)
+    if flat:
+        pts[2] = 0.0
+    plain = _device_eval(engine, prog, pts, pts.shape[1], pts.shape[1], 0, engine.MODE_NOCULL)
+    rows = _device_eval(engine, prog, pts, pts.shape[1], pts.shape[1], 0, engine.MODE_SPECIALIZED, row_len=48)
+    np.testing.assert_array_equal(rows, plain)
+
+
+_FORCED_CHAIN = """
+import sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+import numpy as np
+import aegolius_amd.cores as ns
+from aegolius_amd import _engine, workloads
+from aegolius_amd._lower import lower_geometry
+import test_gpu_parity as T
+for tree, size, req, flat in [(workloads.cfg4_scene2d(ns, seed=7, count=c), (10, 10), (140, 75), True) for c in (9, 20, 50, 63, 64, 65)] + \
+                             [(workloads.sphere_union(ns, c), (2, 2, 2), (20, 33, 64), False) for c in (8, 33, 64, 65)]:
+    low = lower_geometry(tree)
+    prog = _engine.Program.from_lowered(low)
+    assert "#define SDFK_CHAIN 1" in prog.source()
+    co, _ = ns.generate_grid(size, req)
+    co32 = co.astype(np.float32)
+    n = co32.shape[1]
+    slower = co32[0] if flat else co32[1]
+    row_len = int(np.flatnonzero(slower != slower[0])[0])
+    interp = T._device_eval(_engine, prog, co32, n, n + 3, 0, _engine.MODE_INTERPRET)
+    plain = T._device_eval(_engine, prog, co32, n, n + 3, 0, _engine.MODE_NOCULL)
+    rows = T._device_eval(_engine, prog, co32, n, n + 3, 1, _engine.MODE_SPECIALIZED, row_len=row_len, flat=flat)
+    assert np.array_equal(plain, interp) and np.array_equal(rows, plain), (len(low.cull_sites) + 1, flat)
+print("ok")
+"""
+
+
+def test_chain_mode_with_few_children(engine):
+    """Chain mode forced onto short chains (SDFK_CHAIN_MIN=8: 9 to 65 children, one mask word and two): the case in
+    which a word written by one lane and read back by all without a barrier gave stale lists and a memory fault."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SDFK_CHAIN_MIN="8")
+    res = subprocess.run([sys.executable, "-c", _FORCED_CHAIN.format(root=root)], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode == 0 and res.stdout.strip().endswith("ok"), res.stderr[-3000:]

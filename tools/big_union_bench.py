@@ -1,0 +1,69 @@
+"""Developer tool (GPU): an n-ary UNION of many spheres on a resident grid — chain mode (culled row blocks, un-culled)
+against the interpreter kernel.   python tools/big_union_bench.py [--spheres 1000] [--grid 512] [--json out.json]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--spheres", type=int, default=1000)
+    ap.add_argument("--grid", type=int, default=512)
+    ap.add_argument("--json", default=None)
+    args = ap.parse_args()
+    import torch
+    import aegolius_amd.cores as ns
+    from aegolius_amd import _engine, workloads
+    from aegolius_amd._lower import lower_geometry
+    from aegolius_amd.cores.helper_functions import grid_axes
+    tree = workloads.sphere_union(ns, args.spheres)
+    t0 = time.perf_counter()
+    low = lower_geometry(tree)
+    prog = _engine.Program.from_lowered(low)
+    t_lower = time.perf_counter() - t0
+    axes = [a.astype(np.float32) for a in grid_axes((2, 2, 2), (args.grid,) * 3)[0]]
+    n = int(np.prod([a.size for a in axes]))
+    stride = (n + 255) // 256 * 256
+    dev = torch.device("cuda", 0)
+    co = torch.empty((3, stride), dtype=torch.float32, device=dev)
+    outs = {k: torch.empty((stride,), dtype=torch.float32, device=dev) for k in ("culled", "plain", "interp")}
+    stream = torch.cuda.current_stream().cuda_stream
+    _engine.grid_fill(co.data_ptr(), stride, axes, 0, n, stream=stream)
+    row_len = int(axes[2].size)
+    res = {"workload": "n-ary UNION of %d spheres" % args.spheres, "instructions": int(low.code.shape[0]),
+           "cull_sites": int(len(low.cull_sites)), "grid": "%d^3" % axes[0].size, "points": n,
+           "chain_mode": "#define SDFK_CHAIN 1" in prog.source(), "lower_and_program_s": t_lower}
+    for key, mode, rows, reps in (("culled", _engine.MODE_SPECIALIZED, True, 5), ("plain", _engine.MODE_NOCULL, False, 2),
+                                  ("interp", _engine.MODE_INTERPRET, False, 1)):
+        def step():
+            prog.eval_device(co.data_ptr(), n, stride, outs[key].data_ptr(), stream=stream, mode=mode,
+                             row_len=row_len if rows else None)
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        first = time.perf_counter() - t0
+        best = 1e30
+        for _ in range(reps):
+            e0, e1 = _engine.Event(), _engine.Event()
+            e0.record(stream)
+            step()
+            e1.record(stream)
+            best = min(best, e0.elapsed_ms(e1))
+        res[key] = {"ms": best, "first_call_s": first, "mpoints_per_s": n / best / 1e3,
+                    "frac_of_hbm_roofline": 16.0 * n / (best * 1e-3) / 8e12}
+        print(key, res[key], flush=True)
+    res["bit_identical"] = bool(torch.equal(outs["culled"][:n], outs["plain"][:n]) and torch.equal(outs["plain"][:n], outs["interp"][:n]))
+    print(json.dumps(res))
+    if args.json:
+        json.dump(res, open(args.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
