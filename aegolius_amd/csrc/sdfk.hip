@@ -585,6 +585,10 @@ static int rows_wbricks(const sdfk_program* p) {
     static int forced = [] { const char* e = getenv("SDFK_RWBRICKS"); int t = e ? atoi(e) : 0; return (t >= 1 && t <= 16) ? t : 0; }();
     if (const int o = g_rwbricks_override.load()) return o;
     if (forced) return forced;
+    // chain mode (measured, 513^3 sphere unions and the 50-child flat union): every brick of a wave costs a fold and an
+    // evaluation pass one after the other, and the leaf values take 6 bytes of LDS per child and brick — few bricks per
+    // wave win: 1000 spheres 21.9 / 11.4 / 5.5 ms with 4 / 2 / 1, the flat union 1.08 / 0.99 / 1.03 ms
+    if (p && p->chain_mode) return p->sites_all.size() + 1 <= 64 ? 2 : 1;
     return (p && p->code.size() / 2 > 150) ? 4 : 2;
 }
 struct RowGeom {           // mirrors sdfk_rowgeom of the generated source

@@ -1312,11 +1312,14 @@ struct Gen {
     // every (leaf, centre) pair on a lane of its own: leafval[leaf][centre] = leaf(centre)
     void emit_probe_leaves() {
         char buf[640];
-        s += "\nstatic __device__ __forceinline__ void sdfk_probe_leaves(const float4* __restrict__ cen, float* __restrict__ leafval, "
+        // (several rounds of a big group in flight at once: each round is two dependent memory round trips — the offsets,
+        //  then the parameters — and nothing else hides them)
+        s += "\n#ifndef SDFK_LEAF_UNROLL\n#define SDFK_LEAF_UNROLL _Pragma(\"unroll 1\")\n#endif\n";
+        s += "static __device__ __forceinline__ void sdfk_probe_leaves(const float4* __restrict__ cen, float* __restrict__ leafval, "
              "const float* __restrict__ PRM, const float* __restrict__ TAB) {\n";
         for (size_t g = 0; g < groups.size(); ++g) {
             snprintf(buf, sizeof buf,
-                     "    _Pragma(\"unroll 1\") for (unsigned item = sdfk_tx(); item < %zuu * SDFK_NCEN; item += 64u * SDFK_RWAVES) {\n"
+                     "    SDFK_LEAF_UNROLL for (unsigned item = sdfk_tx(); item < %zuu * SDFK_NCEN; item += 64u * SDFK_RWAVES) {\n"
                      "        unsigned m = item / SDFK_NCEN;\n"
                      "        if (SDFK_NCEN %% 64 == 0) m = __builtin_amdgcn_readfirstlane(m);   // one member per wave: scalar parameter loads\n"
                      "        const unsigned c = item - m * SDFK_NCEN;\n"
@@ -1716,12 +1719,14 @@ struct Gen {
 
 }  // namespace
 
-// leaves beyond which an n-ary min / max chain is generated table-driven (SDFK_CHAIN_MIN overrides: tests)
+// leaves from which an n-ary min / max chain is generated table-driven (SDFK_CHAIN_MIN overrides: tests). Measured on
+// the 50-child flat union at 16385^2: the table-driven kernel runs as fast as the fully specialised one (1.08 vs 1.07 ms)
+// and builds in 1.5 s instead of 12 s, so short chains go this way too; below ~16 children the specialised code wins.
 static size_t chain_min_leaves() {
     static const size_t v = [] {
         const char* e = getenv("SDFK_CHAIN_MIN");
         const long t = e ? atol(e) : 0;
-        return (size_t)(t >= 2 ? t : 65);
+        return (size_t)(t >= 2 ? t : 17);
     }();
     return v;
 }
@@ -1770,7 +1775,8 @@ std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32
             g.s += kWaveHelpers;
             if (flat2) g.s += "\n#define SDFK_FLAT 1\n";
             g.s += "\n#define SDFK_NP 4\n#define SDFK_EACH _Pragma(\"unroll\") for (int q = 0; q < SDFK_NP; ++q)\n"
-                   "#define SDFK_SIMT 1\n#define SDFK_NSUB 1\n";
+                   "#define SDFK_SIMT 1\n#define SDFK_NSUB 1\n"
+                   "#ifndef SDFK_LEAF_UNROLL\n#define SDFK_LEAF_UNROLL _Pragma(\"unroll 4\")\n#endif\n";
             g.s += kSimtGeometry;
             g.emit_probe_leaves();
             g.s += kRowsKernel;
