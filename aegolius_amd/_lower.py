@@ -141,11 +141,80 @@ class Lowerer:
         self._affine[len(self.code)] = (A, c, self.lip_c.get(b, _lip.INF))
         self.emit(name, a, b, params=prm, _fold=False)
 
+    # float64 limits of the exponent of the strictly positive value maps (C/post_processing.py:380-429, 526-558):
+    # exp(t) is non-zero down to t = -745.13; 1 + exp(x) is finite up to x = 709.78
+    _EXP_ZERO, _EXP_INF = -745.13, -709.78
+
+    def _fold_positive_map(self, opname, a, b, params):
+        """sign(v) / hard_binarization(v, 0) right after a strictly positive value map on the same register: in the
+        reference (float64) the map only reaches 0 where exp underflows at an exponent of -745; in fp32 it is 0 from -103
+        on, and the sign of the fp32 value would be 0 where the reference has 1 (fuzz seeds 70109 / 70139 / 70197 of
+        round 2: off by 1.0 at > 1000 points). The pair becomes ONE operator that decides on the exponent
+        (csrc/sdfk_device.h val_expflag). Returns True when it has emitted it."""
+        if a != b or not self.code:
+            return False
+        if opname == "VHARDBIN" and params[0] != 0.0:
+            return False
+        last = len(self.code) - 1
+        if last < self._fold_floor:
+            return False
+
+        def positive_map(i, reg):
+            """parameter block of the exponent test if instruction i is a positive map applied in place to V[reg]"""
+            w, poff = self.code[i]
+            name = _ops.OPS[w & 255].name
+            if name not in ("VGAUSS", "VCAPEXP", "VSIGMOID") or (w >> 8) & 255 != reg or (w >> 16) & 255 != reg:
+                return None
+            lp = self.params[poff:poff + 3]
+            if not (lp[0] > 0.0 and np.isfinite(lp[0]) and np.isfinite(lp[1])):
+                return None
+            if name == "VGAUSS":
+                return [0.0, lp[1], lp[2], self._EXP_ZERO]
+            if name == "VCAPEXP":
+                return [1.0, lp[1], 0.0, self._EXP_ZERO]
+            return [2.0, lp[1], lp[2], self._EXP_INF]
+
+        block = positive_map(last, a)
+        if block is not None:
+            # sign: 1 while the map is non-zero, 0 once it has underflowed; hard_binarization(v <= 0): the other way round
+            block += [1.0, 0.0] if opname == "VSIGN" else [0.0, 1.0]
+            lpoff = self.code[last][1]
+            self.code.pop()
+            del self.params[lpoff:]
+            self.emit("VEXPFLAG", a, a, params=block, _fold=False)
+            return True
+        # sign(map * g) (recover_volume / define_volume of a mapped field, C/modifications.py:325-369): the sign of the
+        # product is the sign of g while the map is non-zero in float64 and 0 once it has underflowed there — the map is
+        # replaced IN PLACE by its 1 / 0 flag (new parameters at the end of the table) and product and sign stay
+        lw = self.code[last][0]
+        if opname != "VSIGN" or _ops.OPS[lw & 255].name != "VMUL" or (lw >> 8) & 255 != a:
+            return False
+        for reg in {(lw >> 16) & 255, lw >> 24}:
+            for j in range(last - 1, -1, -1):
+                w = self.code[j][0]
+                kind = _ops.OPS[w & 255].kind
+                if kind == "C_C":
+                    continue
+                if (w >> 8) & 255 == reg:                         # the instruction that defines this factor
+                    block = positive_map(j, reg)
+                    if block is not None:
+                        self.code[j] = (_ops.BY_NAME["VEXPFLAG"].code | (reg << 8) | (reg << 16), len(self.params))
+                        self.params.extend(block + [1.0, 0.0])
+                        self.lip_v[reg] = _lip.INF
+                        return False                              # (the sign itself is still emitted)
+                    break
+                if (kind == "V_V" and (w >> 16) & 255 == reg) or \
+                        (kind == "V_VV" and reg in ((w >> 16) & 255, w >> 24)):
+                    break                                          # somebody else reads the factor in between
+        return False
+
     def emit(self, opname, a, b=0, c=0, params=(), _fold=True):
         info = _ops.BY_NAME[opname]
         params = [float(x) for x in np.asarray(params, dtype=np.float64).ravel()]
         if len(params) != info.nparams:
             raise LoweringError("%s expects %d parameters, got %d" % (opname, info.nparams, len(params)))
+        if _fold and opname in ("VSIGN", "VHARDBIN") and self._fold_positive_map(opname, a, b, params):
+            return
         if _fold and opname in self._AFFINE:
             # Consecutive affine maps on the same register (nested Euclidean transforms, move_sdf / scale_sdf /
             # shear chains) are composed here in float64 and rounded ONCE: g(f(p)) = A2 A1 p - (A2 c1 + c2).

@@ -857,6 +857,27 @@ SDFK_DEV float val_gauss(float v, const float* __restrict__ P) {
     return P[0] * expf(-4.0f * (u * u));
 }
 
+// sign() / hard_binarization(. , 0) of a value map that is strictly positive in exact arithmetic — A exp(-4 (v/w)^2),
+// A min(exp(-4 v / w), 1), A / (1 + exp(4 (v - shift) / w)) with A > 0 (C/post_processing.py:380-429, 526-558). The
+// reference computes the map in float64, where exp reaches zero at an exponent of -745.13 (and 1 + exp(x) infinity at
+// x = 709.78); in fp32 the map is zero from -103 on, so sign(map) would be 0 where the reference still has 1 (|v / w|
+// between 5.1 and 13.6 for the Gaussian). The lowering (aegolius_amd/_lower.py, Lowerer.emit) therefore replaces the
+// pair by this operator, which compares the EXPONENT with float64's limit.
+// P = (kind: 0 Gaussian, 1 capped exponential, 2 sigmoid; scale; clamp flag | shift; limit; result while non-zero; result at zero)
+SDFK_DEV float val_expflag(float v, const float* __restrict__ P) {
+    float t;
+    if (P[0] == 0.0f) {                      // (wave-uniform: parameters)
+        float u = (P[2] != 0.0f) ? sd_max(v, 0.0f) : v;
+        u = u * P[1];
+        t = -4.0f * (u * u);
+    } else if (P[0] == 1.0f) {
+        t = v * P[1];
+    } else {
+        t = -((v - P[2]) * P[1]);
+    }
+    return (t >= P[3]) ? P[4] : P[5];
+}
+
 // =============================================================================================
 // (value, value) -> value     signature: float f(float a, float b, const float* P)
 // =============================================================================================
@@ -936,7 +957,7 @@ SDFK_PAIR_V_C(prim_nearest3) SDFK_PAIR_V_C(prim_neucircle) SDFK_PAIR_V_C(prim_se
 SDFK_PAIR_V_C(prim_triangle2) SDFK_PAIR_V_C(prim_arc2) SDFK_PAIR_V_C(prim_sector) SDFK_PAIR_V_C(prim_infsector)
 SDFK_PAIR_V_C(prim_ngon) SDFK_PAIR_V_C(prim_segline2) SDFK_PAIR_V_C(prim_nearest2) SDFK_PAIR_V_C(prim_polysign)
 SDFK_PAIR_V_C(prim_shapesign) SDFK_PAIR_V_C(prim_neartree)
-SDFK_PAIR_V_V(val_sigmoid) SDFK_PAIR_V_V(val_capexp) SDFK_PAIR_V_V(val_hardbin) SDFK_PAIR_V_V(val_gauss)
+SDFK_PAIR_V_V(val_sigmoid) SDFK_PAIR_V_V(val_capexp) SDFK_PAIR_V_V(val_hardbin) SDFK_PAIR_V_V(val_gauss) SDFK_PAIR_V_V(val_expflag)
 SDFK_PAIR_V_VV(cmb_boltz) SDFK_PAIR_V_VV(cmb_boltzsub)
 
 #endif  // SDFK_DEVICE_H

@@ -23,7 +23,7 @@ def main(cases=80):
     lib = _engine.lib()
     vp = _engine._vp
     rng = np.random.default_rng(77)
-    trees = [scenes.cfg2_tree(ns), scenes.cfg5_tree(ns), scenes.SCENES["tree_pawn_like"](ns), scenes.random_tree(ns, 9002, 4)]
+    trees = [scenes.cfg2_tree(ns), scenes.cfg5_tree(ns), scenes.SCENES["tree_pawn_3D"](ns), scenes.random_tree(ns, 9002, 4)]
     progs = [_engine.Program.from_lowered(lower_geometry(t)) for t in trees]
     cap = 1 << 21
     d_co, d_out = lib.sdfk_malloc((3 * cap + 64) * 4), lib.sdfk_malloc((cap + 64) * 4)

@@ -16,6 +16,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))     # the repository root: tests/scenes.py takes its recipes from aegolius_amd/workloads.py
 sys.dont_write_bytecode = True
 
 

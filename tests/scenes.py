@@ -407,47 +407,13 @@ scene("tree_cfg4_union50_2d", True)(cfg4_scene2d)
 scene("tree_cfg5_three_level")(cfg5_tree)
 
 
-@scene("tree_pawn_like")
-def _(ns):
-    body = ns.Cone(1.2, np.pi / 9)
-    body.move((0, 0, 0.2))
-    head = ns.Sphere(0.25)
-    head.move((0, 0, 0.55))
-    base = ns.Cylinder(0.45, 0.15)
-    base.rounding(0.03)
-    base.move((0, 0, -0.7))
-    collar = ns.Torus(0.2, 0.05)
-    collar.move((0, 0, 0.3))
-    t = ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(body, head, parameters=0.1)
-    t = ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(t, base, parameters=0.2)
-    t = ns.CombineGeometry("UNION2").combine(t, collar)
-    cut = ns.Box(2.0, 2.0, 0.3)
-    cut.move((0, 0, -0.95))
-    return ns.CombineGeometry("SUBTRACT2").combine(t, cut)
+# the reference's own example scenes (Code/examples/scalar/3D/pawn_3D.py, chip_3D.py, 2D/olympic_rings_2D.py): the builders
+# are proven equal to the scripts by tests/golden/generate_example_golden.py; here on the shared input cloud
+import example_scenes  # noqa: E402
 
-
-@scene("tree_chip_like")
-def _(ns):
-    body = ns.Box(1.2, 0.8, 0.2)
-    body.rounding_cs(0.04, 1.2)
-    pin = ns.Box(0.08, 0.3, 0.05)
-    pin.move((0.0, 0.5, 0.0))
-    pins = ns.GenericGeometry(pin.propagate, ())
-    pins.symmetry(1)
-    pins.finite_repetition((1.0, 3.0, 1.0), (5, 1, 1))
-    pins.move((0.0, 0.0, -0.05))
-    return placed(ns.CombineGeometry("UNION2").combine(body, pins), angle=0.3, axis=(1, 0, 0), move=(0, 0, 0.1))
-
-
-@scene("tree_rings_2d")
-def _(ns):
-    rings = []
-    for k in range(5):
-        c = ns.Circle(0.3)
-        c.onion(0.03)
-        c.move((-0.7 + 0.35 * k, 0.15 * (-1) ** k, 0))
-        rings.append(c)
-    return ns.CombineGeometry("UNION").combine(*rings)
+scene("tree_pawn_3D")(example_scenes.pawn)
+scene("host_chip_3D")(example_scenes.chip)          # (a Python callable as displacement: host stage)
+scene("tree_olympic_rings_2D")(example_scenes.olympic_rings)
 
 
 @scene("tree_deep_right")
@@ -669,6 +635,56 @@ def _(ns):
 # -------------------------------------------------------------------------------------------------
 GRIDS = {"g3": ((2.0, 2.0, 2.0), (14, 12, 10)), "g2": ((3.0, 3.0), (30, 24))}
 GRID_SCENES = {}
+
+# -------------------------------------------------------------------------------------------------
+# the fp32 RANGE class: sign() / hard_binarization(0) of a value map that is strictly positive in exact arithmetic. The
+# reference (float64) keeps a tiny positive number where fp32 underflows to 0, so the sign of the fp32 value would be
+# off by 1.0; the lowering decides on the exponent instead (Lowerer._fold_positive_map). The three random chains are
+# the cases the round-2 fuzzer flagged (tests/fuzz_mods.py seeds 70109 / 70139 / 70197).
+# -------------------------------------------------------------------------------------------------
+def _fuzz_mods_scene(seed):
+    def build(ns):
+        import sys
+        import fuzz_mods
+        return fuzz_mods.build(ns, sys.modules[__name__], seed)[0]
+    return build
+
+
+for _seed in (70109, 70139, 70197):
+    scene("range_fuzz_mods_%d" % _seed, True)(_fuzz_mods_scene(_seed))
+
+
+@scene("range_gaussian_boundary_sign", True)
+def _(ns):
+    s = ns.Sphere(0.5)                      # |v / w| up to 30: fp32 underflows at 5.1, float64 at 13.6
+    s.gaussian_boundary(2.0, 0.1)
+    s.sign()
+    return placed(s)
+
+
+@scene("range_gaussian_falloff_hardbin", True)
+def _(ns):
+    b = ns.Box(0.6, 0.5, 0.4)
+    b.gaussian_falloff(0.7, 0.08)
+    b.hard_binarization(0.0)
+    return placed(b)
+
+
+@scene("range_capped_exponential_sign", True)
+def _(ns):
+    t = ns.Torus(0.5, 0.1)
+    t.capped_exponential(1.5, 0.004)        # exponent -4 v / w down to -3000: beyond float64's -745 too
+    t.sign()
+    return placed(t)
+
+
+@scene("range_sigmoid_sign", True)
+def _(ns):
+    c = ns.Cylinder(0.3, 0.8)
+    c.sigmoid_falloff(1.0, 0.005)           # 1 + exp(4 v / w) overflows in fp32 at v / w = 22, in float64 at 177
+    c.sign()
+    return placed(c)
+
 
 
 def grid_scene(name, grid, discontinuous=False):

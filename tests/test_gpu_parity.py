@@ -429,7 +429,7 @@ def test_single_process_sharded_grid(engine):
         prog.eval_grid_sharded(axes, 2, devices=[0, 99])
 
 
-CULL_SCENES = ["tree_cfg2_smooth_union10", "tree_cfg5_three_level", "tree_cfg4_union50_2d", "tree_pawn_like",
+CULL_SCENES = ["tree_cfg2_smooth_union10", "tree_cfg5_three_level", "tree_cfg4_union50_2d", "tree_pawn_3D",
                "tree_deep_right", "combine_SMOOTH_SUBTRACT2", "combine_SUBTRACT2", "combine_INTERSECT_nary",
                "combine_SMOOTH_INTERSECT2", "combine_modified_result", "alias_symmetry_in_child_not_visible"]
 

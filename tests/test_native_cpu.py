@@ -59,7 +59,7 @@ def test_every_scene_lowers_to_a_valid_program(name, built):
 
 @pytest.mark.parametrize("name", ["tree_cfg2_smooth_union10", "tree_cfg3_mod_chain", "tree_cfg4_union50_2d",
                                   "tree_cfg5_three_level", "prim_polygon_concave", "mod_fully_aligned_curve_instancing",
-                                  "alias_rotsym_recover", "prim_quad", "tree_deep_right", "tree_pawn_like",
+                                  "alias_rotsym_recover", "prim_quad", "tree_deep_right", "tree_pawn_3D",
                                   "combine_SMOOTH_SUBTRACT2", "combine_INTERSECT_nary", "combine_modified_result"])
 def test_specialised_kernel_compiles_for_gfx950(name, built):
     low = lower_geometry(scenes.SCENES[name](ns))
