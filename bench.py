@@ -65,37 +65,64 @@ def build_workload(name, ns):
     return workloads.build(name, ns)
 
 
-def cpu_baseline(workload, axes, budget_s):
-    """Oracle (float64 NumPy restatement of the reference, same operation order and temporaries)
-    on whole x-planes of the same grid, default NumPy/BLAS threading."""
+def _cpu_plane_worker(args):
+    """One x-plane of the grid through the oracle (a worker process of cpu_baseline: NumPy only, no GPU)."""
+    workload, x, ax1, ax2 = args
     import aegolius_amd.cores as ns
     from oracle import sdf_oracle
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:  # noqa: BLE001
-        threads = os.cpu_count() or 1
-    tree, _size, _desc = build_workload(workload, ns)
-    ny, nz = axes[1].size, axes[2].size
+    tree = _CPU_TREES.get(workload)
+    if tree is None:
+        tree = _CPU_TREES[workload] = build_workload(workload, ns)[0]
+    ny, nz = ax1.size, ax2.size
     plane = np.empty((3, ny * nz))
-    plane[1] = np.repeat(axes[1].astype(np.float64), nz)
-    plane[2] = np.tile(axes[2].astype(np.float64), ny)
-    done_pts, spent, k = 0, 0.0, 0
-    order = np.linspace(0, axes[0].size - 1, min(axes[0].size, 64)).astype(int)   # planes spread over the grid
-    while k < len(order):
-        plane[0] = float(axes[0][order[k]])
-        t0 = time.perf_counter()
-        with np.errstate(all="ignore"):
-            sdf_oracle.evaluate(tree, plane)
-        dt = time.perf_counter() - t0
-        spent += dt
-        done_pts += plane.shape[1]
-        k += 1
-        if spent + dt > budget_s:
-            break
-    return {"value": done_pts / spent / 1e6, "unit": "Mpoints/s", "cores": int(threads), "kind": "port",
-            "sample": "%d x-planes of %dx%d points of the same grid (%.1f s)" % (k, ny, nz, spent),
-            "host_cpus": os.cpu_count()}
+    plane[0] = x
+    plane[1] = np.repeat(ax1.astype(np.float64), nz)
+    plane[2] = np.tile(ax2.astype(np.float64), ny)
+    t0 = time.perf_counter()
+    with np.errstate(all="ignore"):
+        sdf_oracle.evaluate(tree, plane)
+    return time.perf_counter() - t0
+
+
+_CPU_TREES = {}
+
+
+def cpu_baseline(workload, axes, budget_s):
+    """Oracle (float64 NumPy restatement of the reference, same operation order and temporaries) on whole x-planes of
+    the same grid. The reference's NumPy path is single-threaded but for a 3x3 BLAS product, so the host's cores are used
+    the way a user of the reference would use them: one process per core of this GPU's share of the host (16), each
+    evaluating planes with one BLAS thread. `single_process` is one process with NumPy's default threading."""
+    import multiprocessing as mp
+    cores = max(1, min(16, os.cpu_count() or 1))
+    ny, nz = int(axes[1].size), int(axes[2].size)
+    order = np.linspace(0, axes[0].size - 1, min(axes[0].size, 4096)).astype(int)       # planes spread over the grid
+    t1 = _cpu_plane_worker((workload, float(axes[0][order[0]]), axes[1], axes[2]))      # one plane, this process
+    single = {"value": ny * nz / t1 / 1e6, "unit": "Mpoints/s", "planes": 1}
+    per_core = max(1, int(0.8 * budget_s / max(t1, 1e-3)))
+    planes = [float(axes[0][order[(7 * k) % len(order)]]) for k in range(per_core * cores)]
+    saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+    os.environ.update({k: "1" for k in saved})
+    try:
+        # (a ProcessPoolExecutor: a worker that cannot start raises BrokenProcessPool instead of being respawned for ever;
+        #  spawn, not fork: this process holds a GPU)
+        from concurrent.futures import ProcessPoolExecutor
+        with ProcessPoolExecutor(cores, mp_context=mp.get_context("spawn")) as pool:
+            warm = [(workload, planes[0], axes[1], axes[2])] * cores
+            list(pool.map(_cpu_plane_worker, warm, timeout=120 + 20 * t1))                   # imports, tree: not timed
+            t0 = time.perf_counter()
+            busy = list(pool.map(_cpu_plane_worker, [(workload, x, axes[1], axes[2]) for x in planes], chunksize=1,
+                                 timeout=120 + 3 * budget_s))
+            wall = time.perf_counter() - t0
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return {"value": len(planes) * ny * nz / wall / 1e6, "unit": "Mpoints/s", "cores": cores, "kind": "port",
+            "sample": "%d x-planes of %dx%d points of the same grid on %d worker processes (%.1f s wall, %.1f s of "
+                      "oracle time)" % (len(planes), ny, nz, cores, wall, float(np.sum(busy))),
+            "single_process": single, "host_cpus": os.cpu_count()}
 
 
 def verify_sample(workload, axes, start, out, count, samples=20000, seed=11):

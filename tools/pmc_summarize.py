@@ -13,7 +13,11 @@ def collect(root, kernel):
     for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
             for row in csv.DictReader(f):
-                if row.get("Kernel_Name", "").split("(")[0].strip() != kernel:      # exact name, not a prefix
+                name_ = row.get("Kernel_Name", "").split("(")[0].strip()
+                if kernel.startswith("~"):                                          # "~text": any kernel whose name contains text
+                    if kernel[1:] not in name_:                                     # (template kernels: "void f<1>")
+                        continue
+                elif name_ != kernel:                                               # exact name, not a prefix
                     continue
                 name, val = row["Counter_Name"], float(row["Counter_Value"])
                 did = row.get("Dispatch_Id")
@@ -30,6 +34,8 @@ def main(root, kernel="sdfk_spec_v4", out=None):
         rec["hbm_read_bytes_per_launch"] = avg["FETCH_SIZE"] * 1024 * 2
         rec["hbm_write_bytes_per_launch"] = avg["WRITE_SIZE"] * 1024
         rec["hbm_bytes_per_launch"] = rec["hbm_read_bytes_per_launch"] + rec["hbm_write_bytes_per_launch"]
+    if "TCC_HIT_sum" in avg and "TCC_MISS_sum" in avg:
+        rec["l2_hit_rate"] = avg["TCC_HIT_sum"] / max(1.0, avg["TCC_HIT_sum"] + avg["TCC_MISS_sum"])
     if "SQ_ACTIVE_INST_VALU" in avg and "GRBM_GUI_ACTIVE" in avg:
         # SQ_ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs; GRBM_GUI_ACTIVE is the sum over the 8 XCDs
         rec["valu_active_frac"] = avg["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * avg["GRBM_GUI_ACTIVE"] / 8.0)
