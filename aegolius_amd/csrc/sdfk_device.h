@@ -97,6 +97,10 @@ SDFK_DEV V3 sd_hi(V3P p) { V3 r = {p.x.y, p.y.y, p.z.y}; return r; }
 SDFK_DEV V3P sd_join(V3 a, V3 b) { V3P r = {{a.x, b.x}, {a.y, b.y}, {a.z, b.z}}; return r; }
 // np.mod(a, d): floored modulo, result carries the sign of the divisor. inv_d = 1/d (host, f64->f32).
 // One fma recovers a - q*d exactly once q is right; the two fix-ups repair an off-by-one q.
+// (Round 3, measured on the modification-chain config at 1025^3, four variants in one process: a branch-free form of
+//  the fix-ups — sign folded in with xor, no scalar branch on d — has fewer instructions in the listing but executes
+//  more of them, 3.64 against 3.50 ms; sincos / atan2 on packed pairs (v_pk_fma for reduction and polynomials) 3.73 ms:
+//  the packed forms need their constants in SGPR pairs and cost 1.3 plain issues each. Both were removed again.)
 SDFK_DEV float sd_mod(float a, float d, float inv_d) {
     float q = __builtin_floorf(a * inv_d);
     float r = sd_fma(-q, d, a);
