@@ -29,8 +29,11 @@ extern "C" {
 #define SDFK_MODE_AUTO 0        /* topology-specialised kernel (hiprtc): only the kernel flavour a call launches is built,
                                    in a background thread, and cached (per process and on disk); until it is ready calls
                                    are served by the interpreter kernel (bit-identical results; SDFK_ASYNC_JIT=0: wait
-                                   instead). Programs beyond SDFK_SPECIALIZE_LIMIT (env, default 1200) instructions stay
-                                   on the interpreter kernel */
+                                   instead). The background build runs in a CHILD PROCESS (aegolius_amd/sdfk_rtc_helper:
+                                   hiprtc inside the caller deadlocks against a dlopen of any HIP library on another
+                                   thread); without the helper the first call waits. Programs beyond
+                                   SDFK_SPECIALIZE_LIMIT (env, default 1200) instructions stay on the interpreter kernel
+                                   unless they run in chain mode (sdfk_program_set_cull) */
 #define SDFK_MODE_INTERPRET 1   /* generic register-machine interpreter kernel */
 #define SDFK_MODE_SPECIALIZED 2 /* wait for the specialised kernel; fail instead of falling back if hiprtc fails */
 #define SDFK_MODE_NOCULL 3      /* specialised kernel with brick culling switched off (A/B runs, tests) */
@@ -58,13 +61,19 @@ sdfk_program* sdfk_program_create(const uint32_t* code, size_t n_instr, const fl
 void sdfk_program_destroy(sdfk_program* prog);
 /* Replace the parameter values of a program in place (same topology, new shape parameters). */
 int sdfk_program_set_params(sdfk_program* prog, const float* params, size_t n_params);
-/* Brick culling (optional, before first use of the program): n_sites rows (at most 64) {combiner index, a_start,
+/* Brick culling (optional, before first use of the program): n_sites rows (at most 4095) {combiner index, a_start,
  * a_end, b_start, b_end} naming, for min/max-type combiners, the instruction ranges that produce the
  * two operands, and k[i] = L_a + L_b, the sum of the Lipschitz constants of the operand fields with
- * respect to the input point. The specialised kernel then evaluates the tree once per brick of 128
- * consecutive points and skips operand subtrees that provably cannot change the result on that brick;
- * results are bit-identical to the un-culled evaluation. Sites whose ranges have side effects on
- * registers read later are kept but never skipped. */
+ * respect to the input point. The specialised kernels then probe the tree per BRICK — 32 points x 16 grid rows when the
+ * caller gives the row length (sdfk_eval_device_rows, grids), 128 consecutive points otherwise — and skip operand
+ * subtrees that provably cannot change the result on that brick; results are bit-identical to the un-culled
+ * evaluation. Sites whose ranges have side effects on registers read later are kept but never skipped.
+ * How the sites are used: up to 64 of them as two mask bits each (the widest, in program order; the line-brick kernel
+ * takes 31). The probe runs lane-parallel when every leaf range (a range without a site inside) reads nothing but the
+ * input point: all leaves at all probe centres on the lanes of the workgroup, 8 / 4 / 1 centres per brick. A program
+ * that is ONE n-ary hard min / max over 17 to 2048 such leaves (CombineGeometry("UNION").combine(*many)) runs in
+ * "chain mode" with all of its sites: one function per kind of leaf, tables of parameter offsets, a list of surviving
+ * leaves per brick; it builds in about a second whatever its size. */
 int sdfk_program_set_cull(sdfk_program* prog, const uint32_t* sites, size_t n_sites, const float* k);
 /* Generated HIP source of the specialised kernel (for inspection / tests); NULL on error. */
 const char* sdfk_program_source(sdfk_program* prog);
