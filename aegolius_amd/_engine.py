@@ -59,6 +59,11 @@ SIGNATURES = {
     "sdfk_field_select": (_int, [_vp, _i64, _c.c_float, _vp, _i64, _c.POINTER(_i64), _vp, _vp]),
     "sdfk_field_select_finish": (_int, [_i64, _i64, _vp, _i64, _vp, _vp]),
     "sdfk_field_gradient": (_int, [_vp, _i64, _i64, _i64, _int, _int, _vp, _i64, _vp]),
+    "sdfk_eval_select_scratch": (_sz, [_i64]),
+    "sdfk_eval_device_select": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _c.c_float, _vp, _i64, _c.POINTER(_i64), _vp, _vp, _int]),
+    "sdfk_eval_grid_select": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _c.c_float, _vp, _i64, _c.POINTER(_i64),
+                                     _vp, _vp, _int]),
+    "sdfk_eval_select_finish": (_int, [_i64, _i64, _vp, _i64, _vp, _vp]),
     "sdfk_vec_eval_device": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _i64, _int, _vp, _i64, _vp]),
     "sdfk_vec_set_interpret": (None, [_int]),
     "sdfk_vec_source": (_c.c_char_p, [_vp, _int, _int, _int]),
@@ -263,6 +268,84 @@ class Program:
         ax = [np.ascontiguousarray(a, dtype=np.float32) for a in axes]
         check(lib().sdfk_eval_grid(self._h, _ptr(ax[0]), ax[0].size, _ptr(ax[1]), ax[1].size, _ptr(ax[2]),
                                    ax[2].size, start, count, _vp(d_out), _vp(stream or 0), mode), "sdfk_eval_grid")
+
+    def _select(self, n, first, device):
+        """Two-step protocol of the fused selection: `first(d_scratch, byref(count))` evaluates into flags and counts;
+        the indices follow from the flags. -> ascending int64 host array."""
+        require_gpu()
+        L = lib()
+        check(L.sdfk_set_device(int(device)), "sdfk_set_device")
+        m = _i64(0)
+        d_scratch = L.sdfk_malloc(L.sdfk_eval_select_scratch(n))
+        d_index = None
+        try:
+            if not d_scratch:
+                raise SdfkError("select: out of device memory")
+            first(_vp(d_scratch), ctypes.byref(m))
+            out = np.empty(m.value, dtype=np.int64)
+            if m.value:
+                d_index = L.sdfk_malloc(m.value * 8)
+                if not d_index:
+                    raise SdfkError("select: out of device memory")
+                check(L.sdfk_eval_select_finish(n, m.value, _vp(d_index), m.value, _vp(d_scratch), None),
+                      "sdfk_eval_select_finish")
+                check(L.sdfk_memcpy_d2h(_ptr(out), _vp(d_index), out.size * 8), "sdfk_memcpy_d2h")
+            return out
+        finally:
+            for d in (d_scratch, d_index):
+                if d:
+                    L.sdfk_free(_vp(d))
+
+    def select_grid(self, axes, threshold=0.0, start=0, count=None, device=0, mode=MODE_AUTO):
+        """numpy.flatnonzero(field <= threshold) of the grid spanned by three per-axis tables, WITHOUT a field: the
+        evaluation kernels write one flag bit per point, the compaction reads the flags (sdfk_eval_grid_select)."""
+        ax = [np.ascontiguousarray(a, dtype=np.float32) for a in axes]
+        total = ax[0].size * ax[1].size * ax[2].size
+        count = total - start if count is None else count
+
+        def first(d_scratch, m):
+            check(lib().sdfk_eval_grid_select(self._h, _ptr(ax[0]), ax[0].size, _ptr(ax[1]), ax[1].size, _ptr(ax[2]),
+                                              ax[2].size, start, count, float(threshold), None, 0, m, d_scratch, None,
+                                              mode), "sdfk_eval_grid_select")
+        return self._select(count, first, device)
+
+    def select_host(self, co, threshold=0.0, device=0, mode=MODE_AUTO):
+        """The same for a (3, N) host array (uploaded once as float32; the row-length hint is detected like create())."""
+        require_gpu()
+        co = np.asarray(co)
+        if co.ndim != 2 or co.shape[0] != 3:
+            raise ValueError("coordinates must have shape (3, N); got %r" % (co.shape,))
+        co32 = np.ascontiguousarray(co, dtype=np.float32)
+        n = co32.shape[1]
+        if n == 0:
+            return np.empty(0, dtype=np.int64)
+        L = lib()
+        check(L.sdfk_set_device(int(device)), "sdfk_set_device")
+        stride = (n + 63) // 64 * 64
+        d_co = L.sdfk_malloc(3 * stride * 4)
+        if not d_co:
+            raise SdfkError("select: out of device memory")
+        try:
+            for r in range(3):
+                check(L.sdfk_memcpy_h2d(_vp(d_co + 4 * r * stride), _ptr(co32[r]), n * 4), "sdfk_memcpy_h2d")
+            # rows: the index at which x or y first changes (3-D grids), else at which x first changes (flat grids)
+            row_len, flat = 0, 0
+            head = co32[:, :min(n, 1 << 22)]
+            ch = np.flatnonzero((head[0] != head[0, 0]) | (head[1] != head[1, 0]))
+            if ch.size and ch[0] >= 32 and n % int(ch[0]) == 0:
+                row_len = int(ch[0])
+            else:
+                cx = np.flatnonzero(head[0] != head[0, 0])
+                if cx.size and cx[0] >= 32 and n % int(cx[0]) == 0:
+                    row_len = int(cx[0])
+                    flat = int(co32[2, 0] == 0 and co32[2, row_len - 1] == 0 and co32[2, -1] == 0)
+
+            def first(d_scratch, m):
+                check(L.sdfk_eval_device_select(self._h, _vp(d_co), n, stride, row_len, flat, float(threshold), None, 0, m,
+                                                d_scratch, None, mode), "sdfk_eval_device_select")
+            return self._select(n, first, device)
+        finally:
+            L.sdfk_free(_vp(d_co))
 
     def eval_grid_host(self, axes, start=0, count=None, device=0, mode=MODE_AUTO):
         """Field of the grid spanned by three per-axis tables (flat index z fastest), straight to a host array."""

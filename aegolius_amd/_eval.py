@@ -79,6 +79,26 @@ def _run_resident(lowered, co, axes):
     return field
 
 
+def select_geometry(node, co, threshold=0.0):
+    """numpy.flatnonzero(node.create(co) <= threshold) — for a tree that lowers to ONE program without the field ever
+    existing: the evaluation kernels write flag bits, the compaction reads them (csrc/sdfk_fieldops.inc, "fused selection").
+    Trees with grid-neighbourhood operators or user callables are evaluated to a resident field first."""
+    from ._lower import NeedsStage
+    try:
+        lowered = lower_geometry(node)
+    except NeedsStage:
+        field = evaluate_geometry(node, co, resident=True)
+        try:
+            return field.select(threshold)
+        finally:
+            field.free()
+    prog = program_for(lowered)
+    axes = getattr(co, "grid_axes", None) if config.grid_fast_path else None
+    if axes is not None:
+        return prog.select_grid(axes, threshold, device=config.device, mode=config.mode)
+    return prog.select_host(co, threshold, device=config.device, mode=config.mode)
+
+
 def evaluate_geometry(node, co, resident=False):
     return _evaluate(lambda **kw: lower_geometry(node, **kw), co, node.modified_object, resident)
 

@@ -46,13 +46,11 @@ class GenericGeometry(EuclideanTransform, ModifyObject):
         return evaluate_geometry(self, co, resident=True)
 
     def point_cloud(self, co):
-        """Interior points (field <= 0) as a (3, M) cloud with z = 0 (reference cores/geom.py:62-74). The mask is
-        applied on the device; only the indices of the interior points come back."""
-        field = self.create_resident(co)
-        try:
-            inside = field.select(0.0)
-        finally:
-            field.free()
+        """Interior points (field <= 0) as a (3, M) cloud with z = 0 (reference cores/geom.py:62-74). Evaluation and
+        mask are fused on the device — the kernels write one flag bit per point instead of the field — and only the
+        indices of the interior points come back."""
+        from .._eval import select_geometry
+        inside = select_geometry(self, co, 0.0)
         pts = np.zeros((3, inside.size))
         pts[:2, :] = np.asarray(co)[:2, inside]
         return pts

@@ -1247,13 +1247,17 @@ static inline unsigned blocks_for(long long n, int vec) {
 // flat: the caller states that the rows of the array are rows of a flat grid (z = 0, rows along y); grids know it
 static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long long n, float* d_out, void* stream_,
                int mode, bool vec_ok, long long row_len = 0, const float* aux = nullptr, long long aux_stride = 0,
-               bool flat = false, long long plane_rows = 0, long long plane_phase = 0) {
+               bool flat = false, long long plane_rows = 0, long long plane_phase = 0, unsigned* d_flags = nullptr,
+               unsigned thr_key = 0) {
     if (!p) return fail(-1, "null program");
     if (n < 0) return fail(-1, "negative point count");
     if (p->n_aux > 0 && (!aux || aux_stride < n))
         return fail(-1, "this program reads auxiliary fields (staged evaluation): use sdfk_eval_device_aux / sdfk_eval_grid_aux");
     if (n == 0) return 0;
     if (mode == SDFK_MODE_AUTO) mode = g_default_mode;
+    // flags instead of the field (fused selection): the specialised plain / row-block kernels only — the call waits for
+    // their build instead of starting on the interpreter kernel
+    if (d_flags && (mode == SDFK_MODE_AUTO || mode == SDFK_MODE_INTERPRET)) mode = SDFK_MODE_SPECIALIZED;
     hipStream_t stream = (hipStream_t)stream_;
     int device = 0;
     HIPCHK(hipGetDevice(&device));
@@ -1273,7 +1277,7 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
         const long long v = e ? atoll(e) : 1200;
         return v > 0 ? v : 1200;
     }();
-    if (mode == SDFK_MODE_AUTO && (long long)(p->code.size() / 2) > spec_limit && p->interp_ok && !p->chain_mode)
+    if (mode == SDFK_MODE_AUTO && (long long)(p->code.size() / 2) > spec_limit && p->interp_ok && !p->chain_mode && !d_flags)
         mode = SDFK_MODE_INTERPRET;
 
     // Which flavour does this call launch? (row blocks > line bricks > plain; NOCULL and programs without sites: plain)
@@ -1283,12 +1287,12 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
     if (!p->sites.empty() && mode != SDFK_MODE_NOCULL && mode != SDFK_MODE_INTERPRET) {
         if (arr && rows_geometry(n, row_len, &rg, flat ? 0 : plane_rows, plane_phase))
             flavour = flat ? SDFK_FL_ROWS2D_ARRAY : SDFK_FL_ROWS_ARRAY;   // rows need no alignment beyond 4 bytes
-        else if (arr && vec_ok && !p->chain_mode) flavour = SDFK_FL_TILE_ARRAY;
+        else if (arr && vec_ok && !p->chain_mode && !d_flags) flavour = SDFK_FL_TILE_ARRAY;
         else if (grid && grid->start % grow == 0 &&
                  rows_geometry(n, grow, &rg, grid->n2 > 1 ? (long long)grid->n1 : 0,
                                grid->n2 > 1 ? (grid->start / grow) % (long long)grid->n1 : 0))
             flavour = grid->n2 > 1 ? SDFK_FL_ROWS_GRID : SDFK_FL_ROWS2D_GRID;
-        else if (grid && vec_ok && !p->chain_mode) flavour = SDFK_FL_TILE_GRID;
+        else if (grid && vec_ok && !p->chain_mode && !d_flags) flavour = SDFK_FL_TILE_GRID;
     }
     std::shared_ptr<SpecModule> sk;
     if (mode != SDFK_MODE_INTERPRET) {
@@ -1324,7 +1328,7 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
             if (arr) {
                 const float* co = arr->co;
                 long long stride = arr->stride;
-                void* args[] = {&prm, &tab, &co, &stride, &rg, &d_out};
+                void* args[] = {&prm, &tab, &co, &stride, &rg, &d_out, &d_flags, &thr_key};
                 HIPCHK(hipModuleLaunchKernel(sk->fn[0], tiles, 1, 1, rthreads, 1, 1, 0, stream, args, nullptr));
             } else {
                 // whole grid rows (x-slabs of a sharded evaluation always are); rows along the third axis, or along
@@ -1332,7 +1336,7 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
                 SrcGrid g = *grid;
                 rg.row0 = grid->start / grow;
                 rg.yrows = grid->n2 > 1 ? 0 : 1;
-                void* args[] = {&prm, &tab, &g, &rg, &d_out};
+                void* args[] = {&prm, &tab, &g, &rg, &d_out, &d_flags, &thr_key};
                 HIPCHK(hipModuleLaunchKernel(sk->fn[0], tiles, 1, 1, rthreads, 1, 1, 0, stream, args, nullptr));
             }
             return 0;
@@ -1357,13 +1361,13 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
             long long stride = arr->stride;
             if (n4) {
                 long long off = 0;
-                void* args[] = {&prm, &tab, &co, &stride, &off, &n4, &d_out, &aux, &aux_stride};
+                void* args[] = {&prm, &tab, &co, &stride, &off, &n4, &d_out, &aux, &aux_stride, &d_flags, &thr_key};
                 HIPCHK(hipModuleLaunchKernel(sk->fn[0], blocks_for(n4, 4), 1, 1, SDFK_BLOCK, 1, 1, 0, stream, args,
                                              nullptr));
             }
             if (tail) {
                 long long off = n4;
-                void* args[] = {&prm, &tab, &co, &stride, &off, &tail, &d_out, &aux, &aux_stride};
+                void* args[] = {&prm, &tab, &co, &stride, &off, &tail, &d_out, &aux, &aux_stride, &d_flags, &thr_key};
                 HIPCHK(hipModuleLaunchKernel(sk->fn[1], blocks_for(tail, 1), 1, 1, SDFK_BLOCK, 1, 1, 0, stream, args,
                                              nullptr));
             }
@@ -1371,13 +1375,13 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
             SrcGrid g = *grid;
             if (n4) {
                 long long off = 0;
-                void* args[] = {&prm, &tab, &g, &off, &n4, &d_out, &aux, &aux_stride};
+                void* args[] = {&prm, &tab, &g, &off, &n4, &d_out, &aux, &aux_stride, &d_flags, &thr_key};
                 HIPCHK(hipModuleLaunchKernel(sk->fn[0], blocks_for(n4, 4), 1, 1, SDFK_BLOCK, 1, 1, 0, stream, args,
                                              nullptr));
             }
             if (tail) {
                 long long off = n4;
-                void* args[] = {&prm, &tab, &g, &off, &tail, &d_out, &aux, &aux_stride};
+                void* args[] = {&prm, &tab, &g, &off, &tail, &d_out, &aux, &aux_stride, &d_flags, &thr_key};
                 HIPCHK(hipModuleLaunchKernel(sk->fn[1], blocks_for(tail, 1), 1, 1, SDFK_BLOCK, 1, 1, 0, stream, args,
                                              nullptr));
             }
@@ -1385,6 +1389,7 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
         return 0;
     }
     // interpreter
+    if (d_flags) return fail(-3, "fused selection needs the specialised kernels");
     const int n_instr = (int)(p->code.size() / 2);
     const long long zero = 0;
     auto launch = [&](auto src, int vec, long long off, long long cnt) {

@@ -75,6 +75,37 @@ static __device__ __forceinline__ void sdfk_load(const SrcGrid& s, long long blo
     }
 }
 
+// ---- flags instead of the field (fused interior selection, GenericGeometry.point_cloud: C/geom.py:62-74) -----------
+// An evaluation kernel that is handed a flag buffer writes ONE BIT per point — bit j of byte b = point 8 b + j,
+// "field <= threshold" — and no field: 12 B/point of coordinates in, 1/8 B/point out. The compaction
+// (sdfk_fieldops.inc: count, scan, scatter from the flags) then never sees the field either.
+// Selection key: an unsigned integer that orders like the float (negative zero = zero), every NaN above all numbers so
+// that it is never selected (NumPy: nan <= t is False). Integer compares only: the kernels are built with
+// -fno-honor-nans, which leaves float compares with NaN undefined.
+static __host__ __device__ __forceinline__ unsigned sdfk_sel_key(float v) {
+    unsigned u = __builtin_bit_cast(unsigned, v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;  // NaN
+    if (u == 0x80000000u) u = 0u;                             // -0.0 == 0.0
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+// VEC points per lane starting at flat index i (i % VEC == 0; a wave covers 64 * VEC consecutive points, its first one
+// at a multiple of 64 * VEC): the lanes' VEC-bit groups are OR-ed into 32-bit words inside the wave (VEC = 4: 8 lanes per
+// word, three exchange steps) and stored by one lane per word. nib = 0 for lanes past the end of the array — they must
+// still get here (the exchange is wave-wide).
+template <int VEC>
+static __device__ __forceinline__ void sdfk_store_flags(unsigned* __restrict__ flags, long long i, unsigned nib, bool active) {
+    if constexpr (VEC == 4) {
+        const unsigned lane = __builtin_amdgcn_workitem_id_x() & 63u;
+        unsigned w = nib << (4u * (lane & 7u));
+        w |= __shfl_xor(w, 1);
+        w |= __shfl_xor(w, 2);
+        w |= __shfl_xor(w, 4);
+        if ((lane & 7u) == 0u && active) flags[i >> 5] = w;
+    } else {
+        if (active && nib) atomicOr(&flags[i >> 5], nib << (unsigned)(i & 31));   // single points (tails, unaligned arrays)
+    }
+}
+
 template <int VEC>
 static __device__ __forceinline__ void sdfk_store(float* __restrict__ out, long long i, const float (&v)[VEC]) {
     if constexpr (VEC == 4) {

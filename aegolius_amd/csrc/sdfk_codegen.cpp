@@ -16,9 +16,30 @@ template <int VEC, typename SRC>
 static __device__ __forceinline__ void sdfk_body(const float* __restrict__ PRM, const float* __restrict__ TAB,
                                                  const SRC& src, long long off, long long n,
                                                  float* __restrict__ out, const float* __restrict__ aux,
-                                                 long long aux_stride) {
+                                                 long long aux_stride, unsigned* __restrict__ flags, unsigned thr) {
     const long long block_base = (long long)sdfk_bx() * (SDFK_BLOCK * VEC);
     const unsigned lane_off = sdfk_tx() * VEC;
+    if (flags) {                                               // (wave-uniform) one bit per point instead of the field
+        const bool active = block_base + lane_off < n;
+        unsigned nib = 0u;
+        if (active) {
+            V3 p[VEC];
+            sdfk_load<VEC>(src, off + block_base, lane_off, p);
+            const float* ax = aux + (off + block_base + lane_off);
+            if constexpr (VEC == 4) {
+                const f2 ra = sdfk_point<f2>(sd_join(p[0], p[1]), PRM, TAB, ax, aux_stride);
+                const f2 rb = sdfk_point<f2>(sd_join(p[2], p[3]), PRM, TAB, ax + 2, aux_stride);
+                nib = (sdfk_sel_key(ra.x) <= thr ? 1u : 0u) | (sdfk_sel_key(ra.y) <= thr ? 2u : 0u) |
+                      (sdfk_sel_key(rb.x) <= thr ? 4u : 0u) | (sdfk_sel_key(rb.y) <= thr ? 8u : 0u);
+            } else {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k)
+                    nib |= (sdfk_sel_key(sdfk_point<float>(p[k], PRM, TAB, ax + k, aux_stride)) <= thr ? 1u : 0u) << k;
+            }
+        }
+        sdfk_store_flags<VEC>(flags, off + block_base + lane_off, nib, active);
+        return;
+    }
     if (block_base + lane_off >= n) return;
     V3 p[VEC];
     sdfk_load<VEC>(src, off + block_base, lane_off, p);
@@ -39,27 +60,29 @@ static __device__ __forceinline__ void sdfk_body(const float* __restrict__ PRM, 
 static const char kWrappersArray[] = R"SDFKW(
 extern "C" __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_spec_v4(
     const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
-    long long off, long long n, float* __restrict__ out, const float* __restrict__ aux, long long aux_stride) {
+    long long off, long long n, float* __restrict__ out, const float* __restrict__ aux, long long aux_stride,
+    unsigned* __restrict__ flags, unsigned thr) {
     SrcArray s = {co, stride};
-    sdfk_body<4>(PRM, TAB, s, off, n, out, aux, aux_stride);
+    sdfk_body<4>(PRM, TAB, s, off, n, out, aux, aux_stride, flags, thr);
 }
 extern "C" __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_spec_v1(
     const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
-    long long off, long long n, float* __restrict__ out, const float* __restrict__ aux, long long aux_stride) {
+    long long off, long long n, float* __restrict__ out, const float* __restrict__ aux, long long aux_stride,
+    unsigned* __restrict__ flags, unsigned thr) {
     SrcArray s = {co, stride};
-    sdfk_body<1>(PRM, TAB, s, off, n, out, aux, aux_stride);
+    sdfk_body<1>(PRM, TAB, s, off, n, out, aux, aux_stride, flags, thr);
 }
 )SDFKW";
 static const char kWrappersGrid[] = R"SDFKW(
 extern "C" __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_spec_g4(
     const float* __restrict__ PRM, const float* __restrict__ TAB, SrcGrid g, long long off, long long n,
-    float* __restrict__ out, const float* __restrict__ aux, long long aux_stride) {
-    sdfk_body<4>(PRM, TAB, g, off, n, out, aux, aux_stride);
+    float* __restrict__ out, const float* __restrict__ aux, long long aux_stride, unsigned* __restrict__ flags, unsigned thr) {
+    sdfk_body<4>(PRM, TAB, g, off, n, out, aux, aux_stride, flags, thr);
 }
 extern "C" __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_spec_g1(
     const float* __restrict__ PRM, const float* __restrict__ TAB, SrcGrid g, long long off, long long n,
-    float* __restrict__ out, const float* __restrict__ aux, long long aux_stride) {
-    sdfk_body<1>(PRM, TAB, g, off, n, out, aux, aux_stride);
+    float* __restrict__ out, const float* __restrict__ aux, long long aux_stride, unsigned* __restrict__ flags, unsigned thr) {
+    sdfk_body<1>(PRM, TAB, g, off, n, out, aux, aux_stride, flags, thr);
 }
 )SDFKW";
 
@@ -799,7 +822,8 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
 
 template <typename SRC>
 static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict__ PRM, const float* __restrict__ TAB,
-                                                        const SRC& s, const sdfk_rowgeom& g, float* __restrict__ out) {
+                                                        const SRC& s, const sdfk_rowgeom& g, float* __restrict__ out,
+                                                        unsigned* __restrict__ flags, unsigned thr) {
     __shared__ __attribute__((aligned(16))) sdfk_rowmeta meta;
 #ifdef SDFK_LDSPAD
     if (g.L == 0xffffffffu) meta.pad[sdfk_tx()] = 1.0f;
@@ -911,6 +935,23 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
             SDFK_EACH res[q] = sdfk_chain_tail<f2>(acc[q], PRM);
         }
 #endif
+        if (flags) {                                               // (wave-uniform) one bit per point instead of the field:
+            unsigned bits = 0u;                                    // the lane's 8 consecutive points are one byte
+            SDFK_EACH bits |= ((sdfk_sel_key(res[q].x) <= thr ? 1u : 0u) | (sdfk_sel_key(res[q].y) <= thr ? 2u : 0u)) << (2 * q);
+            if (live_row) {
+                if (interior) {
+                    reinterpret_cast<unsigned char*>(flags)[f >> 3] = (unsigned char)bits;
+                } else {                                           // an edge window shares its bytes with the row before /
+                    unsigned ok = 0u;                              // after it: only this row's bits, OR-ed in
+                    SDFK_EACH {
+                        if (z + 2 * q >= 0 && z + 2 * q <= last) ok |= 1u << (2 * q);
+                        if (z + 2 * q + 1 >= 0 && z + 2 * q + 1 <= last) ok |= 2u << (2 * q);
+                    }
+                    bits &= ok;
+                    if (bits) atomicOr(&flags[f >> 5], bits << (unsigned)(f & 31));
+                }
+            }
+        } else
         if (live_row) {
             float* po = out + f;
             if (interior) {
@@ -938,17 +979,18 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
 static const char kRowsArray[] = R"SDFKR(
 extern "C" __global__ __launch_bounds__(64 * SDFK_RWAVES) SDFK_ROWS_ATTR void sdfk_spec_r(
     const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
-    sdfk_rowgeom g, float* __restrict__ out) {
+    sdfk_rowgeom g, float* __restrict__ out, unsigned* __restrict__ flags, unsigned thr) {
     const SrcArray s = {co, stride};
-    sdfk_rows_kernel(PRM, TAB, s, g, out);
+    sdfk_rows_kernel(PRM, TAB, s, g, out, flags, thr);
 }
 )SDFKR";
 static const char kRowsGrid[] = R"SDFKR(
 // the same on a regular grid expanded from three per-axis tables (no coordinate array: 4 B/point); the slab
 // starts at a row boundary and out[0] is its first point
 extern "C" __global__ __launch_bounds__(64 * SDFK_RWAVES) void sdfk_spec_rg(
-    const float* __restrict__ PRM, const float* __restrict__ TAB, SrcGrid s, sdfk_rowgeom g, float* __restrict__ out) {
-    sdfk_rows_kernel(PRM, TAB, s, g, out);
+    const float* __restrict__ PRM, const float* __restrict__ TAB, SrcGrid s, sdfk_rowgeom g, float* __restrict__ out,
+    unsigned* __restrict__ flags, unsigned thr) {
+    sdfk_rows_kernel(PRM, TAB, s, g, out, flags, thr);
 }
 )SDFKR";
 static const char kRowsMask[] = R"SDFKR(

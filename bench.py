@@ -648,7 +648,25 @@ def main():
             torch.cuda.synchronize()
             sel_ms, grad_ms, chain_ms = best_ms(select), best_ms(gradient), best_ms(chain)
             sel_bytes = 4.0 * count + 8.0 * selected.value
+            # GenericGeometry.point_cloud's mask WITHOUT a field: evaluation kernels write flag bits, compaction reads them
+            fscratch = torch.empty(lib.sdfk_eval_select_scratch(count), dtype=torch.uint8, device=dev)
+            fsel = ctypes.c_int64(0)
+            flat_i = 1 if flat else 0
+
+            def fused():
+                _engine.check(lib.sdfk_eval_device_select(prog.handle, vp(run.co.data_ptr()), count, stride, row_len, flat_i, 0.0,
+                                                          vp(index.data_ptr()), index.numel(), ctypes.byref(fsel),
+                                                          vp(fscratch.data_ptr()), vp(stream), mode), "sdfk_eval_device_select")
+            fused()
+            fused_ms = best_ms(fused)
+            fused_same = bool(fsel.value == selected.value)
+            fused_bytes = 12.0 * count + 8.0 * selected.value
             return {
+                "fused_evaluate_and_select": {"ms": fused_ms, "selected": fsel.value, "same_count_as_field_path": fused_same,
+                                              "bytes": fused_bytes, "evaluate_then_select_ms": kernel_ms_max + sel_ms,
+                                              "frac_of_hbm_peak": fused_bytes / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                              "note": "sdfk_eval_device_select: 12 B/point in, flag bits + 8 B per selected "
+                                                      "point out; includes the zeroing of the flags and two stream syncs"},
                 "interior_selection": {"ms": sel_ms, "selected": selected.value, "bytes": sel_bytes,
                                        "frac_of_hbm_peak": sel_bytes / (sel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
                 "gradient_direction": {"ms": grad_ms, "bytes": (12.0 if flat else 16.0) * count,

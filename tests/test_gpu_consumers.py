@@ -329,3 +329,39 @@ def test_signed_shards_across_ranks(world, engine):
         want = build().create(co)
         assert (want < 0).any() and (want > 0).any()
         np.testing.assert_array_equal(np.concatenate([got[r][name] for r in range(world)]), want, err_msg=name)
+
+
+@pytest.mark.parametrize("name", ["tree_cfg2_smooth_union10", "tree_cfg5_three_level", "tree_cfg4_union50_2d", "tree_cfg3_mod_chain",
+                                  "prim_sphere", "combine_SUBTRACT2"])
+def test_fused_selection_equals_flatnonzero_of_the_field(name, engine):
+    """Program.select_grid / select_host (evaluation kernels writing flag bits, compaction from the flags) return exactly
+    numpy.flatnonzero(field <= threshold) of the field the same kernels write — row-block, chain-mode and plain kernels,
+    tagged grids and plain arrays, odd row lengths (edge windows OR their bits in), thresholds that select nothing / all."""
+    import scenes
+    from aegolius_amd._lower import lower_geometry
+    tree = scenes.SCENES[name](ns)
+    prog = engine.Program.from_lowered(lower_geometry(tree))
+    flat = "2d" in name
+    for shape in ((9, 37, 1025), (20, 33, 64), (7, 50, 40), (5, 5, 333)):
+        if flat:
+            co, _ = ns.generate_grid((10, 10), (shape[0] * shape[1] - 1, shape[2] - 1))
+        else:
+            co, _ = ns.generate_grid((2.6, 2.6, 2.6), tuple(r - 1 for r in shape))
+        axes = [a.astype(np.float32) for a in co.grid_axes]
+        field = prog.eval_grid_host(axes, mode=engine.MODE_SPECIALIZED)
+        plain = np.asarray(co).astype(np.float32)
+        for thr in (0.0, 0.13, -1e9, 1e9, float(np.median(field))):
+            want = np.flatnonzero(field <= np.float32(thr))
+            np.testing.assert_array_equal(prog.select_grid(axes, thr), want)
+            np.testing.assert_array_equal(prog.select_host(plain, thr), want)
+        # a slab of whole rows from the axis tables; scattered points (no row structure: plain kernel)
+        row = shape[2] if not flat else shape[2]
+        s0, cnt = 3 * row, (field.size // row - 5) * row
+        np.testing.assert_array_equal(prog.select_grid(axes, 0.05, start=s0, count=cnt), np.flatnonzero(field[s0:s0 + cnt] <= np.float32(0.05)))
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-1.5, 1.5, (3, 10007)).astype(np.float32)
+    if flat:
+        pts[2] = 0
+    got = prog.select_host(pts, 0.1)
+    np.testing.assert_array_equal(got, np.flatnonzero(prog.eval_host(pts, mode=engine.MODE_SPECIALIZED) <= np.float32(0.1)))
+    assert prog.select_host(pts, float("nan")).size == 0
