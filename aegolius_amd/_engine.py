@@ -59,11 +59,11 @@ SIGNATURES = {
     "sdfk_field_select": (_int, [_vp, _i64, _c.c_float, _vp, _i64, _c.POINTER(_i64), _vp, _vp]),
     "sdfk_field_select_finish": (_int, [_i64, _i64, _vp, _i64, _vp, _vp]),
     "sdfk_field_gradient": (_int, [_vp, _i64, _i64, _i64, _int, _int, _vp, _i64, _vp]),
-    "sdfk_eval_select_scratch": (_sz, [_i64]),
+    "sdfk_eval_select_scratch": (_sz, [_i64, _i64]),
     "sdfk_eval_device_select": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _c.c_float, _vp, _i64, _c.POINTER(_i64), _vp, _vp, _int]),
     "sdfk_eval_grid_select": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _c.c_float, _vp, _i64, _c.POINTER(_i64),
                                      _vp, _vp, _int]),
-    "sdfk_eval_select_finish": (_int, [_i64, _i64, _vp, _i64, _vp, _vp]),
+    "sdfk_eval_select_finish": (_int, [_vp, _i64, _i64, _int, _i64, _vp, _i64, _vp, _vp]),
     "sdfk_vec_eval_device": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _int, _i64, _int, _vp, _i64, _vp]),
     "sdfk_vec_set_interpret": (None, [_int]),
     "sdfk_vec_source": (_c.c_char_p, [_vp, _int, _int, _int]),
@@ -269,14 +269,14 @@ class Program:
         check(lib().sdfk_eval_grid(self._h, _ptr(ax[0]), ax[0].size, _ptr(ax[1]), ax[1].size, _ptr(ax[2]),
                                    ax[2].size, start, count, _vp(d_out), _vp(stream or 0), mode), "sdfk_eval_grid")
 
-    def _select(self, n, first, device):
+    def _select(self, n, first, device, row_len=0, mode=MODE_AUTO):
         """Two-step protocol of the fused selection: `first(d_scratch, byref(count))` evaluates into flags and counts;
         the indices follow from the flags. -> ascending int64 host array."""
         require_gpu()
         L = lib()
         check(L.sdfk_set_device(int(device)), "sdfk_set_device")
         m = _i64(0)
-        d_scratch = L.sdfk_malloc(L.sdfk_eval_select_scratch(n))
+        d_scratch = L.sdfk_malloc(L.sdfk_eval_select_scratch(n, int(row_len)))
         d_index = None
         try:
             if not d_scratch:
@@ -287,8 +287,8 @@ class Program:
                 d_index = L.sdfk_malloc(m.value * 8)
                 if not d_index:
                     raise SdfkError("select: out of device memory")
-                check(L.sdfk_eval_select_finish(n, m.value, _vp(d_index), m.value, _vp(d_scratch), None),
-                      "sdfk_eval_select_finish")
+                check(L.sdfk_eval_select_finish(self._h, n, int(row_len), mode, m.value, _vp(d_index), m.value, _vp(d_scratch),
+                                                None), "sdfk_eval_select_finish")
                 check(L.sdfk_memcpy_d2h(_ptr(out), _vp(d_index), out.size * 8), "sdfk_memcpy_d2h")
             return out
         finally:
@@ -307,7 +307,8 @@ class Program:
             check(lib().sdfk_eval_grid_select(self._h, _ptr(ax[0]), ax[0].size, _ptr(ax[1]), ax[1].size, _ptr(ax[2]),
                                               ax[2].size, start, count, float(threshold), None, 0, m, d_scratch, None,
                                               mode), "sdfk_eval_grid_select")
-        return self._select(count, first, device)
+        grow = ax[2].size if ax[2].size > 1 else ax[1].size
+        return self._select(count, first, device, row_len=grow if start % grow == 0 and count % grow == 0 else 0, mode=mode)
 
     def select_host(self, co, threshold=0.0, device=0, mode=MODE_AUTO):
         """The same for a (3, N) host array (uploaded once as float32; the row-length hint is detected like create())."""
@@ -343,7 +344,7 @@ class Program:
             def first(d_scratch, m):
                 check(L.sdfk_eval_device_select(self._h, _vp(d_co), n, stride, row_len, flat, float(threshold), None, 0, m,
                                                 d_scratch, None, mode), "sdfk_eval_device_select")
-            return self._select(n, first, device)
+            return self._select(n, first, device, row_len=row_len, mode=mode)
         finally:
             L.sdfk_free(_vp(d_co))
 

@@ -1285,12 +1285,12 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
     int flavour = arr ? SDFK_FL_PLAIN_ARRAY : SDFK_FL_PLAIN_GRID;
     const long long grow = grid ? (grid->n2 > 1 ? (long long)grid->n2 : (long long)grid->n1) : 0;
     if (!p->sites.empty() && mode != SDFK_MODE_NOCULL && mode != SDFK_MODE_INTERPRET) {
-        if (arr && rows_geometry(n, row_len, &rg, flat ? 0 : plane_rows, plane_phase))
+        if (arr && rows_geometry(n, row_len, &rg, (flat || d_flags) ? 0 : plane_rows, plane_phase))
             flavour = flat ? SDFK_FL_ROWS2D_ARRAY : SDFK_FL_ROWS_ARRAY;   // rows need no alignment beyond 4 bytes
         else if (arr && vec_ok && !p->chain_mode && !d_flags) flavour = SDFK_FL_TILE_ARRAY;
         else if (grid && grid->start % grow == 0 &&
-                 rows_geometry(n, grow, &rg, grid->n2 > 1 ? (long long)grid->n1 : 0,
-                               grid->n2 > 1 ? (grid->start / grow) % (long long)grid->n1 : 0))
+                 rows_geometry(n, grow, &rg, (grid->n2 > 1 && !d_flags) ? (long long)grid->n1 : 0,    // (flags: the slot layout
+                               grid->n2 > 1 ? (grid->start / grow) % (long long)grid->n1 : 0))         //  knows blocks of 16 rows)
             flavour = grid->n2 > 1 ? SDFK_FL_ROWS_GRID : SDFK_FL_ROWS2D_GRID;
         else if (grid && vec_ok && !p->chain_mode && !d_flags) flavour = SDFK_FL_TILE_GRID;
     }

@@ -649,7 +649,7 @@ def main():
             sel_ms, grad_ms, chain_ms = best_ms(select), best_ms(gradient), best_ms(chain)
             sel_bytes = 4.0 * count + 8.0 * selected.value
             # GenericGeometry.point_cloud's mask WITHOUT a field: evaluation kernels write flag bits, compaction reads them
-            fscratch = torch.empty(lib.sdfk_eval_select_scratch(count), dtype=torch.uint8, device=dev)
+            fscratch = torch.empty(lib.sdfk_eval_select_scratch(count, row_len), dtype=torch.uint8, device=dev)
             fsel = ctypes.c_int64(0)
             flat_i = 1 if flat else 0
 

@@ -242,17 +242,20 @@ int sdfk_field_select_finish(int64_t n, int64_t count, int64_t* d_index, int64_t
  * bit per point — field <= threshold — instead of the field (12 B/point of coordinates in, 1/8 B/point out), and count,
  * scan and scatter work on those flags alone; the indices are numpy.flatnonzero(tree(co) <= threshold), ascending, and
  * the bits are those of sdfk_eval_device's field. Same two-step protocol as sdfk_field_select: d_index == NULL returns
- * the count and keeps the flags in d_scratch (sdfk_eval_select_scratch(n) bytes of device memory, 8-byte aligned) for
+ * the count and keeps the flags in d_scratch (sdfk_eval_select_scratch(n, row_len) bytes of device memory, 8-byte aligned) for
  * sdfk_eval_select_finish. row_len / flat: the layout hints of sdfk_eval_device_rows / _rows2d (0: none). Runs on the
  * specialised kernels (the call waits for their build); programs with auxiliary fields are refused. */
-size_t sdfk_eval_select_scratch(int64_t n);
+size_t sdfk_eval_select_scratch(int64_t n, int64_t row_len);
 int sdfk_eval_device_select(sdfk_program* prog, const float* d_co, int64_t n, int64_t row_stride, int64_t row_len, int flat,
                             float threshold, int64_t* d_index, int64_t capacity, int64_t* count, void* d_scratch,
                             void* stream, int mode);
 int sdfk_eval_grid_select(sdfk_program* prog, const float* ax0, int64_t n0, const float* ax1, int64_t n1, const float* ax2,
                           int64_t n2, int64_t start, int64_t count_points, float threshold, int64_t* d_index,
                           int64_t capacity, int64_t* count, void* d_scratch, void* stream, int mode);
-int sdfk_eval_select_finish(int64_t n, int64_t count, int64_t* d_index, int64_t capacity, void* d_scratch, void* stream);
+/* row_len, mode: as in the count-only call before it (grids: the last grid dimension longer than one point when the range
+ * starts at a row boundary, else 0) — they decide how the flags are laid out. */
+int sdfk_eval_select_finish(sdfk_program* prog, int64_t n, int64_t row_len, int mode, int64_t count, int64_t* d_index,
+                            int64_t capacity, void* d_scratch, void* stream);
 int sdfk_field_select(const float* d_field, int64_t n, float threshold, int64_t* d_index, int64_t capacity,
                       int64_t* count, void* d_scratch, void* stream);
 int sdfk_field_gradient(const float* d_field, int64_t n0, int64_t n1, int64_t n2, int ncomp, int normalize,
