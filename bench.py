@@ -499,8 +499,8 @@ def main():
         def grid_512():
             ax = fp32_axes(512)
             r2 = Run(torch, dist, _engine, prog, ax, world, rank, dev, red_dev, mode, not args.no_rows)
-            steps2 = max(10, args.steps)
-            e2, k2, med2, min2 = r2.timed(steps2, 3)
+            steps2 = max(30, args.steps)                          # 0.4 ms per step: 30 steps after 10 warm-ups, so that the
+            e2, k2, med2, min2 = r2.timed(steps2, 10)             # clocks have settled before the timed region
             v = verify_sample(args.workload, ax, r2.start, r2.out, r2.count, samples=5000)
             return {"grid": "%dx%dx%d" % (ax[0].size, ax[1].size, ax[2].size), "points": r2.n_total, "steps": steps2,
                     "value": r2.n_total * steps2 / e2 / 1e6, "unit": "Mpoints/s", "ms_per_step": e2 / steps2 * 1e3,
@@ -537,8 +537,8 @@ def main():
                     r.step()
                     torch.cuda.synchronize()
                     build_s = time.perf_counter() - t0
-                    steps_o = 5
-                    e, k, med, mn = r.timed(steps_o, 2)
+                    steps_o = 10                                  # (short kernels: the clocks need a few launches)
+                    e, k, med, mn = r.timed(steps_o, 5)
                     v = verify_sample(name, ax, 0, r.out, r.count, samples=5000)
                     res[key] = {"workload": t_desc, "grid": "%dx%dx%d" % (ax[0].size, ax[1].size, ax[2].size),
                                 "points": pts, "steps": steps_o, "value": pts * steps_o / e / 1e6, "unit": "Mpoints/s",
