@@ -45,6 +45,7 @@ SIGNATURES = {
     "sdfk_eval_device_rows3d": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int]),
     "sdfk_debug_row_masks": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _c.POINTER(_i64), _c.POINTER(_int), _vp]),
     "sdfk_eval_grid_sharded": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _int, _vp, _vp, _int]),
+    "sdfk_eval_grid_sharded_device": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _int, _vp, _int, _vp, _int]),
     "sdfk_eval_device_aux": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _i64, _vp, _vp, _int]),
     "sdfk_eval_grid_aux": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _int, _i64, _vp, _vp, _int]),
     "sdfk_field_min": (_int, [_vp, _i64, _c.POINTER(_c.c_float), _vp]),
@@ -372,6 +373,20 @@ class Program:
                                            ax[2].size, n_shards, _ptr(dev) if dev is not None else None, _ptr(out),
                                            mode), "sdfk_eval_grid_sharded")
         return out
+
+    def eval_grid_sharded_resident(self, axes, n_shards, devices=None, gather_device=0, mode=MODE_AUTO):
+        """The same partition, the field reassembled on `gather_device` by device-to-device copies (no host buffer)
+        -> DeviceField on that device."""
+        require_gpu()
+        ax = [np.ascontiguousarray(a, dtype=np.float32) for a in axes]
+        dev = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
+        if dev is not None and dev.size != n_shards:
+            raise ValueError("one device per shard")
+        field = DeviceField(ax[0].size * ax[1].size * ax[2].size, gather_device)
+        check(lib().sdfk_eval_grid_sharded_device(self._h, _ptr(ax[0]), ax[0].size, _ptr(ax[1]), ax[1].size, _ptr(ax[2]),
+                                                  ax[2].size, n_shards, _ptr(dev) if dev is not None else None,
+                                                  int(gather_device), _vp(field.ptr), mode), "sdfk_eval_grid_sharded_device")
+        return field
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

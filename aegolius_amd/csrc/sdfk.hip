@@ -1666,6 +1666,63 @@ extern "C" int sdfk_eval_grid_sharded(sdfk_program* p, const float* ax0, int64_t
     return 0;
 }
 
+// The same partition with the field left ON THE DEVICES: shard d is evaluated on devices[d] and lands in its place of
+// `d_full`, a buffer of n0 * n1 * n2 floats on `gather_device` — written in place by the shards that run on that device,
+// moved by hipMemcpyPeerAsync (device to device over xGMI, no host buffer) by the others. A C consumer without torch gets
+// the reassembled field on one GPU this way; the multi-process route with RCCL is aegolius_amd/distributed.py.
+extern "C" int sdfk_eval_grid_sharded_device(sdfk_program* p, const float* ax0, int64_t n0, const float* ax1, int64_t n1,
+                                             const float* ax2, int64_t n2, int n_shards, const int* devices,
+                                             int gather_device, float* d_full, int mode) {
+    if (!p || !d_full) return fail(-1, "sdfk_eval_grid_sharded_device: null argument");
+    if (n_shards < 1 || n_shards > 64) return fail(-1, "sdfk_eval_grid_sharded_device: 1..64 shards");
+    if (!ax0 || !ax1 || !ax2 || n0 < 1 || n1 < 1 || n2 < 1) return fail(-1, "grid axes missing or empty");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return fail(-8, "sdfk_eval_grid_sharded_device: no HIP device");
+    if (gather_device < 0 || gather_device >= n_dev) return fail(-1, "sdfk_eval_grid_sharded_device: gather device out of range");
+    for (int d = 0; d < n_shards; ++d) {
+        const int dev = devices ? devices[d] : d % n_dev;
+        if (dev < 0 || dev >= n_dev) return fail(-1, "sdfk_eval_grid_sharded_device: device index out of range");
+    }
+    const int64_t total = n0 * n1 * n2, unit = n2 > 1 ? n2 : n1;
+    const int64_t per = (total / unit / n_shards) * unit;
+    std::vector<int> rc((size_t)n_shards, 0);
+    std::vector<std::string> msg((size_t)n_shards);
+    std::vector<std::thread> workers;
+    for (int d = 0; d < n_shards; ++d) {
+        const int dev = devices ? devices[d] : d % n_dev;
+        const int64_t start = d * per, count = d < n_shards - 1 ? per : total - start;
+        workers.emplace_back([=, &rc, &msg] {
+            auto shard = [&]() -> int {
+                if (count <= 0) return 0;
+                HIPCHK(hipSetDevice(dev));
+                hipStream_t stream = nullptr;
+                HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+                // (SDFK_FORCE_PEER_COPY=1: the copy path also for the shards of the gather device — how a one-GPU box tests it)
+                static const bool force_copy = [] { const char* e = getenv("SDFK_FORCE_PEER_COPY"); return e && e[0] == '1'; }();
+                const bool in_place = dev == gather_device && !force_copy;
+                float* d_slab = in_place ? d_full + start : nullptr;
+                int r = 0;
+                if (!d_slab && hipMalloc(&d_slab, (size_t)count * sizeof(float)) != hipSuccess) r = fail(-5, "out of device memory for the slab");
+                if (r == 0) r = sdfk_eval_grid(p, ax0, n0, ax1, n1, ax2, n2, start, count, d_slab, stream, mode);   // (synchronises)
+                if (r == 0 && !in_place) {
+                    if (hipMemcpyPeerAsync(d_full + start, gather_device, d_slab, dev, (size_t)count * sizeof(float), stream) != hipSuccess ||
+                        hipStreamSynchronize(stream) != hipSuccess)
+                        r = fail(-6, "peer copy of the slab failed");
+                }
+                if (!in_place && d_slab) (void)hipFree(d_slab);
+                (void)hipStreamDestroy(stream);
+                return r;
+            };
+            rc[(size_t)d] = shard();
+            if (rc[(size_t)d]) msg[(size_t)d] = sdfk_last_error();
+        });
+    }
+    for (std::thread& t : workers) t.join();
+    for (int d = 0; d < n_shards; ++d)
+        if (rc[(size_t)d]) return fail(rc[(size_t)d], "shard " + std::to_string(d) + ": " + msg[(size_t)d]);
+    return 0;
+}
+
 extern "C" int sdfk_grid_fill(float* d_co, int64_t row_stride, const float* ax0, int64_t n0, const float* ax1,
                               int64_t n1, const float* ax2, int64_t n2, int64_t start, int64_t count, void* stream) {
     if (!d_co) return fail(-1, "sdfk_grid_fill: null output");

@@ -162,6 +162,12 @@ int sdfk_eval_grid_host(sdfk_program* prog, const float* ax0, int64_t n0, const 
  * collective. The multi-process route (one rank per GPU, torch.distributed) is aegolius_amd/distributed.py. */
 int sdfk_eval_grid_sharded(sdfk_program* prog, const float* ax0, int64_t n0, const float* ax1, int64_t n1,
                            const float* ax2, int64_t n2, int n_shards, const int* devices, float* out, int mode);
+/* The same partition with the field left on the DEVICES: shard d runs on devices[d] and lands in its place of d_full, a
+ * buffer of n0*n1*n2 floats on gather_device — in place for the shards of that device, by hipMemcpyPeerAsync (device to
+ * device over xGMI, no host buffer) for the others. */
+int sdfk_eval_grid_sharded_device(sdfk_program* prog, const float* ax0, int64_t n0, const float* ax1, int64_t n1,
+                                  const float* ax2, int64_t n2, int n_shards, const int* devices, int gather_device,
+                                  float* d_full, int mode);
 void sdfk_set_default_mode(int mode);
 /* Test / diagnostics aid for brick culling: writes one 64-bit skip mask per brick of 128 consecutive
  * points (ceil(n / 2048) * 16 entries; bit 2k = first operand of site k skipped, bit 2k+1 = second operand,

@@ -427,6 +427,29 @@ def test_single_process_sharded_grid(engine):
     np.testing.assert_array_equal(prog.eval_grid_sharded(axes, 2), whole)
     with pytest.raises(engine.SdfkError):
         prog.eval_grid_sharded(axes, 2, devices=[0, 99])
+    # the field left on the devices: slabs land in place / by peer copies in one device buffer (sdfk_eval_grid_sharded_device)
+    for shards in (1, 3, 8):
+        field = prog.eval_grid_sharded_resident(axes, shards, devices=[0] * shards, gather_device=0)
+        np.testing.assert_array_equal(field.numpy(), whole)
+        field.free()
+    with pytest.raises(engine.SdfkError):
+        prog.eval_grid_sharded_resident(axes, 2, devices=[0, 0], gather_device=99)
+    # the device-to-device copy path (hipMemcpyPeerAsync), forced for the shards of the gather device itself
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests'); import numpy as np, scenes\n"
+              "import aegolius_amd.cores as ns\nfrom aegolius_amd import _engine\nfrom aegolius_amd._lower import lower_geometry\n"
+              "from aegolius_amd.cores.helper_functions import grid_axes\n"
+              "prog = _engine.Program.from_lowered(lower_geometry(scenes.cfg5_tree(ns)))\n"
+              "axes = [a.astype(np.float32) for a in grid_axes((3, 3, 3), (20, 30, 70))[0]]\n"
+              "whole = prog.eval_grid_host(axes)\n"
+              "for shards in (1, 3, 8):\n"
+              "    assert np.array_equal(prog.eval_grid_sharded_resident(axes, shards, devices=[0] * shards).numpy(), whole)\n"
+              "print('ok')\n" % (root, root))
+    res = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, SDFK_FORCE_PEER_COPY="1"), capture_output=True,
+                         text=True, timeout=300)
+    assert res.returncode == 0 and res.stdout.strip().endswith("ok"), res.stderr[-2000:]
 
 
 CULL_SCENES = ["tree_cfg2_smooth_union10", "tree_cfg5_three_level", "tree_cfg4_union50_2d", "tree_pawn_3D",
