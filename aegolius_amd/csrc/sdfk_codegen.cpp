@@ -641,13 +641,28 @@ static __device__ __forceinline__ void sdfk_rows_bounds(const sdfk_rowregs& r, i
 static __device__ __forceinline__ float4 sdfk_sub_centre(const sdfk_rowmeta* meta, unsigned b, unsigned sb) {
     constexpr int NZP = 4, NRP = SDFK_NSUB / NZP, RPS = SDFK_RROWS / NRP, ZPS = SDFK_RZ / NZP;
     static_assert(ZPS % 4 == 0 && RPS >= 1, "sub-brick shape");
-    const int r0 = (int)(sb / NZP) * RPS, i0 = (int)(sb % NZP) * ZPS;
-    const float2 pa = meta->xy[b][r0], pe = meta->xy[b][r0 + RPS - 1];
-    const float za = meta->z[b][r0 * SDFK_RZ + i0], ze = meta->z[b][(r0 + RPS - 1) * SDFK_RZ + i0 + ZPS - 1];
+    int r0 = (int)(sb / NZP) * RPS, r1 = r0 + RPS;
+    const int i0 = (int)(sb % NZP) * ZPS;
+    if constexpr (NRP == 2) {
+        // A brick whose 16 rows come from TWO planes of the grid (1 row block in 32 at 513^3: the last rows of one plane,
+        // y near its maximum, and the first rows of the next, y near its minimum) is split where x changes instead of in the
+        // middle: each part lies in one plane and is bounded tightly; split in the middle, the part that holds the plane
+        // change spans the whole y extent and nothing of the brick could be culled.
+        const float x0 = meta->xy[b][0].x;
+        if (__builtin_bit_cast(unsigned, x0) != __builtin_bit_cast(unsigned, meta->xy[b][SDFK_RROWS - 1].x)) {
+            int s = 1;
+            while (s < SDFK_RROWS - 1 && __builtin_bit_cast(unsigned, meta->xy[b][s].x) == __builtin_bit_cast(unsigned, x0)) ++s;
+            r0 = sb / NZP ? s : 0;
+            r1 = sb / NZP ? SDFK_RROWS : s;
+        }
+    }
+    const float2 pa = meta->xy[b][r0], pe = meta->xy[b][r1 - 1];
+    const float za = meta->z[b][r0 * SDFK_RZ + i0], ze = meta->z[b][(r1 - 1) * SDFK_RZ + i0 + ZPS - 1];
     const float cx = 0.5f * (pa.x + pe.x), cy = 0.5f * (pa.y + pe.y), cz = 0.5f * (za + ze);
     float r2 = 0.0f;
-#pragma unroll
-    for (int r = 0; r < RPS; ++r) {
+#pragma unroll 1
+    for (int rr = r0; rr < r1; ++rr) {
+        const int r = rr - r0;
         const float2 p = meta->xy[b][r0 + r];
         const float dx = p.x - cx, dy = p.y - cy;
         float zm = 0.0f;
