@@ -425,6 +425,15 @@ static const char kRowsKernel[] = R"SDFKR(
 #define SDFK_RBRICK (SDFK_RZ * SDFK_RROWS)
 #define SDFK_RLOADS (SDFK_RROWS / 8)            // load instructions per array and brick
 #define SDFK_RNBRICK (SDFK_RWAVES * SDFK_RWBRICKS)
+#ifndef SDFK_CHUNK
+#define SDFK_CHUNK 16                            // chain mode: children whose parameters are staged in LDS at a time
+#endif
+#ifndef SDFK_STAGE_MIN
+#define SDFK_STAGE_MIN 2                         // ... when more than this many survive on the brick
+#endif
+#ifndef SDFK_CHAIN_STAGED                        // ... and only for chains of more than 64 children: the staged path costs
+#define SDFK_CHAIN_STAGED (SDFK_NLEAF > 64)      // 16 VGPRs and 6 KB of LDS that the 50-child flat union (1.06 survivors per
+#endif                                           // brick, 4 waves per SIMD instead of 5) pays for and never uses
 static_assert(SDFK_NP == 2 || SDFK_NP == 4, "2 or 4 packed pairs per lane");
 static_assert(SDFK_RNBRICK <= 64 * SDFK_RWAVES, "one probe lane per brick");
 
@@ -441,9 +450,12 @@ struct sdfk_rowmeta {
     float leafval[SDFK_NLEAF * SDFK_NCEN];      // [leaf][centre]: every leaf of the tree at every centre
 #endif
 #ifdef SDFK_CHAIN
-    unsigned long long cbits[SDFK_RNBRICK][(SDFK_NLEAF + 63) / 64];   // level k: its child is irrelevant on this brick
-    unsigned short alist[SDFK_RNBRICK][SDFK_NLEAF];                    // the levels that run, in order
+    unsigned short alist[SDFK_RNBRICK][SDFK_NLEAF];                    // the children that run, in order
     unsigned nalive[SDFK_RNBRICK];
+#if SDFK_CHAIN_STAGED
+    float cprm[SDFK_RNBRICK][SDFK_CHUNK][SDFK_NPLMAX];                  // parameters of the chunk of children being evaluated
+    unsigned cgrp[SDFK_RNBRICK][SDFK_CHUNK];                            // ... and their kinds
+#endif
 #endif
 #ifdef SDFK_LDSPAD
     float pad[SDFK_LDSPAD / 4];                 // experiment: a larger LDS footprint per workgroup
@@ -683,53 +695,37 @@ static __device__ __forceinline__ float4 sdfk_sub_centre(const sdfk_rowmeta* met
 #endif
 
 #ifdef SDFK_CHAIN
-// Chain mode, one WAVE per brick: the skip decision of every level from the leaf values at the brick's centre, 64
-// levels at a time. With e_k = +-d_k (min form) the accumulator before level k is the prefix minimum of e_0..e_{k-1}
-// (exact for a hard min / max): the child of level k is irrelevant on the brick if e_k - acc >= thr, everything before
-// level k is irrelevant if acc - e_k >= thr (thr as in the sequential probe, without a smoothing width). What runs:
-// the last level that makes its predecessors irrelevant (level 0 if there is none) and every later level whose child
-// matters — written as a LIST, so that the evaluation never looks at the levels it skips.
+// Chain mode, one WAVE per brick: which children run on this brick, from the leaf values at its centre. A hard min (max:
+// signs flipped, e_k = +-d_k) is exact, associative and commutative, so the ORDER of the chain does not matter for a
+// decision: child k can be dropped wherever some other child j stays below it on the whole brick, and with j = the child
+// that is smallest at the centre that is guaranteed by e_k - m >= thr, m = min_j e_j, thr = K rho + margins with
+// K = the largest Lipschitz sum of the chain (any pair). No prefix minimum, no "restart" level: one reduction for m, then
+// 64 children per step — compare, ballot, and the survivors written as a LIST in index order, so that the evaluation
+// never looks at a child it skips and still combines the others in the chain's order. (Tighter than the sequential rule,
+// which compares a child with its predecessors only.)
 static __device__ __forceinline__ void sdfk_chain_fold(sdfk_rowmeta* meta, int b, int lane) {
     const float4 cc = meta->bound[b];
     const float rho = cc.w, cmag = 1e-6f * (fabsf(cc.x) + fabsf(cc.y) + fabsf(cc.z) + rho);
     constexpr int NW = (SDFK_NLEAF + 63) / 64;
-    const float big = 3.0e38f;
-    float carry = big;
-    int st = 0;
+    float m = 3.0e38f;
+#pragma unroll 4
+    for (int j = 0; j < NW; ++j) {
+        const int k = 64 * j + lane;
+        if (k < SDFK_NLEAF) m = fminf(m, SDFK_CHAIN_SGN * meta->leafval[k * SDFK_NCEN + b]);
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) m = fminf(m, __shfl_xor(m, o));
+    const float thr0 = 1.0001f * SDFK_CHAIN_KMAX * rho + SDFK_CHAIN_KMAX * cmag + 1e-6f * (1.0f + fabsf(m));
+    int n_out = 0;
 #pragma unroll 1
     for (int j = 0; j < NW; ++j) {
         const int k = 64 * j + lane;
         const bool in = k < SDFK_NLEAF;
-        const float e = in ? SDFK_CHAIN_SGN * meta->leafval[k * SDFK_NCEN + b] : big;
-        float pm = e;                                               // inclusive prefix minimum over the lanes
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const float t = __shfl_up(pm, o);
-            if (lane >= o) pm = fminf(pm, t);
-        }
-        float ex = __shfl_up(pm, 1);
-        if (lane == 0) ex = big;
-        const float acc = fminf(carry, ex);
-        const float K = in ? sdfk_chain_k[k] : 0.0f;
-        const float thr = 1.0001f * K * rho + K * cmag + 1e-6f * (1.0f + fabsf(acc) + fabsf(e));
-        const bool sb = in && k > 0 && (e - acc >= thr);
-        const bool sa = in && k > 0 && !sb && (acc - e >= thr);
-        const unsigned long long bsb = __ballot(sb), bsa = __ballot(sa);
-        // EVERY lane stores the (wave-uniform) word it will read back below: written by lane 0 alone, the compiler is free to
-        // let the other lanes' loads overtake that store — no lane but 0 has a store of its own in front of its load —, and
-        // with a single word (fewer than 64 children) it did: stale lists, wild parameter offsets, a memory fault
-        meta->cbits[b][j] = bsb;
-        if (bsa) st = 64 * j + 63 - __builtin_clzll(bsa);
-        carry = fminf(carry, __shfl(pm, 63));
-    }
-    int n_out = 0;
-#pragma unroll 1
-    for (int j = st >> 6; j < NW; ++j) {
-        unsigned long long run = ~meta->cbits[b][j];
-        if (j == (st >> 6)) run &= ~((1ull << (st & 63)) - 1ull);
-        if (j == NW - 1 && (SDFK_NLEAF & 63)) run &= (1ull << (SDFK_NLEAF & 63)) - 1ull;
-        if ((run >> lane) & 1ull) meta->alist[b][n_out + __builtin_popcountll(run & ((1ull << lane) - 1ull))] = (unsigned short)(64 * j + lane);
-        n_out += __builtin_popcountll(run);
+        const float e = in ? SDFK_CHAIN_SGN * meta->leafval[k * SDFK_NCEN + b] : 3.0e38f;
+        const bool run = in && !(e - m >= thr0 + 1e-6f * fabsf(e));
+        const unsigned long long bits = __ballot(run);
+        if (run) meta->alist[b][n_out + __builtin_popcountll(bits & ((1ull << lane) - 1ull))] = (unsigned short)k;
+        n_out += __builtin_popcountll(bits);
     }
     if (lane == 0) meta->nalive[b] = (unsigned)n_out;
 }
@@ -936,17 +932,57 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
 #endif
         }
 #ifdef SDFK_CHAIN
-        {   // the levels on the brick's list, in order; the first one starts the accumulator
+        {   // The children on the brick's list, in order; the first one starts the accumulator. Looked up one by one — kind of
+            // the child, base of its parameters, then the parameters: three dependent scalar loads per child — the evaluation
+            // was bound by memory latency (4200 cycles per child at 1000 children: 3.5 of 4.5 ms). So the wave first GATHERS
+            // the next SDFK_CHUNK children lane-parallel — a lane per (child, parameter) — into LDS, and then evaluates them
+            // from there: the latency is paid once per chunk.
             const unsigned cnt = __builtin_amdgcn_readfirstlane(meta.nalive[b]);
             f2 acc[SDFK_NP];
+#if SDFK_CHAIN_STAGED
+            if (cnt <= SDFK_STAGE_MIN)
+#endif
+            {
+                // one or two survivors (the 50-child flat union: 1.06 per brick): staging costs more than it hides, and
+                // parameters in SGPRs beat parameters read back from LDS — straight from the table
 #pragma unroll 1
-            for (unsigned i = 0; i < cnt; ++i) {
-                const unsigned kk = __builtin_amdgcn_readfirstlane((unsigned)meta.alist[b][i]);
-                f2 val[SDFK_NP];
-                SDFK_EACH val[q] = sdfk_leaf<f2>(kk, P[q], PRM, TAB);
-                if (i == 0u) { SDFK_EACH acc[q] = val[q]; }
-                else { SDFK_EACH acc[q] = SDFK_CHAIN_CMB(acc[q], val[q], PRM); }
+                for (unsigned i = 0; i < cnt; ++i) {
+                    const unsigned kk = __builtin_amdgcn_readfirstlane((unsigned)meta.alist[b][i]);
+                    f2 val[SDFK_NP];
+                    SDFK_EACH val[q] = sdfk_leaf<f2>(kk, P[q], PRM, TAB);
+                    if (i == 0u) { SDFK_EACH acc[q] = val[q]; }
+                    else { SDFK_EACH acc[q] = SDFK_CHAIN_CMB(acc[q], val[q], PRM); }
+                }
             }
+#if SDFK_CHAIN_STAGED
+            else
+#pragma unroll 1
+            for (unsigned c0 = 0; c0 < cnt; c0 += SDFK_CHUNK) {
+                const unsigned nc = cnt - c0 < SDFK_CHUNK ? cnt - c0 : SDFK_CHUNK;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (the previous chunk has been read)
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+                for (unsigned it = (unsigned)lane; it < nc * SDFK_NPLMAX; it += 64u) {
+                    const unsigned ch = it / SDFK_NPLMAX, w = it - ch * SDFK_NPLMAX;
+                    const unsigned kk = meta.alist[b][c0 + ch];
+                    const unsigned at = sdfk_leaf_base[kk] + w;
+                    meta.cprm[b][ch][w] = PRM[at < SDFK_NPARAMS ? at : SDFK_NPARAMS - 1u];
+                    if (w == 0u) meta.cgrp[b][ch] = sdfk_leaf_grp[kk];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+                for (unsigned i = 0; i < nc; ++i) {
+                    const unsigned grp = __builtin_amdgcn_readfirstlane(meta.cgrp[b][i]);
+                    const float* cp = &meta.cprm[b][i][0];
+                    f2 val[SDFK_NP];
+                    SDFK_EACH val[q] = sdfk_leaf_at<f2>(grp, P[q], cp, TAB);
+                    if (c0 + i == 0u) { SDFK_EACH acc[q] = val[q]; }
+                    else { SDFK_EACH acc[q] = SDFK_CHAIN_CMB(acc[q], val[q], PRM); }
+                }
+            }
+#endif
             SDFK_EACH res[q] = sdfk_chain_tail<f2>(acc[q], PRM);
         }
 #endif
@@ -1308,15 +1344,48 @@ struct Gen {
     }
 
     // one function per group of equal leaves + its tables (parameter offsets per member and instruction, leaf ids)
-    void emit_groups() {
+    // rel: every leaf's parameters are ONE contiguous block of the table (leaves_contiguous()): the function takes the
+    // block's base and adds compile-time offsets — no offset table, and the base may as well point into LDS
+    std::vector<unsigned> group_npl;     // parameters per leaf of each group (rel mode)
+    bool leaves_contiguous() {
+        group_npl.assign(groups.size(), 0);
+        for (const Leaf& lf : leaves) {
+            unsigned at = code[2 * lf.lo + 1], total = 0;
+            for (size_t i = lf.lo; i <= lf.hi; ++i) {
+                if (code[2 * i + 1] != at) return false;
+                const int np = ops[code[2 * i] & 255u].nparams;
+                if (np < 0) return false;
+                at += (unsigned)np;
+                total += (unsigned)np;
+            }
+            group_npl[lf.group] = total;
+        }
+        return true;
+    }
+    void emit_groups(bool rel = false) {
         char buf[512];
         for (size_t g = 0; g < groups.size(); ++g) {
             const Group& G = groups[g];
-            snprintf(buf, sizeof buf,
-                     "\ntemplate <typename T> static __device__ __forceinline__ T sdfk_grp%zu(V3T<T> C_0, const unsigned* __restrict__ OFF, "
-                     "const float* __restrict__ PRM, const float* __restrict__ TAB) {\n",
-                     g);
+            if (rel)
+                snprintf(buf, sizeof buf,
+                         "\ntemplate <typename T> static __device__ __forceinline__ T sdfk_grp%zu(V3T<T> C_0, const float* __restrict__ PRM, "
+                         "const float* __restrict__ TAB) {\n    constexpr unsigned OFF[] = {",
+                         g);
+            else
+                snprintf(buf, sizeof buf,
+                         "\ntemplate <typename T> static __device__ __forceinline__ T sdfk_grp%zu(V3T<T> C_0, const unsigned* __restrict__ OFF, "
+                         "const float* __restrict__ PRM, const float* __restrict__ TAB) {\n",
+                         g);
             s += buf;
+            if (rel) {
+                unsigned at = 0;
+                for (size_t j = 0; j < G.sig.size(); ++j) {
+                    snprintf(buf, sizeof buf, "%uu,", at);
+                    s += buf;
+                    at += (unsigned)ops[G.sig[j] & 255u].nparams;
+                }
+                s += "};\n";
+            }
             for (unsigned c = 1; c < G.n_c; ++c) {
                 snprintf(buf, sizeof buf, "    V3T<T> C_%u;\n", c);
                 s += buf;
@@ -1347,18 +1416,20 @@ struct Gen {
             }
             snprintf(buf, sizeof buf, "    return V_%u;\n}\n", G.out);
             s += buf;
-            snprintf(buf, sizeof buf, "static __constant__ const unsigned sdfk_grp%zu_off[%zu][%zu] = {\n", g, G.members.size(),
-                     G.sig.size());
-            s += buf;
-            for (int m : G.members) {
-                s += "    {";
-                for (size_t i = leaves[m].lo; i <= leaves[m].hi; ++i) {
-                    snprintf(buf, sizeof buf, "%uu,", code[2 * i + 1]);
-                    s += buf;
+            if (!rel) {
+                snprintf(buf, sizeof buf, "static __constant__ const unsigned sdfk_grp%zu_off[%zu][%zu] = {\n", g, G.members.size(),
+                         G.sig.size());
+                s += buf;
+                for (int m : G.members) {
+                    s += "    {";
+                    for (size_t i = leaves[m].lo; i <= leaves[m].hi; ++i) {
+                        snprintf(buf, sizeof buf, "%uu,", code[2 * i + 1]);
+                        s += buf;
+                    }
+                    s += "},\n";
                 }
-                s += "},\n";
+                s += "};\n";
             }
-            s += "};\n";
             snprintf(buf, sizeof buf, "static __constant__ const unsigned short sdfk_grp%zu_leaf[%zu] = {", g, G.members.size());
             s += buf;
             for (int m : G.members) {
@@ -1370,8 +1441,29 @@ struct Gen {
     }
 
     // every (leaf, centre) pair on a lane of its own: leafval[leaf][centre] = leaf(centre)
-    void emit_probe_leaves() {
-        char buf[640];
+    void emit_probe_leaves(bool per_leaf = false, bool rel = false) {
+        char buf[900];
+        if (per_leaf) {
+            // chain mode (one centre per brick, few bricks per workgroup): a lane takes a LEAF and walks the centres, so the
+            // leaf's parameters — two dependent memory round trips, the offsets and then the values — are fetched once
+            s += "\nstatic __device__ __forceinline__ void sdfk_probe_leaves(const float4* __restrict__ cen, float* __restrict__ leafval, "
+                 "const float* __restrict__ PRM, const float* __restrict__ TAB) {\n";
+            for (size_t g = 0; g < groups.size(); ++g) {
+                snprintf(buf, sizeof buf,
+                         "    _Pragma(\"unroll 2\") for (unsigned m = sdfk_tx(); m < %zuu; m += 64u * SDFK_RWAVES) {\n"
+                         "        const unsigned leaf = sdfk_grp%zu_leaf[m];\n"
+                         "        _Pragma(\"unroll\") for (unsigned c = 0; c < SDFK_NCEN; ++c) {\n"
+                         "            const float4 cc = cen[c];\n"
+                         "            const V3T<float> p = {cc.x, cc.y, cc.z};\n"
+                         "            leafval[leaf * SDFK_NCEN + c] = sdfk_grp%zu<float>(p, PRM + sdfk_leaf_base[leaf], TAB);\n"
+                         "        }\n"
+                         "    }\n",
+                         groups[g].members.size(), g, g);
+                s += buf;
+            }
+            s += "}\n";
+            return;
+        }
         // (several rounds of a big group in flight at once: each round is two dependent memory round trips — the offsets,
         //  then the parameters — and nothing else hides them)
         s += "\n#ifndef SDFK_LEAF_UNROLL\n#define SDFK_LEAF_UNROLL _Pragma(\"unroll 1\")\n#endif\n";
@@ -1385,9 +1477,11 @@ struct Gen {
                      "        const unsigned c = item - m * SDFK_NCEN;\n"
                      "        const float4 cc = cen[c];\n"
                      "        const V3T<float> p = {cc.x, cc.y, cc.z};\n"
-                     "        leafval[sdfk_grp%zu_leaf[m] * SDFK_NCEN + c] = sdfk_grp%zu<float>(p, sdfk_grp%zu_off[m], PRM, TAB);\n"
+                     "        leafval[sdfk_grp%zu_leaf[m] * SDFK_NCEN + c] = sdfk_grp%zu<float>(p, %s, TAB);\n"
                      "    }\n",
-                     groups[g].members.size(), g, g, g);
+                     groups[g].members.size(), g, g,
+                     rel ? ("PRM + sdfk_leaf_base[sdfk_grp" + std::to_string(g) + "_leaf[m]]").c_str()
+                         : ("sdfk_grp" + std::to_string(g) + "_off[m], PRM").c_str());
             s += buf;
         }
         s += "}\n";
@@ -1490,31 +1584,40 @@ struct Gen {
         snprintf(buf, sizeof buf, "\n#define SDFK_CHAIN 1\n#define SDFK_NLEAF %zu\n#define SDFK_CHAIN_SGN %s\n", n,
                  chain.is_max ? "(-1.0f)" : "1.0f");
         s += buf;
-        emit_groups();
+        emit_groups(true);
         s += "static __constant__ const unsigned short sdfk_leaf_grp[SDFK_NLEAF] = {";
         for (const Leaf& lf : leaves) {
             snprintf(buf, sizeof buf, "%d,", lf.group);
             s += buf;
         }
-        s += "};\nstatic __constant__ const unsigned short sdfk_leaf_mem[SDFK_NLEAF] = {";
+        s += "};\nstatic __constant__ const unsigned sdfk_leaf_base[SDFK_NLEAF] = {";       // first parameter of the leaf's block
+        unsigned npl_max = 1, n_params = 1;
         for (const Leaf& lf : leaves) {
-            snprintf(buf, sizeof buf, "%d,", lf.member);
+            snprintf(buf, sizeof buf, "%uu,", code[2 * lf.lo + 1]);
             s += buf;
-        }
-        s += "};\nstatic __constant__ const float sdfk_chain_k[SDFK_NLEAF] = {";
-        for (float k : chain.k) {
-            snprintf(buf, sizeof buf, "%.9ef,", (double)k);
-            s += buf;
+            npl_max = std::max(npl_max, group_npl[lf.group]);
+            n_params = std::max(n_params, code[2 * lf.lo + 1] + group_npl[lf.group]);
         }
         s += "};\n";
-        // leaf k (wave-uniform) at the lane's points
-        s += "template <typename T> static __device__ __forceinline__ T sdfk_leaf(unsigned k, V3T<T> C_0, const float* __restrict__ PRM, "
-             "const float* __restrict__ TAB) {\n    const unsigned m = sdfk_leaf_mem[k];\n    switch (sdfk_leaf_grp[k]) {\n";
+        for (size_t i = chain.tail; i < n_instr; ++i) n_params = std::max(n_params, code[2 * i + 1] + (unsigned)std::max(0, ops[code[2 * i] & 255u].nparams));
+        float kmax = 0.0f;
+        for (float k : chain.k) kmax = std::max(kmax, k);
+        snprintf(buf, sizeof buf,
+                 "#define SDFK_CHAIN_KMAX %.9ef   // largest Lipschitz sum of a level: bounds any pair of children\n"
+                 "#define SDFK_NPLMAX %u          // parameters of the largest leaf\n"
+                 "#define SDFK_NPARAMS %u         // parameters the leaves and the tail touch (gathers are clamped to it)\n",
+                 (double)kmax, npl_max, n_params);
+        s += buf;
+        // leaf k (wave-uniform) at the lane's points, parameters at P (the leaf's block: in the table or staged in LDS)
+        s += "template <typename T> static __device__ __forceinline__ T sdfk_leaf_at(unsigned grp, V3T<T> C_0, const float* __restrict__ P, "
+             "const float* __restrict__ TAB) {\n    switch (grp) {\n";
         for (size_t g = 0; g < groups.size(); ++g) {
-            snprintf(buf, sizeof buf, "        case %zuu: return sdfk_grp%zu<T>(C_0, sdfk_grp%zu_off[m], PRM, TAB);\n", g, g, g);
+            snprintf(buf, sizeof buf, "        case %zuu: return sdfk_grp%zu<T>(C_0, P, TAB);\n", g, g);
             s += buf;
         }
-        s += "        default: return sp<T>(0.0f);\n    }\n}\n";
+        s += "        default: return sp<T>(0.0f);\n    }\n}\n"
+             "template <typename T> static __device__ __forceinline__ T sdfk_leaf(unsigned k, V3T<T> C_0, const float* __restrict__ PRM, "
+             "const float* __restrict__ TAB) {\n    return sdfk_leaf_at<T>(sdfk_leaf_grp[k], C_0, PRM + sdfk_leaf_base[k], TAB);\n}\n";
         const char* cmb = chain.is_max ? "cmb_max" : "cmb_min";
         // the result modifications, applied to an accumulator of type T
         s += "template <typename T> static __device__ __forceinline__ T sdfk_chain_tail(T V_acc, const float* __restrict__ PRM) {\n";
@@ -1795,7 +1898,7 @@ static bool chain_analyse(Gen& g, int result_reg, const std::vector<sdfk_cullsit
     if (!sites_all || sites_all->size() + 1 < chain_min_leaves() || sites_all->size() + 1 > 2048) return false;
     const std::vector<sdfk_cullsite>* keep = g.sites;
     g.sites = sites_all;
-    const bool ok = g.analyse_leaves() && g.analyse_chain(result_reg);
+    const bool ok = g.analyse_leaves() && g.analyse_chain(result_reg) && g.leaves_contiguous();
     if (!ok) g.sites = keep;
     return ok;
 }
@@ -1838,7 +1941,9 @@ std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32
                    "#define SDFK_SIMT 1\n#define SDFK_NSUB 1\n"
                    "#ifndef SDFK_LEAF_UNROLL\n#define SDFK_LEAF_UNROLL _Pragma(\"unroll 4\")\n#endif\n";
             g.s += kSimtGeometry;
-            g.emit_probe_leaves();
+            // (a lane per LEAF walking the centres pays off once there are more leaves than lanes; below that a lane per
+            //  (leaf, centre) pair keeps more lanes busy: the 50-child flat union has 200 pairs for 128 lanes)
+            g.emit_probe_leaves(g.leaves.size() >= 128, true);
             g.s += kRowsKernel;
             if (all || flavour == SDFK_FL_ROWS_ARRAY || flavour == SDFK_FL_ROWS2D_ARRAY) g.s += kRowsArray;
             if (all || flavour == SDFK_FL_ROWS_GRID || flavour == SDFK_FL_ROWS2D_GRID) g.s += kRowsGrid;
