@@ -180,8 +180,10 @@ static int fail(int code, const std::string& msg) {
 #define HIPCHK(expr)                                                                              \
     do {                                                                                          \
         hipError_t e_ = (expr);                                                                   \
-        if (e_ != hipSuccess)                                                                     \
+        if (e_ != hipSuccess) {                                                                   \
+            (void)hipGetLastError(); /* the runtime keeps it: the next launch check would see it */ \
             return fail(-100 - (int)e_, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+        }                                                                                         \
     } while (0)
 
 struct DevState {

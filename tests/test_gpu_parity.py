@@ -434,6 +434,8 @@ def test_single_process_sharded_grid(engine):
         field.free()
     with pytest.raises(engine.SdfkError):
         prog.eval_grid_sharded_resident(axes, 2, devices=[0, 0], gather_device=99)
+    # a refused call leaves nothing behind in the runtime: the next launch check does not report ITS error
+    np.testing.assert_array_equal(prog.eval_grid_host(axes), whole)
     # the device-to-device copy path (hipMemcpyPeerAsync), forced for the shards of the gather device itself
     import subprocess
     import sys
