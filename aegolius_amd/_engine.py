@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libsdfk.so")
 MODE_AUTO, MODE_INTERPRET, MODE_SPECIALIZED, MODE_NOCULL = 0, 1, 2, 3
 (FLAVOUR_PLAIN_ARRAY, FLAVOUR_PLAIN_GRID, FLAVOUR_TILE_ARRAY, FLAVOUR_TILE_GRID, FLAVOUR_TILE_MASK, FLAVOUR_ROWS_ARRAY,
  FLAVOUR_ROWS_GRID, FLAVOUR_ROWS_MASK, FLAVOUR_ROWS2D_ARRAY, FLAVOUR_ROWS2D_GRID) = range(10)
+FLAVOUR_FLAGS = 0x100      # OR-ed onto a PLAIN / ROWS / ROWS2D flavour: its flag-writing build (fused selection)
 
 _c = ctypes
 _vp, _i64, _int, _sz = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t

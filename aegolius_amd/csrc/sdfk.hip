@@ -1083,11 +1083,14 @@ static std::shared_ptr<CodeObject> code_get(const std::string& key, MakeSource m
     if (wait) e->cv.wait(lk, [&] { return e->state != 1; });
     return e;
 }
-static std::string flavour_key(const sdfk_program* p, int flavour, int rwb) {
-    return p->key + "|f" + std::to_string(flavour) + "|" + rtc_option_key(rwb);
+// with_flags: the build of a flavour that writes one flag bit per point (value <= threshold) instead of the field — a
+// translation unit of its own (#define SDFK_FLAGS), so the field kernels carry none of it.
+static std::string flavour_key(const sdfk_program* p, int flavour, int rwb, bool with_flags = false) {
+    return p->key + "|f" + std::to_string(flavour) + (with_flags ? "s|" : "|") + rtc_option_key(rwb);
 }
-static std::string flavour_source(const sdfk_program* p, int flavour) {
-    return sdfk_generate_source(g_ops, SDFK_OP_COUNT, p->code.data(), p->code.size() / 2, p->result_reg, p->sites, flavour,
+static std::string flavour_source(const sdfk_program* p, int flavour, bool with_flags = false) {
+    return (with_flags ? "#define SDFK_FLAGS 1\n" : "") +
+           sdfk_generate_source(g_ops, SDFK_OP_COUNT, p->code.data(), p->code.size() / 2, p->result_reg, p->sites, flavour,
                                 &p->sites_all);
 }
 
@@ -1109,12 +1112,18 @@ extern "C" int sdfk_program_compile_check(sdfk_program* p, size_t* code_size) {
 /* Build (or fetch) ONE flavour without a GPU: 0 + seconds the build took (0 when it was already there). */
 extern "C" int sdfk_program_compile_flavour(sdfk_program* p, int flavour, size_t* code_size, double* seconds) {
     if (!p) return fail(-1, "null program");
+    const bool with_flags = flavour >= 0 && (flavour & SDFK_FLAVOUR_FLAGS);          // the flag-writing build of the flavour
+    if (with_flags) flavour &= ~SDFK_FLAVOUR_FLAGS;
     if (flavour < 0 || flavour >= SDFK_FL_COUNT) return fail(-1, "sdfk_program_compile_flavour: unknown flavour");
     if (p->sites.empty() && flavour != SDFK_FL_PLAIN_ARRAY && flavour != SDFK_FL_PLAIN_GRID)
         return fail(-2, "sdfk_program_compile_flavour: the program has no cull sites");
+    if (with_flags && (flavour == SDFK_FL_TILE_ARRAY || flavour == SDFK_FL_TILE_GRID || flavour == SDFK_FL_TILE_MASK ||
+                       flavour == SDFK_FL_ROWS_MASK))
+        return fail(-2, "sdfk_program_compile_flavour: this flavour has no flag-writing build");
     const int rwb = rows_geo(p);
     const auto t0 = std::chrono::steady_clock::now();
-    std::shared_ptr<CodeObject> e = code_get(flavour_key(p, flavour, rwb), [&] { return flavour_source(p, flavour); }, rwb, true);
+    std::shared_ptr<CodeObject> e =
+        code_get(flavour_key(p, flavour, rwb, with_flags), [&] { return flavour_source(p, flavour, with_flags); }, rwb, true);
     if (e->state != 2) return fail(-3, e->error);
     if (code_size) *code_size = e->co.size();
     if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -1137,9 +1146,10 @@ extern "C" int sdfk_debug_compile_external(sdfk_program* p, int flavour, size_t*
 
 // The module of one flavour on one device. wait = false: nullptr while the code object is still being built in the
 // background (the caller serves this call from the interpreter kernel — same bits). *err is set on failure.
-static std::shared_ptr<SpecModule> get_module(sdfk_program* p, int device, int flavour, bool wait, std::string* err) {
+static std::shared_ptr<SpecModule> get_module(sdfk_program* p, int device, int flavour, bool wait, std::string* err,
+                                              bool with_flags = false) {
     const int rwb = rows_geo(p);
-    const std::string key = flavour_key(p, flavour, rwb);
+    const std::string key = flavour_key(p, flavour, rwb, with_flags);
     std::shared_ptr<SpecModule> m;
     {
         std::lock_guard<std::mutex> lk(g_code_mu);
@@ -1162,7 +1172,7 @@ static std::shared_ptr<SpecModule> get_module(sdfk_program* p, int device, int f
             state = e->state;
         }
         if (state != 2) {
-            e = code_get(key, [&] { return flavour_source(p, flavour); }, rwb, wait);
+            e = code_get(key, [&] { return flavour_source(p, flavour, with_flags); }, rwb, wait);
             std::lock_guard<std::mutex> el(e->mu);
             state = e->state;
         }
@@ -1304,7 +1314,7 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
         static const bool async_jit = [] { const char* e = getenv("SDFK_ASYNC_JIT"); return !(e && e[0] == '0'); }();
         const bool wait = mode != SDFK_MODE_AUTO || !p->interp_ok || !async_jit;
         std::string err;
-        sk = get_module(p, device, flavour, wait, &err);
+        sk = get_module(p, device, flavour, wait, &err, d_flags != nullptr);
         if (sk && sk->failed) {
             if (mode == SDFK_MODE_SPECIALIZED || !p->interp_ok)
                 return fail(-3, "specialised kernel unavailable: " + err);

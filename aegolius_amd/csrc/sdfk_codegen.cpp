@@ -19,7 +19,8 @@ static __device__ __forceinline__ void sdfk_body(const float* __restrict__ PRM, 
                                                  long long aux_stride, unsigned* __restrict__ flags, unsigned thr) {
     const long long block_base = (long long)sdfk_bx() * (SDFK_BLOCK * VEC);
     const unsigned lane_off = sdfk_tx() * VEC;
-    if (flags) {                                               // (wave-uniform) one bit per point instead of the field
+#ifdef SDFK_FLAGS                                              // the flag-writing build of this flavour (its own code object:
+    {                                                          // carried as a run-time branch it cost the field kernels registers)
         const bool active = block_base + lane_off < n;
         unsigned nib = 0u;
         if (active) {
@@ -40,6 +41,7 @@ static __device__ __forceinline__ void sdfk_body(const float* __restrict__ PRM, 
         sdfk_store_flags<VEC>(flags, off + block_base + lane_off, nib, active);
         return;
     }
+#endif
     if (block_base + lane_off >= n) return;
     V3 p[VEC];
     sdfk_load<VEC>(src, off + block_base, lane_off, p);
@@ -392,8 +394,9 @@ static const char kSimtGeometry[] = R"SDFKR(
 #endif
 #ifndef SDFK_NSUB                        // sub-bricks (probe centres) per brick: 16 = 4 rows x 8 points, 8 = 8 rows x 8, 4 = 16 rows x 8
 // measured (north-star tree, 20-primitive tree; 513^3 and 1025^3): 8 centres beat 16 — half the leaf evaluations, nearly
-// the same radius — and 4 are as good as 8 for 20 leaves; beyond 32 leaves the probe itself is the cost: one centre
-#define SDFK_NSUB ((SDFK_NLEAF <= 12 && 8 * SDFK_RWBRICKS <= 64) ? 8 : ((SDFK_NLEAF <= 32 && 4 * SDFK_RWBRICKS <= 64) ? 4 : 1))
+// the same radius — and beat 4 for 20 leaves too (513^3: 0.56 -> 0.49 ms, 1025^3: 1 %); beyond 32 leaves the probe itself
+// is the cost: one centre
+#define SDFK_NSUB ((SDFK_NLEAF <= 32 && 8 * SDFK_RWBRICKS <= 64) ? 8 : ((SDFK_NLEAF <= 32 && 4 * SDFK_RWBRICKS <= 64) ? 4 : 1))
 #endif
 #define SDFK_NCEN (SDFK_RWAVES * SDFK_RWBRICKS * SDFK_NSUB)
 static_assert(SDFK_NSUB == 1 || SDFK_NSUB == 4 || SDFK_NSUB == 8 || SDFK_NSUB == 16, "1, 4, 8 or 16 probe centres per brick");
@@ -986,7 +989,8 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
             SDFK_EACH res[q] = sdfk_chain_tail<f2>(acc[q], PRM);
         }
 #endif
-        if (flags) {                                               // (wave-uniform) one bit per point instead of the field
+#ifdef SDFK_FLAGS                                                  // (the flag-writing build) one bit per point instead of the field
+        {
             // BRICK-TILED layout: the word of (row r, window k) is flags[(brick * 16 + r % 16)], so the 64 lanes of the
             // wave — lane = 4 * row + octet of the window — write the brick's 64 bytes as ONE contiguous store, and every
             // (row, window) slot belongs to one brick, also where two rows share a flat window: no atomics (a linear bit
@@ -1005,7 +1009,8 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
             }
             if (!live_row) bits = 0u;                              // rows past the end of the last block: empty slots
             reinterpret_cast<unsigned char*>(flags)[(unsigned long long)(q0 + j) * 64ull + (unsigned)lane] = (unsigned char)bits;
-        } else
+        }
+#else
         if (live_row) {
             float* po = out + f;
             if (interior) {
@@ -1021,6 +1026,7 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
                 }
             }
         }
+#endif
     }
   }
 }

@@ -91,6 +91,10 @@ int sdfk_program_compile_check(sdfk_program* prog, size_t* code_size);
 #define SDFK_FLAVOUR_ROWS_MASK 7   /* test aid (sdfk_debug_row_masks) */
 #define SDFK_FLAVOUR_ROWS2D_ARRAY 8 /* the row-block kernel built for flat grids (sdfk_eval_device_rows2d) */
 #define SDFK_FLAVOUR_ROWS2D_GRID 9
+/* OR-ed onto a PLAIN / ROWS / ROWS2D flavour: its flag-writing build (one bit per point, value <= threshold, instead of
+   the field — what sdfk_eval_device_select / sdfk_eval_grid_select launch). A translation unit of its own: the field
+   kernels carry none of it (as a run-time branch it cost the 20-primitive tree 10 % at 1025^3). */
+#define SDFK_FLAVOUR_FLAGS 0x100
 /* Build (or fetch from the caches) ONE flavour, GPU or not: its code-object size and the seconds this call took. */
 int sdfk_program_compile_flavour(sdfk_program* prog, int flavour, size_t* code_size, double* seconds);
 /* Test aid: build one flavour the way BACKGROUND builds are run — in a child process (aegolius_amd/sdfk_rtc_helper,

@@ -118,7 +118,7 @@ def test_from_sdf_matches_reference_golden(name, engine, golden):
 
 @pytest.mark.parametrize("shape", [(2, 2, 2), (3, 70, 129), (33, 17, 64), (35, 5, 201), (2, 300), (129, 65), (7, 2), (77,),
                                    (2,), (5, 17, 1025), (4, 3, 5000), (3, 9000, 3), (40000, 3), (3, 40000), (65, 37, 130), (34, 64, 257),
-                                   (97, 11, 1023), (66, 200, 7)])
+                                   (97, 11, 1023), (66, 200, 7), (40, 3, 160), (9, 40, 161), (33, 20, 513), (70, 9, 322)])
 def test_gradient_direction_on_random_fields(shape, engine):
     rng = np.random.default_rng(sum(shape))
     n = int(np.prod(shape))

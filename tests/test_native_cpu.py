@@ -308,3 +308,25 @@ def test_background_builds_run_in_a_compiler_process(built):
     bad = built.Program.from_lowered(lower_geometry(ns.Sphere(0.5)))
     rc = built.lib().sdfk_debug_compile_external(bad.handle, built.FLAVOUR_ROWS_ARRAY, ctypes.byref(n))
     assert rc == -2 and "no cull sites" in built.last_error()
+
+
+def test_flag_writing_builds_are_code_objects_of_their_own(built):
+    """Fused selection launches the `| FLAVOUR_FLAGS` build of a flavour (#define SDFK_FLAGS: one bit per point instead of
+    the field). It compiles for every kind of kernel — plain, row blocks, flat row blocks, chain mode — and is a separate
+    translation unit: the field kernels carry no flag code (as a run-time branch it cost cfg 5 ten percent)."""
+    import aegolius_amd.cores as ns
+    from aegolius_amd import workloads
+    from aegolius_amd._lower import lower_geometry
+    F = built.FLAVOUR_FLAGS
+    tree = built.Program.from_lowered(lower_geometry(workloads.cfg2_tree(ns, seed=5)))
+    field_size, _ = tree.compile_flavour(built.FLAVOUR_ROWS_ARRAY)
+    flag_size, _ = tree.compile_flavour(built.FLAVOUR_ROWS_ARRAY | F)
+    assert flag_size > 10000 and flag_size != field_size
+    for flavour in (built.FLAVOUR_ROWS_GRID, built.FLAVOUR_PLAIN_ARRAY, built.FLAVOUR_PLAIN_GRID):
+        assert tree.compile_flavour(flavour | F)[0] > 5000
+    chain = built.Program.from_lowered(lower_geometry(workloads.cfg4_scene2d(ns)))
+    assert chain.compile_flavour(built.FLAVOUR_ROWS2D_ARRAY | F)[0] > 10000
+    plain = built.Program.from_lowered(lower_geometry(workloads.cfg3_chain(ns)))
+    assert plain.compile_flavour(built.FLAVOUR_PLAIN_ARRAY | F)[0] > 5000
+    with pytest.raises(built.SdfkError):
+        tree.compile_flavour(built.FLAVOUR_TILE_ARRAY | F)

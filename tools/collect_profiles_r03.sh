@@ -43,9 +43,14 @@ python3 tools/consumers_bench.py 1024 > "$O/${tag}_consumers_1025.json" 2>/dev/n
   done
   rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${tag}_prof_consumers" -- python3 $R/tools/consumers_bench.py 1024 > /dev/null 2> "$O/${tag}_prof_consumers.log" )
 cp "$O/${tag}_prof_consumers"/*/*kernel_stats.csv "$O/${tag}_consumers_kernel_stats.csv" 2>/dev/null
-for k in "~sdfk_gradient" sdfk_select_count_kernel sdfk_select_scatter_kernel; do
+for k in "~sdfk_gradient" sdfk_select_count_kernel sdfk_flags_scatter_kernel; do
   python3 tools/pmc_summarize.py "$O/${tag}_pmc_consumers" "$k" "$O/${tag}_consumers_pmc_$(echo $k | tr -d '~').json" > /dev/null
 done
+# 3b. point_cloud without the field: the evaluation kernel writes flag bits, compaction from the flags
+python3 tools/fused_select_bench.py 1024 cfg2 2>/dev/null > "$O/${tag}_fused_select_1025.txt"
+( cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${tag}_prof_fused" -- python3 $R/tools/fused_select_bench.py 1024 cfg2 > /dev/null 2> "$O/${tag}_prof_fused.log" )
+cp "$O/${tag}_prof_fused"/*/*kernel_stats.csv "$O/${tag}_fused_select_kernel_stats.csv" 2>/dev/null
 # 4. big n-ary unions, mask statistics
 python3 tools/big_union_bench.py --spheres 1000 --grid 512 --json "$O/${tag}_union1000_513.json" > /dev/null 2>&1
 python3 tools/big_union_bench.py --spheres 200 --grid 512 --json "$O/${tag}_union200_513.json" > /dev/null 2>&1

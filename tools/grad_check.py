@@ -7,7 +7,8 @@ if len(sys.argv) > 1:
     from aegolius_amd import DeviceField
     out = {}
     for shape in [(13, 15, 11), (3, 70, 129), (35, 5, 201), (65, 37, 130), (70, 9, 8), (2, 2, 9), (40, 33, 36), (67, 3, 1023),
-                  (34, 129, 130), (100, 7, 11), (5, 200, 200)]:
+                  (34, 129, 130), (100, 7, 11), (5, 200, 200), (9, 40, 161), (33, 20, 513), (6, 12, 1025), (4, 30, 322),
+                  (40, 3, 160), (3, 9, 2051)]:
         rng = np.random.default_rng(sum(shape))
         f = rng.normal(size=int(np.prod(shape))).astype(np.float32)
         f[rng.random(f.size) < 0.2] = 0.25
