@@ -1,7 +1,10 @@
 #!/bin/bash
 # Developer tool (GPU box): the evidence set of round 3. Writes gpurun_out/r03_*; copy what is to be judged to profiles/.
+#   collect_profiles_r03.sh [a|b|c|all]   a: bench lines + counters of cfg2 / 513^3;  b: counters of cfg3 / cfg5 / cfg4 + the other
+#   bench lines;  c: consumers, fused selection, big unions, mask statistics  (one gpurun call of <= 20 minutes each)
 set -u
 tag=r03
+part=${1:-all}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p "$O"
@@ -20,12 +23,15 @@ pmc_set () {   # pmc_set <name> <kernel> <command...>: kernel-trace stats + the 
   echo "pmc $name done"
 }
 B="--steps 20 --warmup 5 --no-extras --cpu-seconds 0"
+if [ "$part" = a ] || [ "$part" = all ]; then
 # 1. the driver's command, with every extra
 python3 bench.py --steps 20 --warmup 5 > "$O/${tag}_cfg2_bench.json" 2> "$O/${tag}_cfg2_bench.err"; echo "bench rc=$?"
 python3 bench.py $B > "$O/${tag}_cfg2_bench_noextras.json" 2>/dev/null
 # 2. counters: the headline workload, the 513^3 grid, and the other BASELINE configs
 pmc_set cfg2 sdfk_spec_r python3 $R/bench.py $B
 pmc_set grid512 sdfk_spec_r python3 $R/bench.py --grid 512 $B
+fi
+if [ "$part" = b ] || [ "$part" = all ]; then
 pmc_set cfg3 sdfk_spec_v4 python3 $R/bench.py --workload cfg3 $B
 pmc_set cfg5 sdfk_spec_r python3 $R/bench.py --workload cfg5 $B
 pmc_set cfg4 sdfk_spec_r python3 $R/bench.py --workload cfg4 --grid 16384 $B
@@ -34,6 +40,8 @@ python3 bench.py --workload cfg4 --grid 16384 $B > "$O/${tag}_cfg4_bench.json" 2
 python3 bench.py --grid 512 --steps 50 --warmup 20 --no-extras --cpu-seconds 0 > "$O/${tag}_grid512_bench.json" 2>/dev/null
 python3 bench.py --mode nocull --steps 10 --warmup 3 --no-extras --cpu-seconds 0 > "$O/${tag}_cfg2_bench_nocull.json" 2>/dev/null
 python3 bench.py --mode interpret --steps 5 --warmup 2 --no-extras --cpu-seconds 0 > "$O/${tag}_cfg2_bench_interpreter.json" 2>/dev/null
+fi
+if [ "$part" = c ] || [ "$part" = all ]; then
 # 3. the consumers of the field
 python3 tools/consumers_bench.py 1024 > "$O/${tag}_consumers_1025.json" 2>/dev/null
 ( cd /tmp && export TMPDIR=/tmp
@@ -56,4 +64,5 @@ python3 tools/big_union_bench.py --spheres 1000 --grid 512 --json "$O/${tag}_uni
 python3 tools/big_union_bench.py --spheres 200 --grid 512 --json "$O/${tag}_union200_513.json" > /dev/null 2>&1
 for g in 512 1024; do python3 tools/row_mask_stats.py cfg2 $g 2>&1 | grep -v amdgpu.ids; done > "$O/${tag}_row_mask_stats.txt"
 python3 tools/row_mask_stats.py cfg5 1024 2>&1 | grep -v amdgpu.ids >> "$O/${tag}_row_mask_stats.txt"
-echo "collected $tag"
+fi
+echo "collected $tag $part"
