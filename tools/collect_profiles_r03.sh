@@ -1,6 +1,6 @@
 #!/bin/bash
 # Developer tool (GPU box): the evidence set of round 3. Writes gpurun_out/r03_*; copy what is to be judged to profiles/.
-#   collect_profiles_r03.sh [a|b|c|all]   a: bench lines + counters of cfg2 / 513^3;  b: counters of cfg3 / cfg5 / cfg4 + the other
+#   collect_profiles_r03.sh [a|g|b|c|all]   a: bench lines + counters of cfg2;  g: counters of the 513^3 grid;  b: counters of cfg3 / cfg5 / cfg4 + the other
 #   bench lines;  c: consumers, fused selection, big unions, mask statistics  (one gpurun call of <= 20 minutes each)
 set -u
 tag=r03
@@ -29,7 +29,11 @@ python3 bench.py --steps 20 --warmup 5 > "$O/${tag}_cfg2_bench.json" 2> "$O/${ta
 python3 bench.py $B > "$O/${tag}_cfg2_bench_noextras.json" 2>/dev/null
 # 2. counters: the headline workload, the 513^3 grid, and the other BASELINE configs
 pmc_set cfg2 sdfk_spec_r python3 $R/bench.py $B
-pmc_set grid512 sdfk_spec_r python3 $R/bench.py --grid 512 $B
+fi
+if [ "$part" = g ] || [ "$part" = all ]; then
+# (a 0.4 ms kernel: 200 launches after 50 of warm-up, or the averages are those of a GPU still raising its clocks)
+pmc_set grid512 sdfk_spec_r python3 $R/bench.py --grid 512 --steps 200 --warmup 50 --no-extras --cpu-seconds 0
+python3 bench.py --grid 512 --steps 200 --warmup 50 --no-extras --cpu-seconds 0 > "$O/${tag}_grid512_bench.json" 2>/dev/null
 fi
 if [ "$part" = b ] || [ "$part" = all ]; then
 pmc_set cfg3 sdfk_spec_v4 python3 $R/bench.py --workload cfg3 $B
@@ -37,7 +41,6 @@ pmc_set cfg5 sdfk_spec_r python3 $R/bench.py --workload cfg5 $B
 pmc_set cfg4 sdfk_spec_r python3 $R/bench.py --workload cfg4 --grid 16384 $B
 for w in cfg1 cfg3 cfg5; do python3 bench.py --workload $w $B > "$O/${tag}_${w}_bench.json" 2>/dev/null; done
 python3 bench.py --workload cfg4 --grid 16384 $B > "$O/${tag}_cfg4_bench.json" 2>/dev/null
-python3 bench.py --grid 512 --steps 50 --warmup 20 --no-extras --cpu-seconds 0 > "$O/${tag}_grid512_bench.json" 2>/dev/null
 python3 bench.py --mode nocull --steps 10 --warmup 3 --no-extras --cpu-seconds 0 > "$O/${tag}_cfg2_bench_nocull.json" 2>/dev/null
 python3 bench.py --mode interpret --steps 5 --warmup 2 --no-extras --cpu-seconds 0 > "$O/${tag}_cfg2_bench_interpreter.json" 2>/dev/null
 fi
