@@ -35,6 +35,7 @@ SIGNATURES = {
     "sdfk_program_set_cull": (_int, [_vp, _vp, _sz, _vp]),
     "sdfk_program_source": (_c.c_char_p, [_vp]),
     "sdfk_program_compile_check": (_int, [_vp, _c.POINTER(_sz)]),
+    "sdfk_program_chain_members": (_int, [_vp]),
     "sdfk_program_compile_flavour": (_int, [_vp, _int, _c.POINTER(_sz), _c.POINTER(_c.c_double)]),
     "sdfk_debug_compile_external": (_int, [_vp, _int, _c.POINTER(_sz)]),
     "sdfk_debug_jit_stats": (None, [_c.POINTER(_i64), _c.POINTER(_c.c_double)]),
@@ -214,6 +215,11 @@ class Program:
     def source(self):
         s = lib().sdfk_program_source(self._h)
         return s.decode() if s else None
+
+    @property
+    def chain_members(self):
+        """Members of the n-ary chain when the program runs on the table-driven chain kernels, else 0."""
+        return int(lib().sdfk_program_chain_members(self._h))
 
     def compile_check(self):
         n = _sz(0)

@@ -281,7 +281,7 @@ class Lowerer:
 
     # ---- nodes: Euclidean transform around an expression (reference transformations.py:232-242) ----
     def lower_node(self, node, creg, mode):
-        self._stack.append(("n", id(node)))
+        self._stack.append(("n", getattr(node, "path_key", None) or id(node)))
         try:
             return self._lower_node(node, creg, mode)
         finally:
@@ -296,6 +296,15 @@ class Lowerer:
             raise ValueError("rotation matrix must have shape (3, 3); got %r" % (R.shape,))
         t = np.asarray(node.center, dtype=np.float64).reshape(3)
         s = node.scale
+        pushed = _push_transform_into_members(node)
+        if pushed is not None:
+            # a large hard union that was moved / rotated / rescaled as a whole (value modifications on top included):
+            # every member behind that transform (see _flatten_hard), so that the members still start from the input
+            # point — what the chain kernels need; the factor on the value stays where it was, after everything
+            v = self.lower_expr(pushed, creg, OWNED if mode == OWNED else FROZEN, node._geo_parameters)
+            if s != 1:
+                self.emit("VSCALE", v, v, params=[s])
+            return v
         ident_r = np.array_equal(R, np.eye(3))
         unit_s = (s == 1)
         if ident_r and unit_s and not np.any(t):
@@ -311,7 +320,7 @@ class Lowerer:
             inner_mode = OWNED
         v = self.lower_expr(node.modified_object, c, inner_mode, node._geo_parameters)
         self.release(c, creg)
-        if not unit_s:
+        if not unit_s and not getattr(node, "coord_only", False):
             self.emit("VSCALE", v, v, params=[s])
         return v
 
@@ -319,7 +328,7 @@ class Lowerer:
     def lower_expr(self, expr, creg, mode, params):
         if isinstance(expr, NodeSDF):              # (a fresh wrapper per lowering: the object it wraps is the identity)
             return self.lower_node(expr.obj, creg, OWNED if mode == OWNED else FROZEN)
-        self._stack.append(id(expr))
+        self._stack.append(getattr(expr, "path_key", None) or id(expr))
         try:
             return self._lower_expr(expr, creg, mode, params)
         finally:
@@ -386,6 +395,8 @@ class Lowerer:
                     raise TypeError("%s takes exactly 2 objects (%d given)" % (op, len(kids)))
             else:
                 raise KeyError(op)
+        if not expr.parametric and opcode in ("VMIN", "VMAX"):
+            kids = _flatten_hard(kids, opcode)
         acc = None
         first = len(self.code)
         for i, kid in enumerate(kids):
@@ -407,6 +418,132 @@ class Lowerer:
                     self.cull.append((idx, first, b_start - 1, b_start, idx - 1, float(k)))
                 self.free_v(v)
         return acc
+
+
+class _Reframed:
+    """A member of a flattened group: geometry `inner` seen through the transform of the group it belonged to (the
+    node protocol of lower_node: the group's XFORM / XLATE, then the member, then the group's VSCALE)."""
+    _geo_parameters = ()
+
+    def __init__(self, group, inner, coord_only=False):
+        self.rotation_matrix = group.rotation_matrix
+        self.center = group.center
+        self.scale = group.scale
+        self.modified_object = NodeSDF(inner)
+        self.coord_only = coord_only               # the group's factor on the VALUE is applied by the caller, once
+        # position keys of staged operators (Lowerer._stack) must be the same in every lowering of one tree: wrappers
+        # are made anew each time, so they are named after the objects they stand for
+        self.path_key = ("reframed", id(group), getattr(inner, "path_key", None) or id(inner))
+
+
+def _flatten_min():
+    """Fewest members at which nested hard unions are flattened: where the table-driven chain kernels take over
+    (sdfk_codegen.cpp chain_min_leaves, same environment variable); smaller trees keep their hierarchy of cull sites."""
+    import os
+    try:
+        return max(2, int(os.environ.get("SDFK_CHAIN_MIN", "17")))
+    except ValueError:
+        return 17
+
+
+def _flatten_hard(kids, opcode, always=False):
+    """Nested hard unions / intersections as ONE n-ary operation. min and max are exact and associative, a rigid
+    transform of a group can be applied to every member instead (the same arithmetic per member, recomputed), and a
+    positive scale commutes with them bit for bit (x -> fl(s x) is monotone): UNION(move(UNION(a, b)), c) is
+    UNION(move∘a, move∘b, c). The group's transform then meets the member's own inside one operand range, where emit()
+    composes consecutive affine maps in float64 into one (as it does along any chain of transforms): one rounding
+    instead of two — the flattened field differs from the nested program's by fp32 rounding (1e-7) and is no further
+    from the float64 reference. A group is flattened when nothing but its transform lies between
+    the two combiners (no modification of the group's value or coordinates). Done only when the flattened operation
+    reaches the size of the chain kernels — 20 instances of a 50-sphere cluster become one 1000-member chain with
+    per-brick survivor lists instead of a program beyond the specialisation limit."""
+    from .cores.combine import BINARY_OPS, NARY_OPS
+    if os_environ_flag("SDFK_NO_FLATTEN"):
+        return kids
+    same = {k for k, v in list(NARY_OPS.items()) + list(BINARY_OPS.items()) if v == opcode}
+
+    def identity(g):
+        R = np.asarray(g.rotation_matrix, dtype=np.float64)
+        t = np.asarray(g.center, dtype=np.float64).reshape(-1)
+        return R.shape == (3, 3) and np.array_equal(R, np.eye(3)) and g.scale == 1 and t.size == 3 and not np.any(t)
+
+    def expand(frames, kid, out):
+        """frames: the groups `kid` lies in, outermost first (only those with a transform)"""
+        inner = getattr(kid, "modified_object", None) if _is_geometry(kid) else None
+        if (len(frames) < 16 and isinstance(inner, CombineSDF) and not inner.parametric
+                and getattr(inner.owner, "operation_type", None) in same and len(inner.children) >= 1):
+            s = kid.scale
+            try:
+                ok = bool(np.isfinite(s)) and s > 0
+            except TypeError:
+                ok = False
+            if ok:
+                below = frames if identity(kid) else frames + [kid]
+                for g in inner.children:
+                    expand(below, g, out)
+                return True
+        for f in reversed(frames):                                 # innermost group first
+            kid = _Reframed(f, kid)
+        out.append(kid)
+        return False
+
+    flat, changed = [], False
+    for kid in kids:
+        changed |= expand([], kid, flat)
+    if not changed or (len(flat) < _flatten_min() and not always):
+        return kids
+    return tuple(flat)
+
+
+class _Operation:
+    def __init__(self, operation_type):
+        self.operation_type = operation_type
+
+
+def _push_transform_into_members(node):
+    """node: a geometry with a transform of its own whose SDF is a hard n-ary combination, bare or under pointwise
+    VALUE modifications (rounding, onion, ... — they never see the coordinates). -> the equivalent expression with the
+    transform's coordinate part applied to every member instead (the caller applies the factor on the value), or None
+    when the rules of _flatten_hard do not apply or the combination is smaller than the chain kernels' minimum."""
+    from ._mods import VALUE_OPS
+    from .cores.combine import BINARY_OPS, NARY_OPS
+    if isinstance(node, _Reframed) or os_environ_flag("SDFK_NO_FLATTEN"):
+        return None
+    R = np.asarray(node.rotation_matrix, dtype=np.float64)
+    t = np.asarray(node.center, dtype=np.float64).reshape(-1)
+    s = node.scale
+    try:
+        if not (np.isfinite(s) and s > 0) or R.shape != (3, 3) or t.size != 3:
+            return None
+    except TypeError:
+        return None
+    if np.array_equal(R, np.eye(3)) and s == 1 and not np.any(t):
+        return None
+    mods, inner = [], node.modified_object
+    while isinstance(inner, ModSDF) and inner.name in VALUE_OPS and inner.second is None and len(mods) < 64:
+        mods.append(inner)
+        inner = inner.inner
+    if not isinstance(inner, CombineSDF) or inner.parametric:
+        return None
+    op = getattr(inner.owner, "operation_type", None)
+    opcode = NARY_OPS.get(op) or BINARY_OPS.get(op)
+    if opcode not in ("VMIN", "VMAX"):
+        return None
+    members = _flatten_hard(inner.children, opcode, always=True)
+    if len(members) < _flatten_min():
+        return None
+    expr = CombineSDF(_Operation("UNION" if opcode == "VMIN" else "INTERSECT"),
+                      [_Reframed(node, m, coord_only=True) for m in members], parametric=False)
+    expr.path_key = ("pushed", id(inner))
+    for m in reversed(mods):
+        expr = ModSDF(m.name, m.args, expr)
+        expr.path_key = ("pushed", id(m))
+    return expr
+
+
+def os_environ_flag(name):
+    import os
+    return os.environ.get(name, "") not in ("", "0")
 
 
 def _is_geometry(obj):

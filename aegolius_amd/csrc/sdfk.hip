@@ -1094,6 +1094,9 @@ static std::string flavour_source(const sdfk_program* p, int flavour, bool with_
                                 &p->sites_all);
 }
 
+extern "C" int sdfk_program_chain_members(const sdfk_program* p) {
+    return p && p->chain_mode ? (int)p->sites_all.size() + 1 : 0;
+}
 extern "C" int sdfk_program_compile_check(sdfk_program* p, size_t* code_size) {
     // every flavour this program can be launched with, each as its own translation unit (what a run would build)
     if (!p) return fail(-1, "null program");

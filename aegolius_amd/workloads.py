@@ -90,6 +90,27 @@ def sphere_union(ns, count=1000, seed=31, radius=0.05, extent=0.9):
     return ns.CombineGeometry("UNION").combine(*objs)
 
 
+def clustered_union(ns, groups=20, members=50, seed=77, radius=0.03, spread=0.15, extent=0.8):
+    """`groups` rigidly placed copies of a cluster of `members` spheres, each cluster a UNION of its own, the clusters
+    rotated / moved (every third one rescaled) and united: the nested form of a large scene (instances of a molecule)."""
+    rng = np.random.default_rng(seed)
+    cluster = [(float(radius * rng.uniform(0.6, 1.4)), rng.uniform(-spread, spread, 3)) for _ in range(members)]
+    out = []
+    for k in range(groups):
+        objs = []
+        for r, c in cluster:
+            o = ns.Sphere(r)
+            o.move(c)
+            objs.append(o)
+        g = ns.CombineGeometry("UNION").combine(*objs)
+        g.rotate(float(rng.uniform(0, np.pi)), tuple(rng.normal(size=3)))
+        g.move(rng.uniform(-extent, extent, 3))
+        if k % 3 == 0:
+            g.rescale(1.2)
+        out.append(g)
+    return ns.CombineGeometry("UNION").combine(*out)
+
+
 # name -> (builder, grid size, description, per-axis request the BASELINE config names)
 BASELINE = {
     "cfg1": (cfg1_sphere, (2, 2, 2), "cfg1: Sphere(0.5)", 128),

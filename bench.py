@@ -537,8 +537,12 @@ def main():
                     r.step()
                     torch.cuda.synchronize()
                     build_s = time.perf_counter() - t0
-                    steps_o = 10                                  # (short kernels: the clocks need a few launches)
-                    e, k, med, mn = r.timed(steps_o, 5)
+                    # about 30 ms of warm-up and 60 ms of timed launches per config: a 0.9 ms kernel measured over 10
+                    # launches after 5 is still on the GPU's way up to its clocks (cfg 4: 0.93-0.98 against 0.89-0.90 ms)
+                    probe_e, _k, _med, _mn = r.timed(3, 2)
+                    one = max(probe_e / 3, 1e-4)
+                    steps_o = int(min(100, max(10, round(0.06 / one))))
+                    e, k, med, mn = r.timed(steps_o, int(min(50, max(5, round(0.03 / one)))))
                     v = verify_sample(name, ax, 0, r.out, r.count, samples=5000)
                     res[key] = {"workload": t_desc, "grid": "%dx%dx%d" % (ax[0].size, ax[1].size, ax[2].size),
                                 "points": pts, "steps": steps_o, "value": pts * steps_o / e / 1e6, "unit": "Mpoints/s",

@@ -75,6 +75,8 @@ int sdfk_program_set_params(sdfk_program* prog, const float* params, size_t n_pa
  * "chain mode" with all of its sites: one function per kind of leaf, tables of parameter offsets, a list of surviving
  * leaves per brick; it builds in about a second whatever its size. */
 int sdfk_program_set_cull(sdfk_program* prog, const uint32_t* sites, size_t n_sites, const float* k);
+/* Members of the n-ary chain when the program runs in chain mode (after sdfk_program_set_cull), else 0. */
+int sdfk_program_chain_members(const sdfk_program* prog);
 /* Generated HIP source of the specialised kernel (for inspection / tests); NULL on error. */
 const char* sdfk_program_source(sdfk_program* prog);
 /* Compile the specialised kernel for gfx950 with hiprtc without needing a GPU (build check).

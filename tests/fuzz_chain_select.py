@@ -3,7 +3,8 @@
     python tests/fuzz_chain_select.py [first_seed] [count]
 
 For each seed a random n-ary hard UNION / INTERSECT (9 .. 400 children of random kinds — 3-D or 2-D primitives with
-random rounding / onion / rotation / position —, optionally with a value modification on top) on a random grid shape
+random rounding / onion / rotation / position —, in a third of the larger scenes as nested groups with rigid transforms
+of their own, optionally with a value modification on top) on a random grid shape
 (odd / short / long rows, 2-D scenes on flat grids):
   * the table-driven chain kernel with per-brick survivor lists (row blocks), its un-culled loop (MODE_NOCULL) and — up
     to 120 children — the interpreter kernel: bit for bit;
@@ -50,7 +51,25 @@ def random_scene(ns, rng):
             o.rotate(float(rng.uniform(0, np.pi)), (0, 0, 1) if flat else tuple(rng.normal(size=3)))
         o.move((float(rng.uniform(-extent, extent)), float(rng.uniform(-extent, extent)), 0.0 if flat else float(rng.uniform(-extent, extent))))
         objs.append(o)
-    tree = ns.CombineGeometry("UNION" if rng.random() < 0.7 else "INTERSECT").combine(*objs)
+    kind = "UNION" if rng.random() < 0.7 else "INTERSECT"
+    if count >= 33 and rng.random() < 0.35:                    # nested: rigidly placed groups (flattened by the lowering)
+        ngroups = int(rng.integers(2, 7))
+        groups = []
+        for part in np.array_split(np.arange(count), ngroups):
+            g = ns.CombineGeometry(kind).combine(*[objs[i] for i in part])
+            if rng.random() < 0.8:
+                g.rotate(float(rng.uniform(0, np.pi)), (0, 0, 1) if flat else tuple(rng.normal(size=3)))
+            if rng.random() < 0.8:
+                g.move((float(rng.uniform(-.5, .5)), float(rng.uniform(-.5, .5)), 0.0 if flat else float(rng.uniform(-.5, .5))))
+            if rng.random() < 0.3:
+                g.rescale(float(rng.uniform(0.7, 1.4)))
+            groups.append(g)
+        if len(groups) > 2 and rng.random() < 0.5:              # a third level
+            pair = ns.CombineGeometry(kind + "2").combine(groups[0], groups[1])
+            pair.move((0.05, -0.1, 0.0))
+            groups = [pair] + groups[2:]
+        objs = groups
+    tree = ns.CombineGeometry(kind).combine(*objs)
     r = rng.random()
     if r < 0.15:
         tree.rounding(0.02)
@@ -106,7 +125,7 @@ def main(first=9000, count=40):
         shape = tuple(int(a.size) for a in axes)
         low = lower_geometry(tree)
         prog = _engine.Program.from_lowered(low)
-        chain = children >= 17
+        chain = prog.chain_members > 0
         chain_seen += chain
         msg = []
         plain = device_eval(_engine, prog, co32, _engine.MODE_NOCULL)

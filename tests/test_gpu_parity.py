@@ -1150,16 +1150,28 @@ def _chain_trees():
         u = workloads.sphere_union(ns, n, seed=9, radius=0.08)
         u.onion(0.01)                                             # value modifications of the result stay in the chain
         if rescale:
-            u.rescale(1.3)                                        # the children read transformed coordinates: no chain mode
+            u.rescale(1.3)                                        # pushed into the members by the lowering: still a chain
         return u
+
+    def union_with_a_smooth_pair(n):
+        rng = np.random.default_rng(9)
+        objs = []
+        for _ in range(n):
+            o = ns.Sphere(float(rng.uniform(0.04, 0.12)))
+            o.move(rng.uniform(-0.9, 0.9, 3))
+            objs.append(o)
+        # one member is a combination of its own (a cull site inside a member): not a chain — the mask kernels
+        objs[n // 2] = ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(objs[n // 2], ns.Box(0.2, 0.1, 0.1), parameters=0.1)
+        return ns.CombineGeometry("UNION").combine(*objs)
     return {"union_150_spheres": (workloads.sphere_union(ns, 150), False, True), "intersect_80_boxes": (boxes(80), False, True),
             "union_130_mixed_2d": (workloads.cfg4_scene2d(ns, seed=3, count=130), True, True),
             "union_70_onion": (modified_union(70, False), False, True),
-            "union_70_onion_rescaled": (modified_union(70, True), False, False)}
+            "union_70_onion_rescaled": (modified_union(70, True), False, True),
+            "union_70_with_a_smooth_pair": (union_with_a_smooth_pair(70), False, False)}
 
 
 @pytest.mark.parametrize("name", ["union_150_spheres", "intersect_80_boxes", "union_130_mixed_2d", "union_70_onion",
-                                  "union_70_onion_rescaled"])
+                                  "union_70_onion_rescaled", "union_70_with_a_smooth_pair"])
 def test_chain_mode_is_bit_exact(name, engine):
     """n-ary UNION / INTERSECT of more than 64 children run TABLE-DRIVEN (one function per kind of child, loops over
     parameter-offset tables, a list of surviving children per brick instead of mask bits): the culled row-block kernel,
@@ -1202,6 +1214,98 @@ def test_chain_mode_is_bit_exact(name, engine):
     plain = _device_eval(engine, prog, pts, pts.shape[1], pts.shape[1], 0, engine.MODE_NOCULL)
     rows = _device_eval(engine, prog, pts, pts.shape[1], pts.shape[1], 0, engine.MODE_SPECIALIZED, row_len=48)
     np.testing.assert_array_equal(rows, plain)
+
+
+def _clustered_scene(kind="UNION", groups=8, members=25, seed=3, nested=True):
+    """`groups` rigidly placed (some rescaled) clusters of `members` primitives each, every cluster an n-ary hard
+    combination of its own; nested: two clusters are themselves combined first (three levels)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(groups):
+        objs = []
+        for j in range(members):
+            o = ns.Sphere(float(rng.uniform(0.03, 0.08))) if (j + k) % 3 else ns.Box(*(float(x) for x in rng.uniform(0.04, 0.12, 3)))
+            if j % 5 == 0:
+                o.rounding(0.01)
+            o.move(rng.uniform(-0.25, 0.25, 3))
+            objs.append(o)
+        g = ns.CombineGeometry(kind).combine(*objs)
+        g.rotate(float(rng.uniform(0, 3)), tuple(rng.normal(size=3)))
+        g.move(rng.uniform(-0.7, 0.7, 3))
+        if k % 3 == 0:
+            g.rescale(1.25)
+        out.append(g)
+    if nested:
+        pair = ns.CombineGeometry(kind + "2").combine(out[0], out[1])
+        pair.move((0.1, -0.05, 0.02))
+        out = [pair] + out[2:]
+    scene = ns.CombineGeometry(kind).combine(*out)
+    scene.rotate(0.3, (1, 0, 0))                    # the whole scene moved and rescaled: pushed into the members too
+    scene.move((0.05, 0.0, -0.02))
+    scene.rescale(0.9)
+    return scene
+
+
+@pytest.mark.parametrize("kind", ["UNION", "INTERSECT"])
+def test_nested_hard_unions_are_flattened_into_one_chain(kind, engine, monkeypatch):
+    """UNION(move(UNION(a, b, ...)), ...) lowers to ONE n-ary chain — every member behind the transforms of the groups
+    it belonged to, the two affine maps composed in float64 into one — and runs on the chain kernels: all kernels of the
+    flattened program agree bit for bit, the field is the oracle's within 1e-6 and the nested program's within fp32
+    rounding (min / max are exact, a positive scale commutes with them; only the composed transform rounds differently)."""
+    tree = _clustered_scene(kind)
+    low = lower_geometry(tree)
+    prog = engine.Program.from_lowered(low)
+    assert prog.chain_members == 200
+    monkeypatch.setenv("SDFK_NO_FLATTEN", "1")
+    nested = engine.Program.from_lowered(lower_geometry(tree))
+    monkeypatch.delenv("SDFK_NO_FLATTEN")
+    assert nested.chain_members == 0
+    for shape, mis in ROW_SHAPES[:3]:
+        co, _ = ns.generate_grid((2.4, 2.4, 2.4), tuple(r - 1 for r in shape))
+        co32 = co.astype(np.float32)
+        n = co32.shape[1]
+        row_len = int(np.flatnonzero(co32[1] != co32[1][0])[0])
+        old = _device_eval(engine, nested, co32, n, n + 5, mis, engine.MODE_NOCULL)
+        want = _device_eval(engine, prog, co32, n, n + 5, mis, engine.MODE_NOCULL)
+        for mode, hint in ((engine.MODE_SPECIALIZED, row_len), (engine.MODE_SPECIALIZED, None), (engine.MODE_INTERPRET, None)):
+            np.testing.assert_array_equal(_device_eval(engine, prog, co32, n, n + 5, mis, mode, row_len=hint), want)
+        with np.errstate(all="ignore"):
+            ref = sdf_oracle.evaluate(tree, co32.astype(np.float64))
+        for field in (want, old):
+            err, bad = violations(field, ref)
+            assert not bad.any(), (kind, shape, float(np.nanmax(err)))
+        assert float(np.max(np.abs(want - old))) < 2e-6
+
+
+def test_staged_operator_inside_a_flattened_union(engine, monkeypatch):
+    """A grid-neighbourhood operator (staged evaluation: its position in the tree is the key of its stage) on ONE member
+    of a moved 20-member union: the members are re-framed by the lowering, the stages still find their operator."""
+    res = (32, 32, 32)
+    co, _ = ns.generate_grid((2, 2, 2), res)
+
+    def build():
+        rng = np.random.default_rng(8)
+        objs = []
+        for k in range(20):
+            o = ns.Sphere(float(rng.uniform(0.1, 0.2)))
+            o.move(rng.uniform(-0.6, 0.6, 3))
+            objs.append(o)
+        blurred = ns.Box(0.5, 0.4, 0.3)
+        blurred.conv_averaging((3, 3, 3), 1, res)
+        objs[5] = blurred
+        u = ns.CombineGeometry("UNION").combine(*objs)
+        u.move((0.05, -0.02, 0.0))
+        u.rescale(1.1)
+        return u
+    got = build().create(co)
+    monkeypatch.setenv("SDFK_NO_FLATTEN", "1")
+    nested = build().create(co)
+    monkeypatch.delenv("SDFK_NO_FLATTEN")
+    with np.errstate(all="ignore"):
+        ref = sdf_oracle.evaluate(build(), np.asarray(co).astype(np.float32).astype(np.float64))
+    for field in (got, nested):
+        err, bad = violations(field.ravel(), ref.ravel())
+        assert not bad.any(), float(np.nanmax(err))
 
 
 _FORCED_CHAIN = """

@@ -1,5 +1,9 @@
 """Developer tool (GPU): an n-ary UNION of many spheres on a resident grid — chain mode (culled row blocks, un-culled)
-against the interpreter kernel.   python tools/big_union_bench.py [--spheres 1000] [--grid 512] [--json out.json]"""
+against the interpreter kernel.   python tools/big_union_bench.py [--spheres 1000] [--grid 512] [--json out.json]
+--groups G: the same number of spheres as G rigidly placed clusters, each a UNION of its own (nested unions: flattened
+into one chain by the lowering); the NESTED program (SDFK_NO_FLATTEN=1, what round 2 ran: the interpreter kernel beyond
+the specialisation limit) is timed next to it (the two differ by fp32 rounding: the flattened program composes the group's
+and the member's transforms into one map)."""
 import argparse
 import json
 import os
@@ -17,17 +21,26 @@ def main():
     ap.add_argument("--spheres", type=int, default=1000)
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--groups", type=int, default=0)
     args = ap.parse_args()
     import torch
     import aegolius_amd.cores as ns
     from aegolius_amd import _engine, workloads
     from aegolius_amd._lower import lower_geometry
     from aegolius_amd.cores.helper_functions import grid_axes
-    tree = workloads.sphere_union(ns, args.spheres)
+    if args.groups:
+        tree = workloads.clustered_union(ns, args.groups, args.spheres // args.groups)
+    else:
+        tree = workloads.sphere_union(ns, args.spheres)
     t0 = time.perf_counter()
     low = lower_geometry(tree)
     prog = _engine.Program.from_lowered(low)
     t_lower = time.perf_counter() - t0
+    nested = None
+    if args.groups:
+        os.environ["SDFK_NO_FLATTEN"] = "1"
+        nested = _engine.Program.from_lowered(lower_geometry(tree))
+        del os.environ["SDFK_NO_FLATTEN"]
     axes = [a.astype(np.float32) for a in grid_axes((2, 2, 2), (args.grid,) * 3)[0]]
     n = int(np.prod([a.size for a in axes]))
     stride = (n + 255) // 256 * 256
@@ -37,7 +50,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     _engine.grid_fill(co.data_ptr(), stride, axes, 0, n, stream=stream)
     row_len = int(axes[2].size)
-    res = {"workload": "n-ary UNION of %d spheres" % args.spheres, "instructions": int(low.code.shape[0]),
+    res = {"workload": ("UNION of %d clusters, each a UNION of %d spheres" % (args.groups, args.spheres // args.groups)) if args.groups
+           else "n-ary UNION of %d spheres" % args.spheres, "chain_members": prog.chain_members, "instructions": int(low.code.shape[0]),
            "cull_sites": int(len(low.cull_sites)), "grid": "%d^3" % axes[0].size, "points": n,
            "chain_mode": "#define SDFK_CHAIN 1" in prog.source(), "lower_and_program_s": t_lower}
     for key, mode, rows, reps in (("culled", _engine.MODE_SPECIALIZED, True, 5), ("plain", _engine.MODE_NOCULL, False, 2),
@@ -59,6 +73,20 @@ def main():
         res[key] = {"ms": best, "first_call_s": first, "mpoints_per_s": n / best / 1e3,
                     "frac_of_hbm_roofline": 16.0 * n / (best * 1e-3) / 8e12}
         print(key, res[key], flush=True)
+    if nested is not None:
+        out_n = torch.empty((stride,), dtype=torch.float32, device=dev)
+        t0 = time.perf_counter()
+        nested.eval_device(co.data_ptr(), n, stride, out_n.data_ptr(), stream=stream, mode=_engine.MODE_AUTO, row_len=row_len)
+        torch.cuda.synchronize()
+        first = time.perf_counter() - t0
+        e0, e1 = _engine.Event(), _engine.Event()
+        e0.record(stream)
+        nested.eval_device(co.data_ptr(), n, stride, out_n.data_ptr(), stream=stream, mode=_engine.MODE_AUTO, row_len=row_len)
+        e1.record(stream)
+        res["nested_program_auto_mode"] = {"ms": e0.elapsed_ms(e1), "first_call_s": first, "chain_members": nested.chain_members,
+                                           # (the flattened program composes group and member transforms into one map)
+                                           "max_abs_difference_to_flattened": float((out_n[:n] - outs["culled"][:n]).abs().max())}
+        print("nested", res["nested_program_auto_mode"], flush=True)
     res["bit_identical"] = bool(torch.equal(outs["culled"][:n], outs["plain"][:n]) and torch.equal(outs["plain"][:n], outs["interp"][:n]))
     print(json.dumps(res))
     if args.json:

@@ -38,9 +38,9 @@ fi
 if [ "$part" = b ] || [ "$part" = all ]; then
 pmc_set cfg3 sdfk_spec_v4 python3 $R/bench.py --workload cfg3 $B
 pmc_set cfg5 sdfk_spec_r python3 $R/bench.py --workload cfg5 $B
-pmc_set cfg4 sdfk_spec_r python3 $R/bench.py --workload cfg4 --grid 16384 $B
+pmc_set cfg4 sdfk_spec_r python3 $R/bench.py --workload cfg4 --grid 16384 --steps 100 --warmup 30 --no-extras --cpu-seconds 0
 for w in cfg1 cfg3 cfg5; do python3 bench.py --workload $w $B > "$O/${tag}_${w}_bench.json" 2>/dev/null; done
-python3 bench.py --workload cfg4 --grid 16384 $B > "$O/${tag}_cfg4_bench.json" 2>/dev/null
+python3 bench.py --workload cfg4 --grid 16384 --steps 100 --warmup 30 --no-extras --cpu-seconds 0 > "$O/${tag}_cfg4_bench.json" 2>/dev/null
 python3 bench.py --mode nocull --steps 10 --warmup 3 --no-extras --cpu-seconds 0 > "$O/${tag}_cfg2_bench_nocull.json" 2>/dev/null
 python3 bench.py --mode interpret --steps 5 --warmup 2 --no-extras --cpu-seconds 0 > "$O/${tag}_cfg2_bench_interpreter.json" 2>/dev/null
 fi
