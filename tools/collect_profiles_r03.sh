@@ -54,7 +54,7 @@ python3 tools/consumers_bench.py 1024 > "$O/${tag}_consumers_1025.json" 2>/dev/n
   done
   rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${tag}_prof_consumers" -- python3 $R/tools/consumers_bench.py 1024 > /dev/null 2> "$O/${tag}_prof_consumers.log" )
 cp "$O/${tag}_prof_consumers"/*/*kernel_stats.csv "$O/${tag}_consumers_kernel_stats.csv" 2>/dev/null
-for k in "~sdfk_gradient" sdfk_select_count_kernel sdfk_flags_scatter_kernel; do
+for k in "~sdfk_gradient" "~sdfk_select_count_kernel" sdfk_flags_scatter_kernel; do
   python3 tools/pmc_summarize.py "$O/${tag}_pmc_consumers" "$k" "$O/${tag}_consumers_pmc_$(echo $k | tr -d '~').json" > /dev/null
 done
 # 3b. point_cloud without the field: the evaluation kernel writes flag bits, compaction from the flags
