@@ -499,8 +499,10 @@ def main():
         def grid_512():
             ax = fp32_axes(512)
             r2 = Run(torch, dist, _engine, prog, ax, world, rank, dev, red_dev, mode, not args.no_rows)
-            steps2 = max(30, args.steps)                          # 0.4 ms per step: 30 steps after 10 warm-ups, so that the
-            e2, k2, med2, min2 = r2.timed(steps2, 10)             # clocks have settled before the timed region
+            # 0.4 ms per step: 150 steps after 75 of warm-up (30 + 60 ms), so that the GPU has reached its clocks before the
+            # timed region — 30 steps after 10 read 0.416 ms where 200 after 50 read 0.397 (profiles/r03_grid512_*)
+            steps2 = max(150, args.steps)
+            e2, k2, med2, min2 = r2.timed(steps2, 75)
             v = verify_sample(args.workload, ax, r2.start, r2.out, r2.count, samples=5000)
             return {"grid": "%dx%dx%d" % (ax[0].size, ax[1].size, ax[2].size), "points": r2.n_total, "steps": steps2,
                     "value": r2.n_total * steps2 / e2 / 1e6, "unit": "Mpoints/s", "ms_per_step": e2 / steps2 * 1e3,
