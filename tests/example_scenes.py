@@ -169,3 +169,319 @@ def hourglass_rounded(ns):
     spc = ns.SegmentedLine(_HOURGLASS, closed=True)
     spc.rounding(0.1)
     return spc
+
+
+# ---- second batch (round 3): the remaining scalar examples whose scene is a geometry of the operator API -------------
+def _sub(ns, module, name):
+    """Classes the reference does not re-export from `cores` (SolidAngle): from the sub-module of the same namespace."""
+    import importlib
+    return getattr(importlib.import_module(ns.__name__ + "." + module), name)
+
+
+@example("candy_cane_2D", (3, 7), (300, 700), (76, 176), "2D/candy_cane_2D.py", "candy_cane_pattern")
+def candy_cane_2d(ns):
+    seg = ns.Segment((-5, 0, 0), (1.5, 0, 0))
+    seg.rounding(0.15)
+    seg.bend(0.5, np.pi)
+    seg.rotate(np.pi, (0, 0, 1))
+    seg.move((0, 2.5, 0))
+    return seg
+
+
+@example("ngon_2D", (3, 3), (400, 400), (100, 100), "2D/ngon_2D.py", "ngon_pattern")
+def ngon_2d(ns):
+    g = ns.NGon(1, 6)
+    g.rotate(np.pi / 12, (0, 0, 1))
+    return g
+
+
+@example("neu_circle_2D", (5, 5), (400, 400), (100, 100), "2D/neu_circle_2D.py", "pattern")
+def neu_circle_2d(ns):
+    circles = []
+    for order, where in ((0.5, (-1, 1, 0)), (1, (1, 1, 0)), (2, (1, -1, 0)), (5, (-1, -1, 0))):
+        c = ns.NEUCircle(1, order)
+        c.move(where)
+        circles.append(c)
+    return ns.CombineGeometry("UNION").combine(*circles)
+
+
+@example("triangle_2D", (4, 4), (400, 400), (100, 100), "2D/triangle_2D.py", "triangle_pattern")
+def triangle_2d(ns):
+    return ns.Triangle((-1, 0.2), (1, -0.2), (0.1, 0.5))
+
+
+@example("polygon_2D", (5, 5), (400, 400), (100, 100), "2D/polygon_2D.py", "polygon_pattern")
+def polygon_2d(ns):
+    return ns.Polygon(np.asarray([[-0.5, 0, 0], [-1, -1, 0], [1, 0, 0], [-1, 1, 0]]).T)
+
+
+@example("rounded_rectangle_2D", (3, 3), (400, 400), (100, 100), "2D/rounded_rectangle_2D.py", "final_pattern")
+def rounded_rectangle_2d(ns):
+    return ns.RoundedRectangle(2, 1, [0.5, 0.2, 0.3, 0.4])
+
+
+@example("slice_of_pie_2D", (2, 2), (200, 200), (100, 100), "2D/slice_of_pie_2D.py", "pie_pattern")
+def slice_of_pie_2d(ns):
+    a1, a2, radius = np.pi / 3, -np.pi / 4, 1
+    pie = ns.Sector(radius, a1, a2)
+    mid = (a2 + a1) / 2
+    pie.set_location(-(radius * np.asarray((np.cos(mid), np.sin(mid))) / 2))
+    return pie
+
+
+@example("water_molecule_2D", (5, 3), (500, 300), (126, 76), "2D/water_molecule_2D.py", "h2o_pattern")
+def water_molecule_2d(ns):
+    angle, d, h_size = 104.5, 0.0957, 0.075
+    o_size = h_size * 1.3
+    x_sep = 10 * d * np.cos(np.deg2rad((180 - angle) / 2))
+    y_sep = 10 * d * np.sin(np.deg2rad((180 - angle) / 2))
+    h = ns.Circle(10 * h_size / 2)
+    h.linear_instancing(2, (-x_sep, 0, 0), (x_sep, 0, 0))
+    h.move((0, -y_sep, 0))
+    o = ns.Circle(10 * o_size / 2)
+    combine = ns.CombineGeometry("")
+    combine.operation_type = "SMOOTH_UNION2"
+    return combine.combine_parametric(h, o, parameters=0.45)
+
+
+@example("therefore_2D", (4, 4), (400, 400), (100, 100), "2D/therefore_2D.py", "thfr_pattern")
+def therefore_2d(ns):
+    c = ns.Circle(0.5)
+    c.rotational_symmetry(3, 1, np.pi / 6)
+    return c
+
+
+@example("mirror_symmetry_2D", (4, 4), (400, 400), (100, 100), "2D/mirror_symmetry_2D.py", "circle_pattern")
+def mirror_symmetry_2d(ns):
+    c = ns.Circle(0.5)
+    c.mirror((-1, 0.6, 0), (1, 0.8, 0))
+    c.symmetry(1)
+    return c
+
+
+def _repetition_2d(kind):
+    def build(ns):
+        quad = ns.Rectangle(1.0, 0.5)
+        if kind == "INFINITE":
+            quad.infinite_repetition((1.2, 1.5, 2))
+        elif kind == "FINITE":
+            quad.finite_repetition((2., 3., 1.), (2, 3, 1))
+        else:
+            quad.finite_repetition_rescaled((2., 3., 1.), (2, 3, 1), (1, 0.5, 1), (0.2, 0.3, 0.0))
+        return quad
+    return build
+
+
+for _kind in ("INFINITE", "FINITE", "FINITE_RESCALED"):
+    example("repetitions_2D_" + _kind.lower(), (4, 4), (400, 400), (100, 100),
+            "2D/finite_infinite_repetitions_2D.py", "quad_pattern", {"repetition_type": _kind})(_repetition_2d(_kind))
+
+
+def _polar_curve(t, radius1, radius2, f1, f2):
+    r = radius1 + radius2 * np.cos(f2 * t * 2 * np.pi)
+    return np.asarray((r * np.cos(f1 * t * 2 * np.pi), r * np.sin(f1 * t * 2 * np.pi)))
+
+
+def _parametric_curve_2d(shape):
+    def build(ns):
+        curve = ns.ParametricCurve(_polar_curve, (2, 0.5, 1, 3), (0, 1, 201), closed=True)
+        if shape:
+            curve.shape()
+        else:
+            curve.rounding(0.1)
+        return curve
+    return build
+
+
+example("parametric_curve_2D_rounded", (6, 6), (600, 600), (100, 100), "2D/parametric_curve_2D.py", "curve_pattern",
+        {"shape": False})(_parametric_curve_2d(False))
+example("parametric_curve_2D_shape", (6, 6), (600, 600), (100, 100), "2D/parametric_curve_2D.py", "curve_pattern",
+        {"shape": True})(_parametric_curve_2d(True))
+
+
+@example("basics_2D", (4, 4), (400, 400), (100, 100), "2D/basics_2D.py", "rectangle_pattern")
+def basics_2d(ns):
+    r = ns.Rectangle(1, 0.5)
+    r.move((0.1, 1, 0))
+    r.set_location((1, 1, 0))
+    r.move((-1, -1, 0))
+    r.rescale(2)
+    r.rescale(1.5)
+    r.set_scale(1.5)
+    r.rescale(2 / 3)
+    r.rotate(np.pi / 4, (0, 0, 1))
+    r.set_rotation(np.pi / 6, (0, 0, 1))
+    r.rotate(-np.pi / 6, (0, 0, 1))
+    r.rotate(np.pi / 4, (0, 0, 1))
+    r.mirror((-1, 0, 0), (1, 0, 0))
+    r = ns.GenericGeometry(r.propagate)
+    r.mirror((0, -0.5, 0), (0, 0.5, 0))
+    return r
+
+
+@example("boilerplate_2D", (4, 4), (400, 400), (100, 100), "2D/boilerplate_2D.py", "final_pattern")
+def boilerplate_2d(ns):
+    return ns.Circle(0.8)
+
+
+@example("approaches_post_processing_2D", (4, 4), (400, 400), (100, 100), "2D/approaches_post_processing_scalar_2D.py",
+         "gb_modification_pattern")
+def approaches_post_processing_2d(ns):
+    c = ns.Circle(1)
+    c.gaussian_boundary(1.0, 0.5)
+    return c
+
+
+def _move_along_vector(sdf_, co_cloud_, sdf_params_, vector):
+    q = co_cloud_.copy()
+    q[0] -= vector[0]
+    q[1] -= vector[1]
+    return sdf_(q, sdf_params_)
+
+
+@example("custom_modification_2D", (4, 4), (400, 400), (100, 100), "2D/custom_modification_2D.py", "circle_pattern")
+def custom_modification_2d(ns):
+    c = ns.Circle(0.5)
+    c.custom_modification(_move_along_vector, (0.5, 1.0, 0.0), modification_name="move_along_vector")
+    return c
+
+
+@example("candy_cane_3D", (3, 3, 7), (100, 100, 250), (34, 34, 84), "3D/candy_cane_3D.py", "candy_cane_pattern")
+def candy_cane_3d(ns):
+    seg = ns.Line((-5, 0, 0), (1.5, 0, 0))
+    seg.rounding(0.15)
+    seg.bend(0.5, np.pi)
+    seg.rotate(-np.pi / 2, (1, 0, 0))
+    seg.rotate(-np.pi / 2, (0, 0, 1))
+    seg.move((0, 0, 2.5))
+    return seg
+
+
+@example("lamp_shade_3D", (2.2, 2.2, 1.2), (200, 200, 100), (50, 50, 26), "3D/lamp_shade_3D.py", "shade_pattern")
+def lamp_shade_3d(ns):
+    shade = ns.Arc(1, np.pi, np.pi + 0.7 * np.pi / 2)
+    shade.axis_revolution(1 + 0.2, -np.pi / 10)
+    shade.rounding(0.02)
+    shade.rotate(np.pi / 10, (0, 0, 1))
+    shade.rotate(np.pi / 2, (1, 0, 0))
+    shade.move((0, 0, 0.3))
+    return shade
+
+
+@example("plate_3D", (2.4, 2.4, 1), (200, 200, 100), (50, 50, 26), "3D/plate_3D.py", "plate_pattern")
+def plate_3d(ns):
+    outer_r, inner_r, rim_h, thickness, rim_r = 1, 0.5, 0.12, 0.015, 0.01
+    inner = ns.Segment((0, 0, 0), (inner_r, 0, 0))
+    inner.rounding(thickness)
+    outer = ns.Segment((inner_r, 0, 0), (outer_r, rim_h, 0))
+    outer.rounding(thickness)
+    rim = ns.Circle(rim_r)
+    rim.move((inner_r, -rim_r * 2, 0))
+    top = ns.CombineGeometry("UNION2").combine(inner, outer)
+    plate = ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(top, rim, parameters=0.05)
+    plate.revolution(0)
+    plate.rotate(np.pi / 2, (1, 0, 0))
+    plate.move((0, 0, -rim_h / 2))
+    return plate
+
+
+@example("rod_3D", (3, 3, 1.6), (200, 200, 100), (50, 50, 26), "3D/rod_3D.py", "combined_pattern")
+def rod_3d(ns):
+    box = ns.Box(3, 1, 0.5)
+    hexagon = ns.NGon(0.3, 6)
+    hexagon.boundary()
+    hexagon.concentric(0.2)
+    hexagon.rounding(0.05)
+    hexagon.extrusion(2)
+    hexagon.move((0.5, 0, 0))
+    cy = ns.Cylinder(0.4, 1)
+    cy.move((-0.5, 0, 0))
+    cy.rotate(np.pi / 6, (0, 1, 0))
+    arc = ns.Arc3D(1, 0.2, np.pi / 4, 7 * np.pi / 4)
+    cya = ns.Cylinder(1.2, 1)
+    union = ns.CombineGeometry("UNION")
+    s1 = union.combine(box, arc)
+    s2 = union.combine(hexagon, cy)
+    s3 = ns.CombineGeometry("SUBTRACT2").combine(s1, s2)
+    return ns.CombineGeometry("INTERSECT2").combine(s3, cya)
+
+
+@example("shear_3D", (4, 4, 4), (100, 100, 100), (34, 34, 34), "3D/shear_3D.py", "box_pattern")
+def shear_3d(ns):
+    box = ns.Box(1, 1, 1)
+    box.shear(np.pi / 6, 1, 2)
+    return box
+
+
+@example("basics_3D", (4, 4, 2), (100, 100, 100), (34, 34, 34), "3D/basics_3D.py", "box_pattern")
+def basics_3d(ns):
+    box = ns.Box(1, 0.5, 0.25)
+    box.move((0.1, 1, -0.25))
+    box.set_location((1, 1, 0.5))
+    box.move((-1, -1, -0.5))
+    box.rescale(2)
+    box.rescale(1.5)
+    box.set_scale(1.5)
+    box.rescale(2 / 3)
+    box.rotate(np.pi / 2, (1, 1, 0))
+    box.rotate(-np.pi / 4, (-1, 1, 0))
+    box.rotate(np.pi / 4, (0, 0, 1))
+    box.set_rotation(np.pi / 6, (0, 0, 1))
+    box.rotate(-np.pi / 6, (0, 0, 1))
+    box.rotate(np.pi / 4, (0, 0, 1))
+    box.mirror((-1, 0, 0), (1, 0, 0))
+    box = ns.GenericGeometry(box.propagate)
+    box.mirror((0, -0.5, 0), (0, 0.5, 0))
+    return box
+
+
+@example("boilerplate_3D", (2.3, 2.3, 2.3), (150, 150, 150), (38, 38, 38), "3D/boilerplate_3D.py", "final_pattern")
+def boilerplate_3d(ns):
+    return ns.Sphere(0.75)
+
+
+@example("solid_angle_3D", (2., 2., 2.), (150, 150, 150), (38, 38, 38), "3D/solid_angle_3D.py", "solid_angle_pattern")
+def solid_angle_3d(ns):
+    a1, a2, radius = np.pi / 3, -np.pi / 4, 1
+    sa = _sub(ns, "geom_3d", "SolidAngle")(radius, a1, a2)
+    mid = (a2 + a1) / 2
+    sa.set_location(-(radius * np.asarray((np.cos(mid), np.sin(mid))) / 2))
+    return sa
+
+
+@example("spiral_3D", (3, 3, 3), (100, 100, 100), (34, 34, 34), "3D/spiral_3D.py", "spiral_pattern")
+def spiral_3d(ns):
+    curve = ns.ParametricCurve3D(_spiral, (1, 2, 2), (0, 1, 101))
+    curve.rounding(0.2)
+    return curve
+
+
+@example("triangle_quad_3D", (2.5, 1.5, 2.5), (200, 100, 200), (50, 26, 50), "3D/triangle_quad_3D.py", "combined_pattern")
+def triangle_quad_3d(ns):
+    trig = ns.Triangle3D((-1, 0.2, -1), (1, -0.2, 0), (0.1, 0.5, 1))
+    trig.rounding(0.05)
+    quad = ns.Quad((-1, 0.2, 0), (1, -0.2, 0), (0.1, 0.5, 0), (-0.5, 0.5, 0))
+    quad.rounding(0.05)
+    return ns.CombineGeometry("UNION").combine(quad, trig)
+
+
+def _custom_circle(co_cloud_, radius_, order_):
+    q = co_cloud_.copy()
+    return np.linalg.norm(q, axis=0, ord=order_) - radius_
+
+
+@example("custom_sdf_2D", (4, 4), (400, 400), (100, 100), "2D/custom_sdf_2D.py", "circle_pattern")
+def custom_sdf_2d(ns):
+    return ns.GenericGeometry(_custom_circle, 0.5, np.inf)            # a user SDF: evaluated by its own code on the host
+
+
+def _sinc(u, amplitude, width):
+    return amplitude * np.sinc(u / width)
+
+
+@example("custom_post_processing_2D", (4, 4), (400, 400), (100, 100), "2D/custom_post_processing_scalar_2D.py",
+         "custom_modification_pattern")
+def custom_post_processing_2d(ns):
+    c = ns.Circle(1)
+    c.custom_post_process(_sinc, (1.0, 0.5), post_process_name="Sinc")
+    return c

@@ -56,7 +56,8 @@ class _Anything:
 
 def _stub_plot_modules():
     stubs = {}
-    for name in ("matplotlib", "matplotlib.pyplot", "matplotlib.cm", "matplotlib.colors", "plotly", "plotly.graph_objects"):
+    for name in ("matplotlib", "matplotlib.pyplot", "matplotlib.cm", "matplotlib.colors", "plotly", "plotly.graph_objects",
+                 "plotly.subplots", "plotly.express"):
         m = types.ModuleType(name)
         m.__getattr__ = lambda _attr: _Anything()
         stubs[name] = m
