@@ -395,6 +395,13 @@ class Lowerer:
                     raise TypeError("%s takes exactly 2 objects (%d given)" % (op, len(kids)))
             else:
                 raise KeyError(op)
+        if not expr.parametric and opcode == "VSUBTRACT":
+            holes = _subtracted_union(kids[1])
+            if holes is not None:
+                # body minus a UNION of many (a perforated plate, a porous block): max(a, -min_j b_j) = max(a, max_j -b_j),
+                # an n-ary INTERSECT of the body and the negated members (negation is exact) — one chain instead of a
+                # chain inside an operand, which the chain kernels do not take
+                kids, opcode = (kids[0],) + holes, "VMAX"
         if not expr.parametric and opcode in ("VMIN", "VMAX"):
             kids = _flatten_hard(kids, opcode)
         acc = None
@@ -495,6 +502,38 @@ def _flatten_hard(kids, opcode, always=False):
     return tuple(flat)
 
 
+class _Negated:
+    """-inner as a geometry of its own (identity frame): a member of the INTERSECT that a subtracted UNION turns into."""
+    rotation_matrix = np.eye(3)
+    center = np.zeros(3)
+    scale = 1.0
+    _geo_parameters = ()
+
+    def __init__(self, inner):
+        self.modified_object = ModSDF("invert", {}, NodeSDF(inner))
+        key = getattr(inner, "path_key", None) or id(inner)
+        self.modified_object.path_key = ("negated-mod", key)
+        self.path_key = ("negated", key)
+
+
+def _subtracted_union(node):
+    """node: the second operand of a SUBTRACT2. -> its members, re-framed and negated, when it is a hard UNION (bare, with
+    at most a transform of its own) of at least as many members as the chain kernels take; else None."""
+    from .cores.combine import BINARY_OPS, NARY_OPS
+    if os_environ_flag("SDFK_NO_FLATTEN") or not _is_geometry(node):
+        return None
+    inner = node.modified_object
+    if not isinstance(inner, CombineSDF) or inner.parametric:
+        return None
+    op = getattr(inner.owner, "operation_type", None)
+    if (NARY_OPS.get(op) or BINARY_OPS.get(op)) != "VMIN":
+        return None
+    members = _flatten_hard((node,), "VMIN", always=True)
+    if (len(members) == 1 and members[0] is node) or len(members) + 1 < _flatten_min():
+        return None
+    return tuple(_Negated(m) for m in members)
+
+
 class _Operation:
     def __init__(self, operation_type):
         self.operation_type = operation_type
@@ -527,9 +566,15 @@ def _push_transform_into_members(node):
         return None
     op = getattr(inner.owner, "operation_type", None)
     opcode = NARY_OPS.get(op) or BINARY_OPS.get(op)
+    kids = inner.children
+    if opcode == "VSUBTRACT" and len(kids) == 2:                # body minus a large UNION: an INTERSECT (see _lower_combine)
+        holes = _subtracted_union(kids[1])
+        if holes is None:
+            return None
+        kids, opcode = (kids[0],) + holes, "VMAX"
     if opcode not in ("VMIN", "VMAX"):
         return None
-    members = _flatten_hard(inner.children, opcode, always=True)
+    members = _flatten_hard(kids, opcode, always=True)
     if len(members) < _flatten_min():
         return None
     expr = CombineSDF(_Operation("UNION" if opcode == "VMIN" else "INTERSECT"),

@@ -70,6 +70,11 @@ def random_scene(ns, rng):
             groups = [pair] + groups[2:]
         objs = groups
     tree = ns.CombineGeometry(kind).combine(*objs)
+    if kind == "UNION" and rng.random() < 0.2:                  # a body minus the union: lowered as one INTERSECT chain
+        if rng.random() < 0.5:
+            tree.move((0.03, -0.02, 0.0))
+        body = ns.Rectangle(1.6 * extent, 1.4 * extent) if flat else ns.Box(1.6 * extent, 1.5 * extent, 1.2 * extent)
+        tree = ns.CombineGeometry("SUBTRACT2").combine(body, tree)
     r = rng.random()
     if r < 0.15:
         tree.rounding(0.02)

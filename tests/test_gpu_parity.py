@@ -1277,6 +1277,58 @@ def test_nested_hard_unions_are_flattened_into_one_chain(kind, engine, monkeypat
         assert float(np.max(np.abs(want - old))) < 2e-6
 
 
+def _perforated_plate(holes=120, seed=5, moved=True):
+    rng = np.random.default_rng(seed)
+    plate = ns.Box(1.8, 1.6, 0.3)
+    plate.rounding(0.02)
+    cyl = []
+    for k in range(holes):
+        c = ns.Cylinder(float(rng.uniform(0.03, 0.07)), 1.0) if k % 4 else ns.Sphere(float(rng.uniform(0.05, 0.12)))
+        c.move((float(rng.uniform(-.85, .85)), float(rng.uniform(-.75, .75)), 0.0 if k % 4 else float(rng.uniform(-.1, .1))))
+        cyl.append(c)
+    u = ns.CombineGeometry("UNION").combine(*cyl)
+    if moved:
+        u.move((0.01, -0.02, 0.0))
+    tree = ns.CombineGeometry("SUBTRACT2").combine(plate, u)
+    if moved:
+        tree.rotate(0.25, (1, 0.2, 0))
+        tree.rescale(1.1)
+    return tree
+
+
+@pytest.mark.parametrize("moved", [False, True])
+def test_body_minus_a_large_union_runs_as_one_chain(moved, engine, monkeypatch):
+    """SUBTRACT2(body, UNION(holes...)) = max(body, max_j -hole_j): lowered as ONE n-ary INTERSECT of the body and the
+    negated holes (negation is exact), also when union and result carry transforms — chain kernels instead of a chain
+    inside an operand. All kernels of the rewritten program agree bit for bit; oracle within 1e-6; the nested program
+    (SDFK_NO_FLATTEN) within fp32 rounding (equal bits when no transform had to be composed)."""
+    tree = _perforated_plate(moved=moved)
+    prog = engine.Program.from_lowered(lower_geometry(tree))
+    assert prog.chain_members == 121
+    monkeypatch.setenv("SDFK_NO_FLATTEN", "1")
+    nested = engine.Program.from_lowered(lower_geometry(tree))
+    monkeypatch.delenv("SDFK_NO_FLATTEN")
+    assert nested.chain_members == 0
+    for shape, mis in ROW_SHAPES[:3]:
+        co, _ = ns.generate_grid((2.4, 2.4, 1.0), tuple(r - 1 for r in shape))
+        co32 = co.astype(np.float32)
+        n = co32.shape[1]
+        row_len = int(np.flatnonzero(co32[1] != co32[1][0])[0])
+        old = _device_eval(engine, nested, co32, n, n + 5, mis, engine.MODE_NOCULL)
+        want = _device_eval(engine, prog, co32, n, n + 5, mis, engine.MODE_NOCULL)
+        for mode, hint in ((engine.MODE_SPECIALIZED, row_len), (engine.MODE_SPECIALIZED, None), (engine.MODE_INTERPRET, None)):
+            np.testing.assert_array_equal(_device_eval(engine, prog, co32, n, n + 5, mis, mode, row_len=hint), want)
+        with np.errstate(all="ignore"):
+            ref = sdf_oracle.evaluate(tree, co32.astype(np.float64))
+        for field in (want, old):
+            err, bad = violations(field, ref)
+            assert not bad.any(), (moved, shape, float(np.nanmax(err)))
+        if moved:
+            assert float(np.max(np.abs(want - old))) < 2e-6
+        else:
+            np.testing.assert_array_equal(want, old)
+
+
 def test_staged_operator_inside_a_flattened_union(engine, monkeypatch):
     """A grid-neighbourhood operator (staged evaluation: its position in the tree is the key of its stage) on ONE member
     of a moved 20-member union: the members are re-framed by the lowering, the stages still find their operator."""

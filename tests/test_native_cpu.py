@@ -370,6 +370,10 @@ def test_nested_hard_unions_flatten_only_at_chain_size(built, monkeypatch):
     assert members(whole) == 20
     whole.onion(0.01)                                           # ... and a value modification on top stays the chain's tail
     assert members(whole) == 20
+    # body minus a large union: an INTERSECT of the body and the negated members
+    assert members(ns.CombineGeometry("SUBTRACT2").combine(ns.Box(1, 1, 1), cluster("UNION", 30, 0.0))) == 31
+    assert members(ns.CombineGeometry("SUBTRACT2").combine(ns.Box(1, 1, 1), cluster("UNION", 8, 0.0))) == 0
+    assert members(ns.CombineGeometry("SUBTRACT2").combine(ns.Box(1, 1, 1), cluster("INTERSECT", 30, 0.0))) == 0
     d = cluster("UNION", 10, 2.0)
     d.rescale(-1.0)                                             # a negative scale turns min into max: not flattened
     assert members(ns.CombineGeometry("UNION2").combine(a, d)) == 0

@@ -1,5 +1,6 @@
 """Developer tool (GPU): an n-ary UNION of many spheres on a resident grid — chain mode (culled row blocks, un-culled)
 against the interpreter kernel.   python tools/big_union_bench.py [--spheres 1000] [--grid 512] [--json out.json]
+--body: a box MINUS that union (lowered as one n-ary INTERSECT of the box and the negated spheres).
 --groups G: the same number of spheres as G rigidly placed clusters, each a UNION of its own (nested unions: flattened
 into one chain by the lowering); the NESTED program (SDFK_NO_FLATTEN=1, what round 2 ran: the interpreter kernel beyond
 the specialisation limit) is timed next to it (the two differ by fp32 rounding: the flattened program composes the group's
@@ -22,6 +23,7 @@ def main():
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--json", default=None)
     ap.add_argument("--groups", type=int, default=0)
+    ap.add_argument("--body", action="store_true", help="a block MINUS the union (porous block): one INTERSECT chain after lowering")
     args = ap.parse_args()
     import torch
     import aegolius_amd.cores as ns
@@ -32,12 +34,14 @@ def main():
         tree = workloads.clustered_union(ns, args.groups, args.spheres // args.groups)
     else:
         tree = workloads.sphere_union(ns, args.spheres)
+    if args.body:
+        tree = ns.CombineGeometry("SUBTRACT2").combine(ns.Box(1.7, 1.7, 1.7), tree)
     t0 = time.perf_counter()
     low = lower_geometry(tree)
     prog = _engine.Program.from_lowered(low)
     t_lower = time.perf_counter() - t0
     nested = None
-    if args.groups:
+    if args.groups or args.body:
         os.environ["SDFK_NO_FLATTEN"] = "1"
         nested = _engine.Program.from_lowered(lower_geometry(tree))
         del os.environ["SDFK_NO_FLATTEN"]
@@ -50,7 +54,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     _engine.grid_fill(co.data_ptr(), stride, axes, 0, n, stream=stream)
     row_len = int(axes[2].size)
-    res = {"workload": ("UNION of %d clusters, each a UNION of %d spheres" % (args.groups, args.spheres // args.groups)) if args.groups
+    res = {"workload": ("a box minus " if args.body else "") + ("UNION of %d clusters, each a UNION of %d spheres" % (args.groups, args.spheres // args.groups)) if args.groups
            else "n-ary UNION of %d spheres" % args.spheres, "chain_members": prog.chain_members, "instructions": int(low.code.shape[0]),
            "cull_sites": int(len(low.cull_sites)), "grid": "%d^3" % axes[0].size, "points": n,
            "chain_mode": "#define SDFK_CHAIN 1" in prog.source(), "lower_and_program_s": t_lower}
