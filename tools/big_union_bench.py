@@ -54,8 +54,9 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     _engine.grid_fill(co.data_ptr(), stride, axes, 0, n, stream=stream)
     row_len = int(axes[2].size)
-    res = {"workload": ("a box minus " if args.body else "") + ("UNION of %d clusters, each a UNION of %d spheres" % (args.groups, args.spheres // args.groups)) if args.groups
-           else "n-ary UNION of %d spheres" % args.spheres, "chain_members": prog.chain_members, "instructions": int(low.code.shape[0]),
+    what = ("UNION of %d clusters, each a UNION of %d spheres" % (args.groups, args.spheres // args.groups)) if args.groups \
+        else "n-ary UNION of %d spheres" % args.spheres
+    res = {"workload": ("a box minus the " if args.body else "") + what, "chain_members": prog.chain_members, "instructions": int(low.code.shape[0]),
            "cull_sites": int(len(low.cull_sites)), "grid": "%d^3" % axes[0].size, "points": n,
            "chain_mode": "#define SDFK_CHAIN 1" in prog.source(), "lower_and_program_s": t_lower}
     for key, mode, rows, reps in (("culled", _engine.MODE_SPECIALIZED, True, 5), ("plain", _engine.MODE_NOCULL, False, 2),
