@@ -395,7 +395,9 @@ class Lowerer:
                     raise TypeError("%s takes exactly 2 objects (%d given)" % (op, len(kids)))
             else:
                 raise KeyError(op)
-        if not expr.parametric and opcode == "VSUBTRACT":
+        if not expr.parametric and opcode == "VSUBTRACT" and not _holds_combiner(kids[0]):
+            # (a body that is a combination of its own stays an operand: the chain kernels then run the union as a chain
+            #  and body and subtraction as the REST of the program, sdfk_codegen.cpp chain_analyse)
             holes = _subtracted_union(kids[1])
             if holes is not None:
                 # body minus a UNION of many (a perforated plate, a porous block): max(a, -min_j b_j) = max(a, max_j -b_j),
@@ -534,6 +536,48 @@ def _subtracted_union(node):
     return tuple(_Negated(m) for m in members)
 
 
+def _large_hard_union(node):
+    """node: an operand. -> (opcode, members framed by the operand's own transform) when it is a bare hard n-ary combination
+    of at least as many members as the chain kernels take, else None."""
+    from .cores.combine import BINARY_OPS, NARY_OPS
+    if not _is_geometry(node):
+        return None
+    inner = node.modified_object
+    if not isinstance(inner, CombineSDF) or inner.parametric:
+        return None
+    op = getattr(inner.owner, "operation_type", None)
+    opcode = NARY_OPS.get(op) or BINARY_OPS.get(op)
+    if opcode not in ("VMIN", "VMAX"):
+        return None
+    members = _flatten_hard((node,), opcode, always=True)
+    if (len(members) == 1 and members[0] is node) or len(members) < _flatten_min():
+        return None
+    return opcode, members
+
+
+def _holds_combiner(node, depth=0):
+    """Is there a CombineGeometry anywhere in the expression of this geometry (a cull site inside it once lowered)?"""
+    if depth > 64:
+        return True
+    stack = [node.modified_object if _is_geometry(node) else node]
+    seen = 0
+    while stack:
+        e = stack.pop()
+        seen += 1
+        if seen > 4096 or isinstance(e, CombineSDF):
+            return True
+        if isinstance(e, NodeSDF):
+            if _is_geometry(e.obj):
+                stack.append(e.obj.modified_object)
+        elif isinstance(e, ModSDF):
+            stack.append(e.inner)
+            if isinstance(e.second, SDFExpr):
+                stack.append(e.second)
+            elif e.second is not None and _is_geometry(getattr(e.second, "__self__", None)):
+                stack.append(e.second.__self__.modified_object)
+    return False
+
+
 class _Operation:
     def __init__(self, operation_type):
         self.operation_type = operation_type
@@ -562,23 +606,43 @@ def _push_transform_into_members(node):
     while isinstance(inner, ModSDF) and inner.name in VALUE_OPS and inner.second is None and len(mods) < 64:
         mods.append(inner)
         inner = inner.inner
-    if not isinstance(inner, CombineSDF) or inner.parametric:
+    if not isinstance(inner, CombineSDF):
         return None
-    op = getattr(inner.owner, "operation_type", None)
-    opcode = NARY_OPS.get(op) or BINARY_OPS.get(op)
-    kids = inner.children
-    if opcode == "VSUBTRACT" and len(kids) == 2:                # body minus a large UNION: an INTERSECT (see _lower_combine)
-        holes = _subtracted_union(kids[1])
-        if holes is None:
+    members = None
+    if not inner.parametric:
+        op = getattr(inner.owner, "operation_type", None)
+        opcode = NARY_OPS.get(op) or BINARY_OPS.get(op)
+        kids = inner.children
+        if opcode == "VSUBTRACT" and len(kids) == 2 and not _holds_combiner(kids[0]):
+            holes = _subtracted_union(kids[1])                  # body minus a large UNION: an INTERSECT (see _lower_combine)
+            if holes is not None:
+                kids, opcode = (kids[0],) + holes, "VMAX"
+        if opcode in ("VMIN", "VMAX"):
+            members = _flatten_hard(kids, opcode, always=True)
+            if len(members) < _flatten_min():
+                members = None
+    if members is not None:
+        expr = CombineSDF(_Operation("UNION" if opcode == "VMIN" else "INTERSECT"),
+                          [_Reframed(node, m, coord_only=True) for m in members], parametric=False)
+    else:
+        # any other combination with a large hard union among its operands (a union clipped by a box, blended with a
+        # ground plane, subtracted from a body that is a combination itself — and then placed): the coordinate part of
+        # the transform goes into every operand, and into the members of those unions; the combination is kept
+        unions = [_large_hard_union(k) for k in inner.children]
+        if not any(u is not None for u in unions):
             return None
-        kids, opcode = (kids[0],) + holes, "VMAX"
-    if opcode not in ("VMIN", "VMAX"):
-        return None
-    members = _flatten_hard(kids, opcode, always=True)
-    if len(members) < _flatten_min():
-        return None
-    expr = CombineSDF(_Operation("UNION" if opcode == "VMIN" else "INTERSECT"),
-                      [_Reframed(node, m, coord_only=True) for m in members], parametric=False)
+        new_kids = []
+        for k, u in zip(inner.children, unions):
+            if u is None:
+                new_kids.append(_Reframed(node, k, coord_only=True))
+                continue
+            sub = CombineSDF(_Operation("UNION" if u[0] == "VMIN" else "INTERSECT"),
+                             [_Reframed(node, m, coord_only=True) for m in u[1]], parametric=False)
+            sub.path_key = ("pushed-operand", id(k))
+            holder = _ExprNode(sub, ())
+            holder.path_key = ("pushed-holder", id(k))
+            new_kids.append(holder)
+        expr = CombineSDF(inner.owner, new_kids, inner.parametric, inner.parameters)
     expr.path_key = ("pushed", id(inner))
     for m in reversed(mods):
         expr = ModSDF(m.name, m.args, expr)

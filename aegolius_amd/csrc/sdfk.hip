@@ -227,6 +227,7 @@ struct sdfk_program {
     std::vector<sdfk_cullsite> sites;  // brick-culling sites the mask kernels use: the 64 widest (sdfk_program_set_cull)
     std::vector<sdfk_cullsite> sites_all;  // every site that was passed in
     bool chain_mode = false;           // long n-ary min / max chain: table-driven kernels (sdfk_codegen.cpp)
+    int chain_members = 0;             // its members (the program may hold more sites: combiners above the chain)
     std::mutex mu;
     std::map<int, DevState> dev;
 };
@@ -536,7 +537,8 @@ extern "C" int sdfk_program_set_cull(sdfk_program* p, const uint32_t* rows, size
         sites.swap(widest);
     }
     p->sites = sites;
-    p->chain_mode = sdfk_chain_mode(g_ops, SDFK_OP_COUNT, p->code.data(), p->code.size() / 2, p->result_reg, p->sites_all);
+    p->chain_members = sdfk_chain_mode(g_ops, SDFK_OP_COUNT, p->code.data(), p->code.size() / 2, p->result_reg, p->sites_all);
+    p->chain_mode = p->chain_members > 0;
     p->key.append("|cull");
     for (const sdfk_cullsite& t : p->sites_all) {
         p->key.append(reinterpret_cast<const char*>(&t), sizeof t);
@@ -590,7 +592,7 @@ static int rows_wbricks(const sdfk_program* p) {
     // chain mode (measured, 513^3 sphere unions and the 50-child flat union): every brick of a wave costs a fold and an
     // evaluation pass one after the other, and the leaf values take 6 bytes of LDS per child and brick — few bricks per
     // wave win: 1000 spheres 21.9 / 11.4 / 5.5 ms with 4 / 2 / 1, the flat union 1.08 / 0.99 / 1.03 ms
-    if (p && p->chain_mode) return p->sites_all.size() + 1 <= 64 ? 2 : 1;
+    if (p && p->chain_mode) return p->chain_members <= 64 ? 2 : 1;
     return (p && p->code.size() / 2 > 150) ? 4 : 2;
 }
 struct RowGeom {           // mirrors sdfk_rowgeom of the generated source
@@ -1095,7 +1097,7 @@ static std::string flavour_source(const sdfk_program* p, int flavour, bool with_
 }
 
 extern "C" int sdfk_program_chain_members(const sdfk_program* p) {
-    return p && p->chain_mode ? (int)p->sites_all.size() + 1 : 0;
+    return p && p->chain_mode ? p->chain_members : 0;
 }
 extern "C" int sdfk_program_compile_check(sdfk_program* p, size_t* code_size) {
     // every flavour this program can be launched with, each as its own translation unit (what a run would build)

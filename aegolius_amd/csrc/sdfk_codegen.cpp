@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <set>
 
 // text of sdfk_device.h / sdfk_access.h, generated at build time by __graft_entry__.build()
@@ -986,7 +987,7 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
                 }
             }
 #endif
-            SDFK_EACH res[q] = sdfk_chain_tail<f2>(acc[q], PRM);
+            SDFK_EACH res[q] = sdfk_chain_tail<f2>(acc[q], P[q], PRM, TAB);
         }
 #endif
 #ifdef SDFK_FLAGS                                                  // (the flag-writing build) one bit per point instead of the field
@@ -1253,6 +1254,9 @@ struct Gen {
     std::vector<int> leaf_at;        // instruction -> leaf (or -1)
     bool simt = false;
 
+    // [region_lo, region_hi]: the instructions the leaf analysis is about — the whole program, or (chain mode with a REST,
+    // see chain_analyse) the chain's own instructions: what lies outside is evaluated per point by sdfk_chain_tail
+    size_t region_lo = 0, region_hi = (size_t)-1;
     bool analyse_leaves() {
         leaves.clear();
         groups.clear();
@@ -1287,7 +1291,9 @@ struct Gen {
             if ((int)op >= n_ops) return false;
             const int kind = ops[op].kind;
             if (!strcmp(ops[op].name, "V_FIELD")) return false;
-            if (leaf_at[i] < 0 && kind != SDFK_KIND_V_V && kind != SDFK_KIND_V_VV) return false;
+            const bool inside = i >= region_lo && i <= region_hi;
+            if (inside && leaf_at[i] < 0 && kind != SDFK_KIND_V_V && kind != SDFK_KIND_V_VV) return false;
+            if (!inside && i < region_lo && kind == SDFK_KIND_C_C && a == 0) return false;   // the leaves start from the INPUT point
             // a leaf may rewrite the input point for itself (the last child of a combiner reuses C_0: inside the leaf's
             // function that is a local copy) — but nobody else may read it afterwards
             const unsigned b = (w >> 16) & 255u;
@@ -1547,8 +1553,12 @@ struct Gen {
         unsigned acc = 0;           // accumulator register
         bool is_max = false;        // VMAX (INTERSECT) instead of VMIN (UNION)
         size_t tail = 0;            // first instruction after the last combiner
+        size_t lo = 0;              // first instruction of the first leaf
+        bool rest = false;          // instructions before the chain, or after it other than in-place modifications of its value
+        int result = 0;             // the program's result register
         std::vector<float> k;       // Lipschitz sum of level k (site k - 1)
     } chain;
+    std::vector<sdfk_cullsite> chain_sites;      // the sites of the chain itself (a program with a rest has others too)
 
     bool analyse_chain(int result_reg) {
         chain = Chain();
@@ -1573,13 +1583,48 @@ struct Gen {
             chain.k[j + 1] = t.k;
         }
         chain.tail = (*sites)[n - 2].comb + 1;
-        for (size_t i = chain.tail; i < n_instr; ++i) {              // value modifications of the result, in place
+        chain.lo = leaves[0].lo;
+        chain.result = result_reg;
+        chain.rest = chain.lo > 0 || (unsigned)result_reg != chain.acc;
+        for (size_t i = chain.tail; i < n_instr; ++i) {              // value modifications of the result, in place: no rest
             const uint32_t w = code[2 * i];
-            if (ops[w & 255u].kind != SDFK_KIND_V_V) return false;
-            if (((w >> 8) & 255u) != chain.acc || ((w >> 16) & 255u) != chain.acc) return false;
+            if (ops[w & 255u].kind != SDFK_KIND_V_V || ((w >> 8) & 255u) != chain.acc || ((w >> 16) & 255u) != chain.acc) chain.rest = true;
         }
-        if ((unsigned)result_reg != chain.acc) return false;
+        // the rest runs un-culled, straight-line, for every point: worth it while it is small next to the chain (a clip, a
+        // ground plane, a body) — a program of many medium-sized unions is better off on the mask kernels, whose widest
+        // sites skip whole unions
+        if (chain.rest && chain.lo + (n_instr - chain.tail) > 64 + (chain.tail - chain.lo) / 4) return false;
+        if (chain.rest && !rest_ok()) return false;
         chain.ok = true;
+        return true;
+    }
+    // A program with a REST: instructions before the chain (other operands of the combiners above it) and after it (those
+    // combiners, value modifications). sdfk_chain_tail evaluates them per point around the chain's value — which the
+    // chain kernels produce from the brick's survivor list, exact at every point of the brick whatever is done with it
+    // afterwards. That is the original program iff nothing after the chain reads a register the chain's instructions wrote,
+    // other than its accumulator (temporaries of the leaves; C_0 where the last leaf reused it).
+    bool rest_ok() const {
+        std::vector<char> wc(256, 0), wv(256, 0);                   // written by the chain's instructions
+        for (size_t i = chain.lo; i < chain.tail; ++i) {
+            const uint32_t w = code[2 * i];
+            if (ops[w & 255u].kind == SDFK_KIND_C_C) wc[(w >> 8) & 255u] = 1;
+            else wv[(w >> 8) & 255u] = 1;
+        }
+        std::vector<char> sc(256, 0), sv(256, 0);                   // written since, by the instructions after the chain
+        sv[chain.acc] = 1;
+        for (size_t i = chain.tail; i < n_instr; ++i) {
+            const uint32_t w = code[2 * i];
+            const unsigned op = w & 255u, a = (w >> 8) & 255u, b = (w >> 16) & 255u, c = w >> 24;
+            const int kind = ops[op].kind;
+            if (kind == SDFK_KIND_C_C || kind == SDFK_KIND_V_C) {
+                if (wc[b] && !sc[b]) return false;
+            } else {
+                if (wv[b] && !sv[b]) return false;
+                if (kind == SDFK_KIND_V_VV && wv[c] && !sv[c]) return false;
+            }
+            if (kind == SDFK_KIND_C_C) sc[a] = 1;
+            else sv[a] = 1;
+        }
         return true;
     }
 
@@ -1605,7 +1650,9 @@ struct Gen {
             n_params = std::max(n_params, code[2 * lf.lo + 1] + group_npl[lf.group]);
         }
         s += "};\n";
-        for (size_t i = chain.tail; i < n_instr; ++i) n_params = std::max(n_params, code[2 * i + 1] + (unsigned)std::max(0, ops[code[2 * i] & 255u].nparams));
+        for (size_t i = 0; i < n_instr; ++i)
+            if (i < chain.lo || i >= chain.tail)
+                n_params = std::max(n_params, code[2 * i + 1] + (unsigned)std::max(0, ops[code[2 * i] & 255u].nparams));
         float kmax = 0.0f;
         for (float k : chain.k) kmax = std::max(kmax, k);
         snprintf(buf, sizeof buf,
@@ -1626,20 +1673,33 @@ struct Gen {
              "const float* __restrict__ TAB) {\n    return sdfk_leaf_at<T>(sdfk_leaf_grp[k], C_0, PRM + sdfk_leaf_base[k], TAB);\n}\n";
         const char* cmb = chain.is_max ? "cmb_max" : "cmb_min";
         // the result modifications, applied to an accumulator of type T
-        s += "template <typename T> static __device__ __forceinline__ T sdfk_chain_tail(T V_acc, const float* __restrict__ PRM) {\n";
-        for (size_t i = chain.tail; i < n_instr; ++i) {
-            const uint32_t w = code[2 * i], poff = code[2 * i + 1];
-            snprintf(buf, sizeof buf, "    V_acc = %s(V_acc, PRM + %u);\n", ops[w & 255u].func, poff);
+        s += "template <typename T> static __device__ __forceinline__ T sdfk_chain_tail(T V_chain, V3T<T> C_0, const float* __restrict__ PRM, "
+             "const float* __restrict__ TAB) {\n";
+        if (!chain.rest) {
+            s += "    T V_acc = V_chain;\n";
+            for (size_t i = chain.tail; i < n_instr; ++i) {
+                const uint32_t w = code[2 * i], poff = code[2 * i + 1];
+                snprintf(buf, sizeof buf, "    V_acc = %s(V_acc, PRM + %u);\n", ops[w & 255u].func, poff);
+                s += buf;
+            }
+            s += "    return V_acc;\n}\n";
+        } else {
+            // the rest of the program around the chain's value: what comes before the chain, then what comes after it
+            declare("V3T<T>", "T", false);
+            for (size_t i = 0; i < chain.lo; ++i) instr(i, "    ");
+            snprintf(buf, sizeof buf, "    V_%u = V_chain;\n", chain.acc);
+            s += buf;
+            for (size_t i = chain.tail; i < n_instr; ++i) instr(i, "    ");
+            snprintf(buf, sizeof buf, "    return V_%d;\n}\n", chain.result);
             s += buf;
         }
-        s += "    return V_acc;\n}\n";
         // plain evaluation: every leaf in order
         snprintf(buf, sizeof buf,
                  "template <typename T> static __device__ __forceinline__ T sdfk_point(V3T<T> C_0, const float* __restrict__ PRM, "
                  "const float* __restrict__ TAB, const float* __restrict__, long long) {\n"
                  "    T acc = sdfk_leaf<T>(0u, C_0, PRM, TAB);\n"
                  "    _Pragma(\"unroll 1\") for (unsigned k = 1u; k < SDFK_NLEAF; ++k) acc = %s(acc, sdfk_leaf<T>(k, C_0, PRM, TAB), PRM);\n"
-                 "    return sdfk_chain_tail<T>(acc, PRM);\n}\n",
+                 "    return sdfk_chain_tail<T>(acc, C_0, PRM, TAB);\n}\n",
                  cmb);
         s += buf;
         // culled evaluation of one row-block brick: the levels on the brick's list, in order
@@ -1900,18 +1960,39 @@ static size_t chain_min_leaves() {
     return v;
 }
 static bool chain_analyse(Gen& g, int result_reg, const std::vector<sdfk_cullsite>* sites_all) {
+    if (!sites_all || sites_all->size() + 1 < chain_min_leaves()) return false;
+    // The chain: the largest set of sites that share their first operand's start and their combiner (the in-place fold
+    // of an n-ary min / max; analyse_chain checks the pattern). Other sites — combiners above the chain, with the chain
+    // in one operand — belong to the REST of the program, which runs un-culled around the chain's value.
+    std::map<std::pair<uint32_t, uint32_t>, std::vector<sdfk_cullsite>> by_start;
+    for (const sdfk_cullsite& t : *sites_all) by_start[{t.a0, g.code[2 * t.comb] & 0xffffffu}].push_back(t);
+    const std::vector<sdfk_cullsite>* best = nullptr;
+    for (const auto& kv : by_start)
+        if (!best || kv.second.size() > best->size()) best = &kv.second;
     // (at most 2048 leaves: 24 bytes of LDS per leaf and workgroup for the leaf values and the lists)
-    if (!sites_all || sites_all->size() + 1 < chain_min_leaves() || sites_all->size() + 1 > 2048) return false;
+    if (!best || best->size() + 1 < chain_min_leaves() || best->size() + 1 > 2048) return false;
+    g.chain_sites = *best;
+    std::sort(g.chain_sites.begin(), g.chain_sites.end(), [](const sdfk_cullsite& x, const sdfk_cullsite& y) { return x.comb < y.comb; });
+    for (const sdfk_cullsite& t : *sites_all) {                     // a site inside the chain that is not of the chain: no
+        const bool ours = std::any_of(g.chain_sites.begin(), g.chain_sites.end(), [&](const sdfk_cullsite& c) { return c.comb == t.comb; });
+        if (!ours && t.comb >= g.chain_sites.front().a0 && t.comb <= g.chain_sites.back().comb) return false;
+    }
     const std::vector<sdfk_cullsite>* keep = g.sites;
-    g.sites = sites_all;
+    g.sites = &g.chain_sites;
+    g.region_lo = g.chain_sites.front().a0;
+    g.region_hi = g.chain_sites.back().comb;
     const bool ok = g.analyse_leaves() && g.analyse_chain(result_reg) && g.leaves_contiguous();
-    if (!ok) g.sites = keep;
+    if (!ok) {
+        g.sites = keep;
+        g.region_lo = 0;
+        g.region_hi = (size_t)-1;
+    }
     return ok;
 }
-bool sdfk_chain_mode(const sdfk_opinfo* ops, int n_ops, const uint32_t* code, size_t n_instr, int result_reg,
-                     const std::vector<sdfk_cullsite>& sites_all) {
+int sdfk_chain_mode(const sdfk_opinfo* ops, int n_ops, const uint32_t* code, size_t n_instr, int result_reg,
+                    const std::vector<sdfk_cullsite>& sites_all) {
     Gen g{ops, n_ops, code, n_instr, &sites_all, std::string()};
-    return chain_analyse(g, result_reg, &sites_all);
+    return chain_analyse(g, result_reg, &sites_all) ? (int)g.leaves.size() : 0;
 }
 
 std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32_t* code, size_t n_instr,

@@ -51,10 +51,10 @@ enum sdfk_flavour {
 std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32_t* code, size_t n_instr,
                                  int result_reg, const std::vector<sdfk_cullsite>& sites, int flavour,
                                  const std::vector<sdfk_cullsite>* sites_all = nullptr);
-// does the program run in chain mode? (the launcher then has no line-brick flavour and never falls back to the interpreter
-// for size)
-bool sdfk_chain_mode(const sdfk_opinfo* ops, int n_ops, const uint32_t* code, size_t n_instr, int result_reg,
-                     const std::vector<sdfk_cullsite>& sites_all);
+// members of the chain when the program runs in chain mode, else 0 (the launcher then has no line-brick flavour and never
+// falls back to the interpreter for size)
+int sdfk_chain_mode(const sdfk_opinfo* ops, int n_ops, const uint32_t* code, size_t n_instr, int result_reg,
+                    const std::vector<sdfk_cullsite>& sites_all);
 
 // Text every chain-specialised vector kernel starts with: sdfk_device.h followed by sdfk_vecdev.h.
 std::string sdfk_vector_prelude();

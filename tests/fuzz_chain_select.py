@@ -75,6 +75,19 @@ def random_scene(ns, rng):
             tree.move((0.03, -0.02, 0.0))
         body = ns.Rectangle(1.6 * extent, 1.4 * extent) if flat else ns.Box(1.6 * extent, 1.5 * extent, 1.2 * extent)
         tree = ns.CombineGeometry("SUBTRACT2").combine(body, tree)
+    if count >= 17 and rng.random() < 0.3:                      # the union as an OPERAND of a larger program (chain + rest)
+        w = rng.random()
+        other = ns.Circle(0.8 * extent) if flat else ns.Sphere(0.8 * extent)
+        if w < 0.35:
+            tree = ns.CombineGeometry("INTERSECT2").combine(tree, other)
+        elif w < 0.7:
+            tree = ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(other, tree, parameters=0.1)
+        else:
+            body = ns.CombineGeometry("SMOOTH_UNION2_2").combine_parametric(other, ns.Rectangle(extent, extent) if flat else ns.Box(extent, extent, extent), parameters=0.2)
+            tree = ns.CombineGeometry("SUBTRACT2").combine(body, tree)
+        if rng.random() < 0.5:
+            tree.rotate(float(rng.uniform(0, 1)), (0, 0, 1))
+            tree.move((0.02, 0.03, 0.0))
     r = rng.random()
     if r < 0.15:
         tree.rounding(0.02)

@@ -1308,7 +1308,9 @@ def test_body_minus_a_large_union_runs_as_one_chain(moved, engine, monkeypatch):
     monkeypatch.setenv("SDFK_NO_FLATTEN", "1")
     nested = engine.Program.from_lowered(lower_geometry(tree))
     monkeypatch.delenv("SDFK_NO_FLATTEN")
-    assert nested.chain_members == 0
+    # (not rewritten, the union is still a chain of its own with plate and subtraction as the rest of the program — unless
+    #  its members read moved coordinates)
+    assert nested.chain_members == (0 if moved else 120)
     for shape, mis in ROW_SHAPES[:3]:
         co, _ = ns.generate_grid((2.4, 2.4, 1.0), tuple(r - 1 for r in shape))
         co32 = co.astype(np.float32)
@@ -1327,6 +1329,67 @@ def test_body_minus_a_large_union_runs_as_one_chain(moved, engine, monkeypatch):
             assert float(np.max(np.abs(want - old))) < 2e-6
         else:
             np.testing.assert_array_equal(want, old)
+
+
+def _rest_scenes():
+    from aegolius_amd import workloads
+
+    def union(n=100, seed=4):
+        return workloads.sphere_union(ns, n, seed=seed, radius=0.08)
+    out = {}
+    out["clipped"] = ns.CombineGeometry("INTERSECT2").combine(union(), ns.Box(1.5, 1.5, 1.5))
+    ground = ns.Box(2.0, 2.0, 0.2)
+    ground.move((0, 0, -0.8))
+    out["blended_with_ground"] = ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(ground, union(), parameters=0.1)
+    body = ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(ns.Box(1.6, 1.6, 1.6), ns.Sphere(1.0), parameters=0.1)
+    out["composite_body_minus_union"] = ns.CombineGeometry("SUBTRACT2").combine(body, union())
+    t = ns.CombineGeometry("INTERSECT2").combine(union(), ns.Sphere(0.9))
+    t.onion(0.01)
+    out["clipped_onion"] = t
+    u = union()
+    u.move((0.05, 0, 0))
+    t = ns.CombineGeometry("INTERSECT2").combine(u, ns.Box(1.5, 1.5, 1.5))
+    t.rotate(0.3, (0, 1, 0))
+    t.move((0.1, 0, 0))
+    t.rescale(1.1)
+    out["clipped_and_placed"] = t
+    ground = ns.Box(2.0, 2.0, 0.2)
+    ground.move((0, 0, -0.8))
+    t = ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(ground, union(), parameters=0.1)
+    t.rotate(0.2, (1, 0, 0))
+    t.onion(0.02)
+    out["blended_placed_onion"] = t
+    two = ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(union(60, 4), union(30, 9), parameters=0.05)   # the larger one is the chain
+    out["two_unions_blended"] = two
+    return out
+
+
+@pytest.mark.parametrize("name", ["clipped", "blended_with_ground", "composite_body_minus_union", "clipped_onion",
+                                  "clipped_and_placed", "blended_placed_onion", "two_unions_blended"])
+def test_chain_inside_a_larger_program(name, engine):
+    """A large hard union that is an OPERAND — clipped by a box, blended with a ground plane, subtracted from a composite
+    body, with value modifications on top, placed as a whole: the union runs as a chain (per-brick survivor lists), the rest
+    of the program per point around its value (sdfk_chain_tail). All kernels agree bit for bit — the survivor list is
+    exact whatever is done with the chain's value afterwards — and with the oracle within 1e-6."""
+    tree = _rest_scenes()[name]
+    low = lower_geometry(tree)
+    prog = engine.Program.from_lowered(low)
+    assert prog.chain_members == (60 if name == "two_unions_blended" else 100)
+    for shape, mis in ROW_SHAPES[:3]:
+        co, _ = ns.generate_grid((2.2, 2.2, 2.2), tuple(r - 1 for r in shape))
+        co32 = co.astype(np.float32)
+        n = co32.shape[1]
+        row_len = int(np.flatnonzero(co32[1] != co32[1][0])[0])
+        want = _device_eval(engine, prog, co32, n, n + 5, mis, engine.MODE_NOCULL)
+        for mode, hint in ((engine.MODE_SPECIALIZED, row_len), (engine.MODE_SPECIALIZED, None), (engine.MODE_INTERPRET, None)):
+            np.testing.assert_array_equal(_device_eval(engine, prog, co32, n, n + 5, mis, mode, row_len=hint), want)
+        axes = [a.astype(np.float32) for a in co.grid_axes]
+        np.testing.assert_array_equal(prog.eval_grid_host(axes), want)
+        np.testing.assert_array_equal(prog.select_grid(axes, 0.0), np.flatnonzero(want <= 0))
+        with np.errstate(all="ignore"):
+            ref = sdf_oracle.evaluate(tree, co32.astype(np.float64))
+        err, bad = violations(want, ref)
+        assert not bad.any(), (name, shape, float(np.nanmax(err)))
 
 
 def test_staged_operator_inside_a_flattened_union(engine, monkeypatch):

@@ -373,7 +373,24 @@ def test_nested_hard_unions_flatten_only_at_chain_size(built, monkeypatch):
     # body minus a large union: an INTERSECT of the body and the negated members
     assert members(ns.CombineGeometry("SUBTRACT2").combine(ns.Box(1, 1, 1), cluster("UNION", 30, 0.0))) == 31
     assert members(ns.CombineGeometry("SUBTRACT2").combine(ns.Box(1, 1, 1), cluster("UNION", 8, 0.0))) == 0
-    assert members(ns.CombineGeometry("SUBTRACT2").combine(ns.Box(1, 1, 1), cluster("INTERSECT", 30, 0.0))) == 0
+    # ... minus an INTERSECT: not rewritten, but the intersection itself is a chain and box + subtraction the REST of the
+    # program, evaluated per point around the chain's value (sdfk_codegen.cpp chain_analyse); so are a clipped union, a
+    # union blended with something else, and either of them placed as a whole
+    assert members(ns.CombineGeometry("SUBTRACT2").combine(ns.Box(1, 1, 1), cluster("INTERSECT", 30, 0.0))) == 30
+    clipped = ns.CombineGeometry("INTERSECT2").combine(cluster("UNION", 40, 0.0), ns.Sphere(2.0))
+    assert members(clipped) == 40
+    clipped.rotate(0.3, (0, 1, 0))
+    clipped.move((0.1, 0, 0))
+    clipped.rescale(1.2)
+    assert members(clipped) == 40
+    blended = ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(ns.Box(3, 3, 0.1), cluster("UNION", 25, 0.0), parameters=0.1)
+    blended.onion(0.01)
+    assert members(blended) == 25
+    body = ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(ns.Box(1, 1, 1), ns.Sphere(0.7), parameters=0.1)
+    assert members(ns.CombineGeometry("SUBTRACT2").combine(body, cluster("UNION", 30, 0.0))) == 30
+    twisted = cluster("UNION", 30, 0.0)
+    twisted.twist(0.3)                                          # the members read warped coordinates: no chain
+    assert members(twisted) == 0
     d = cluster("UNION", 10, 2.0)
     d.rescale(-1.0)                                             # a negative scale turns min into max: not flattened
     assert members(ns.CombineGeometry("UNION2").combine(a, d)) == 0

@@ -1,6 +1,8 @@
 """Developer tool (GPU): an n-ary UNION of many spheres on a resident grid — chain mode (culled row blocks, un-culled)
 against the interpreter kernel.   python tools/big_union_bench.py [--spheres 1000] [--grid 512] [--json out.json]
 --body: a box MINUS that union (lowered as one n-ary INTERSECT of the box and the negated spheres).
+--clip / --blend: the union as an operand of a larger program (INTERSECT2 with a sphere / SMOOTH_UNION2 with a slab, rotated):
+the union runs as a chain, the rest of the program per point around its value.
 --groups G: the same number of spheres as G rigidly placed clusters, each a UNION of its own (nested unions: flattened
 into one chain by the lowering); the NESTED program (SDFK_NO_FLATTEN=1, what round 2 ran: the interpreter kernel beyond
 the specialisation limit) is timed next to it (the two differ by fp32 rounding: the flattened program composes the group's
@@ -24,6 +26,8 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--groups", type=int, default=0)
     ap.add_argument("--body", action="store_true", help="a block MINUS the union (porous block): one INTERSECT chain after lowering")
+    ap.add_argument("--clip", action="store_true", help="the union clipped by a sphere (INTERSECT2): chain + rest of the program")
+    ap.add_argument("--blend", action="store_true", help="the union blended with a ground slab (SMOOTH_UNION2): chain + rest")
     args = ap.parse_args()
     import torch
     import aegolius_amd.cores as ns
@@ -36,12 +40,19 @@ def main():
         tree = workloads.sphere_union(ns, args.spheres)
     if args.body:
         tree = ns.CombineGeometry("SUBTRACT2").combine(ns.Box(1.7, 1.7, 1.7), tree)
+    if args.clip:
+        tree = ns.CombineGeometry("INTERSECT2").combine(tree, ns.Sphere(0.85))
+    if args.blend:
+        slab = ns.Box(2.0, 2.0, 0.3)
+        slab.move((0, 0, -0.7))
+        tree = ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(slab, tree, parameters=0.1)
+        tree.rotate(0.2, (1, 0, 0))
     t0 = time.perf_counter()
     low = lower_geometry(tree)
     prog = _engine.Program.from_lowered(low)
     t_lower = time.perf_counter() - t0
     nested = None
-    if args.groups or args.body:
+    if args.groups:
         os.environ["SDFK_NO_FLATTEN"] = "1"
         nested = _engine.Program.from_lowered(lower_geometry(tree))
         del os.environ["SDFK_NO_FLATTEN"]
@@ -56,7 +67,8 @@ def main():
     row_len = int(axes[2].size)
     what = ("UNION of %d clusters, each a UNION of %d spheres" % (args.groups, args.spheres // args.groups)) if args.groups \
         else "n-ary UNION of %d spheres" % args.spheres
-    res = {"workload": ("a box minus the " if args.body else "") + what, "chain_members": prog.chain_members, "instructions": int(low.code.shape[0]),
+    res = {"workload": ("a box minus the " if args.body else "") + what + (" clipped by a sphere" if args.clip else "")
+           + (" blended with a ground slab, rotated" if args.blend else ""), "chain_members": prog.chain_members, "instructions": int(low.code.shape[0]),
            "cull_sites": int(len(low.cull_sites)), "grid": "%d^3" % axes[0].size, "points": n,
            "chain_mode": "#define SDFK_CHAIN 1" in prog.source(), "lower_and_program_s": t_lower}
     for key, mode, rows, reps in (("culled", _engine.MODE_SPECIALIZED, True, 5), ("plain", _engine.MODE_NOCULL, False, 2),

@@ -67,6 +67,8 @@ python3 tools/big_union_bench.py --spheres 1000 --grid 512 --json "$O/${tag}_uni
 python3 tools/big_union_bench.py --spheres 200 --grid 512 --json "$O/${tag}_union200_513.json" > /dev/null 2>&1
 python3 tools/big_union_bench.py --spheres 1000 --groups 20 --grid 512 --json "$O/${tag}_clusters1000_513.json" > /dev/null 2>&1
 python3 tools/big_union_bench.py --spheres 500 --body --grid 512 --json "$O/${tag}_porous500_513.json" > /dev/null 2>&1
+python3 tools/big_union_bench.py --spheres 500 --clip --grid 512 --json "$O/${tag}_clipped500_513.json" > /dev/null 2>&1
+python3 tools/big_union_bench.py --spheres 500 --blend --grid 512 --json "$O/${tag}_blended500_513.json" > /dev/null 2>&1
 for g in 512 1024; do python3 tools/row_mask_stats.py cfg2 $g 2>&1 | grep -v amdgpu.ids; done > "$O/${tag}_row_mask_stats.txt"
 python3 tools/row_mask_stats.py cfg5 1024 2>&1 | grep -v amdgpu.ids >> "$O/${tag}_row_mask_stats.txt"
 fi
