@@ -1593,7 +1593,8 @@ struct Gen {
         // the rest runs un-culled, straight-line, for every point: worth it while it is small next to the chain (a clip, a
         // ground plane, a body) — a program of many medium-sized unions is better off on the mask kernels, whose widest
         // sites skip whole unions
-        if (chain.rest && chain.lo + (n_instr - chain.tail) > 64 + (chain.tail - chain.lo) / 4) return false;
+        // (and at most 256 instructions: it is compiled inline)
+        if (chain.rest && chain.lo + (n_instr - chain.tail) > std::min<size_t>(256, 64 + (chain.tail - chain.lo) / 4)) return false;
         if (chain.rest && !rest_ok()) return false;
         chain.ok = true;
         return true;

@@ -75,7 +75,7 @@ int sdfk_program_set_params(sdfk_program* prog, const float* params, size_t n_pa
  * "chain mode" with all of the chain's sites: one function per kind of leaf, tables of parameter offsets, a list of
  * surviving leaves per brick; it builds in about a second whatever its size. The chain may be the whole program (with
  * value modifications of its result) or an operand of a small program around it — clipped, blended, subtracted: those
- * instructions (at most 64 + a quarter of the chain's) run per point around the chain's value, un-culled. */
+ * instructions (at most 64 + a quarter of the chain's, and 256) run per point around the chain's value, un-culled. */
 int sdfk_program_set_cull(sdfk_program* prog, const uint32_t* sites, size_t n_sites, const float* k);
 /* Members of the n-ary chain when the program runs in chain mode (after sdfk_program_set_cull), else 0. */
 int sdfk_program_chain_members(const sdfk_program* prog);

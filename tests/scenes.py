@@ -416,6 +416,96 @@ scene("host_chip_3D")(example_scenes.chip)          # (a Python callable as disp
 scene("tree_olympic_rings_2D")(example_scenes.olympic_rings)
 
 
+# large hard unions in the forms the lowering rewrites (nested groups flattened, a transform of the whole pushed into the
+# members, body minus union as one INTERSECT) or runs as a chain inside a larger program — pinned against the REAL reference
+def _scattered(ns, count, seed, radius=0.12, extent=1.0, kinds=2):
+    rng = np.random.default_rng(seed)
+    objs = []
+    for k in range(count):
+        o = ns.Sphere(float(radius * rng.uniform(0.5, 1.5))) if k % kinds == 0 else ns.Box(*(float(x) for x in rng.uniform(0.1, 0.3, 3)))
+        if k % 5 == 0:
+            o.rounding(0.01)
+        if k % 3 == 0:
+            o.rotate(float(rng.uniform(0, 3)), tuple(rng.normal(size=3)))
+        o.move(rng.uniform(-extent, extent, 3))
+        objs.append(o)
+    return objs
+
+
+@scene("chain_union_60_flat")
+def _(ns):
+    return ns.CombineGeometry("UNION").combine(*_scattered(ns, 60, 1))
+
+
+@scene("chain_clusters_nested_placed")
+def _(ns):
+    rng = np.random.default_rng(2)
+    groups = []
+    for g in range(6):
+        u = ns.CombineGeometry("UNION").combine(*_scattered(ns, 12, 10 + g, radius=0.08, extent=0.3))
+        u.rotate(float(rng.uniform(0, 3)), tuple(rng.normal(size=3)))
+        u.move(rng.uniform(-0.8, 0.8, 3))
+        if g % 2:
+            u.rescale(1.3)
+        groups.append(u)
+    pair = ns.CombineGeometry("UNION2").combine(groups[0], groups[1])
+    pair.move((0.1, 0.0, -0.1))
+    scene_ = ns.CombineGeometry("UNION").combine(pair, *groups[2:])
+    scene_.rotate(0.4, (0, 1, 0))
+    scene_.rescale(0.9)
+    scene_.onion(0.02)
+    return scene_
+
+
+@scene("chain_perforated_plate")
+def _(ns):
+    plate = ns.Box(2.2, 2.0, 0.5)
+    holes = ns.CombineGeometry("UNION").combine(*_scattered(ns, 40, 3, radius=0.1, kinds=1))
+    holes.move((0.05, 0, 0))
+    out = ns.CombineGeometry("SUBTRACT2").combine(plate, holes)
+    out.rotate(0.3, (1, 0, 0))
+    return out
+
+
+@scene("chain_intersection_40")
+def _(ns):
+    objs = []
+    rng = np.random.default_rng(4)
+    for _k in range(40):
+        b = ns.Box(*(float(x) for x in rng.uniform(2.0, 3.0, 3)))
+        b.rotate(float(rng.uniform(0, 3)), tuple(rng.normal(size=3)))
+        b.move(rng.uniform(-0.4, 0.4, 3))
+        objs.append(b)
+    return ns.CombineGeometry("INTERSECT").combine(*objs)
+
+
+@scene("chain_clipped_and_placed")
+def _(ns):
+    u = ns.CombineGeometry("UNION").combine(*_scattered(ns, 50, 5))
+    t = ns.CombineGeometry("INTERSECT2").combine(u, ns.Sphere(1.1))
+    t.rotate(0.3, (0, 1, 0))
+    t.move((0.1, 0, 0))
+    t.rescale(1.1)
+    return t
+
+
+@scene("chain_blended_with_ground")
+def _(ns):
+    ground = ns.Box(3.0, 3.0, 0.3)
+    ground.move((0, 0, -0.9))
+    u = ns.CombineGeometry("UNION").combine(*_scattered(ns, 50, 6))
+    t = ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(ground, u, parameters=0.15)
+    t.rounding(0.01)
+    return t
+
+
+@scene("chain_composite_body_minus_union")
+def _(ns):
+    body = ns.CombineGeometry("SMOOTH_UNION2_2").combine_parametric(ns.Box(2.0, 2.0, 2.0), ns.Sphere(1.3), parameters=0.2)
+    u = ns.CombineGeometry("UNION").combine(*_scattered(ns, 40, 7, kinds=1))
+    return ns.CombineGeometry("SUBTRACT2").combine(body, u)
+
+
 @scene("tree_deep_right")
 def _(ns):
     """Right-deep nesting: exercises the value-register stack."""
