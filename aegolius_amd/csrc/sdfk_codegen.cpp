@@ -1970,8 +1970,9 @@ static bool chain_analyse(Gen& g, int result_reg, const std::vector<sdfk_cullsit
     const std::vector<sdfk_cullsite>* best = nullptr;
     for (const auto& kv : by_start)
         if (!best || kv.second.size() > best->size()) best = &kv.second;
-    // (at most 2048 leaves: 24 bytes of LDS per leaf and workgroup for the leaf values and the lists)
-    if (!best || best->size() + 1 < chain_min_leaves() || best->size() + 1 > 2048) return false;
+    // (at most 4096 leaves — the lowering keeps 4095 sites —: 13 bytes of LDS per leaf and workgroup for the leaf values and
+    //  the lists, 54 KB at 4096: two workgroups per CU)
+    if (!best || best->size() + 1 < chain_min_leaves() || best->size() + 1 > 4096) return false;
     g.chain_sites = *best;
     std::sort(g.chain_sites.begin(), g.chain_sites.end(), [](const sdfk_cullsite& x, const sdfk_cullsite& y) { return x.comb < y.comb; });
     for (const sdfk_cullsite& t : *sites_all) {                     // a site inside the chain that is not of the chain: no
@@ -1982,7 +1983,11 @@ static bool chain_analyse(Gen& g, int result_reg, const std::vector<sdfk_cullsit
     g.sites = &g.chain_sites;
     g.region_lo = g.chain_sites.front().a0;
     g.region_hi = g.chain_sites.back().comb;
-    const bool ok = g.analyse_leaves() && g.analyse_chain(result_reg) && g.leaves_contiguous();
+    bool ok = g.analyse_leaves() && g.analyse_chain(result_reg) && g.leaves_contiguous();
+    // (a member is compiled inline: beyond 4096 members the lowering drops the sites of the first levels, and what they
+    //  combined becomes ONE member of hundreds of primitives — minutes of hiprtc; such programs stay where they were)
+    for (size_t k = 0; ok && k < g.leaves.size(); ++k)
+        if (g.leaves[k].hi - g.leaves[k].lo + 1 > 256) ok = false;
     if (!ok) {
         g.sites = keep;
         g.region_lo = 0;

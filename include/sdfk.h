@@ -71,7 +71,7 @@ int sdfk_program_set_params(sdfk_program* prog, const float* params, size_t n_pa
  * How the sites are used: up to 64 of them as two mask bits each (the widest, in program order; the line-brick kernel
  * takes 31). The probe runs lane-parallel when every leaf range (a range without a site inside) reads nothing but the
  * input point: all leaves at all probe centres on the lanes of the workgroup, 8 / 4 / 1 centres per brick. A program
- * that holds an n-ary hard min / max over 17 to 2048 such leaves (CombineGeometry("UNION").combine(*many)) runs in
+ * that holds an n-ary hard min / max over 17 to 4096 such leaves (CombineGeometry("UNION").combine(*many)) runs in
  * "chain mode" with all of the chain's sites: one function per kind of leaf, tables of parameter offsets, a list of
  * surviving leaves per brick; it builds in about a second whatever its size. The chain may be the whole program (with
  * value modifications of its result) or an operand of a small program around it — clipped, blended, subtracted: those

@@ -888,6 +888,31 @@ def test_very_large_trees_run_without_a_compile(engine, golden_inputs):
     check("smooth_union_of_100_spheres", smooth, sdf_oracle.evaluate(acc, golden_inputs))
 
 
+def test_the_largest_chain_has_4096_members(engine):
+    """4096 spheres (the lowering keeps 4095 cull sites): still one chain — culled row blocks, the un-culled chain kernel
+    and the interpreter agree bit for bit on a small grid, and with the oracle on a sample; one member more and the
+    program is no chain (mask kernels / interpreter)."""
+    from aegolius_amd import workloads
+    tree = workloads.sphere_union(ns, 4096, seed=12, radius=0.03)
+    prog = engine.Program.from_lowered(lower_geometry(tree))
+    assert prog.chain_members == 4096
+    # (a few members more: the lowering drops the sites of the first levels, their operands become one member — a pair, a
+    #  triple; beyond a member of 256 instructions the program is no chain any more: mask kernels / interpreter)
+    assert engine.Program.from_lowered(lower_geometry(workloads.sphere_union(ns, 4098, seed=12, radius=0.03))).chain_members == 4096
+    assert engine.Program.from_lowered(lower_geometry(workloads.sphere_union(ns, 4300, seed=12, radius=0.03))).chain_members == 0
+    co, _ = ns.generate_grid((2, 2, 2), (20, 24, 64))
+    co32 = co.astype(np.float32)
+    n = co32.shape[1]
+    row_len = int(np.flatnonzero(co32[1] != co32[1][0])[0])
+    plain = _device_eval(engine, prog, co32, n, n, 0, engine.MODE_NOCULL)
+    np.testing.assert_array_equal(_device_eval(engine, prog, co32, n, n, 0, engine.MODE_SPECIALIZED, row_len=row_len), plain)
+    np.testing.assert_array_equal(_device_eval(engine, prog, co32, n, n, 0, engine.MODE_INTERPRET), plain)
+    pick = np.random.default_rng(1).choice(n, 1500, replace=False)
+    ref = sdf_oracle.evaluate(tree, co32[:, pick].astype(np.float64))
+    err, bad = violations(plain[pick], ref)
+    assert not bad.any(), float(np.nanmax(err))
+
+
 def test_sharded_evaluation_of_trees_with_conv_operators(engine):
     """Slabs of whole planes with a recomputed halo (evaluate_slab_staged): conv_averaging (iterated, even and odd
     kernels, nested under other modifications) and conv_edge_detection give, slab by slab, exactly the whole-grid
