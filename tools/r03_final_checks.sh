@@ -17,17 +17,17 @@ if [ "$part" = parity ] || [ "$part" = all ]; then
   timeout -k 10 600 python tests/report_gpu_parity.py > $O/r03_parity_report.txt 2>&1; echo "parity rc=$?"; tail -3 $O/r03_parity_report.txt
 fi
 if [ "$part" = fuzz1 ] || [ "$part" = all ]; then
-  run 400 python tests/fuzz_random_trees.py 21000 200 3
-  run 300 python tests/fuzz_random_trees.py 22000 80 4
+  run 400 python tests/fuzz_random_trees.py 41000 200 3
+  run 300 python tests/fuzz_random_trees.py 42000 80 4
   run 300 python tests/fuzz_row_layouts.py 200
-  run 400 python tests/fuzz_chain_select.py 23000 60
+  run 400 python tests/fuzz_chain_select.py 43000 80
 fi
 if [ "$part" = fuzz2 ] || [ "$part" = all ]; then
-  run 400 python tests/fuzz_prims.py gpu 24000 400
-  run 400 python tests/fuzz_mods.py gpu 25000 400
-  run 300 python tests/fuzz_staged.py 26000 40
-  run 300 python tests/fuzz_consumers.py 27000 200
-  run 400 python tests/fuzz_vector.py gpu 28000 300
-  run 300 python tests/fuzz_instancing.py 29000 60
+  run 400 python tests/fuzz_prims.py gpu 44000 400
+  run 400 python tests/fuzz_mods.py gpu 45000 400
+  run 300 python tests/fuzz_staged.py 46000 40
+  run 300 python tests/fuzz_consumers.py 47000 200
+  run 400 python tests/fuzz_vector.py gpu 48000 300
+  run 300 python tests/fuzz_instancing.py 49000 60
 fi
 echo "final checks $part done"
