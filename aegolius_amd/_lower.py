@@ -467,7 +467,7 @@ def _flatten_hard(kids, opcode, always=False):
     reaches the size of the chain kernels — 20 instances of a 50-sphere cluster become one 1000-member chain with
     per-brick survivor lists instead of a program beyond the specialisation limit."""
     from .cores.combine import BINARY_OPS, NARY_OPS
-    if os_environ_flag("SDFK_NO_FLATTEN"):
+    if _env_flag("SDFK_NO_FLATTEN"):
         return kids
     same = {k for k, v in list(NARY_OPS.items()) + list(BINARY_OPS.items()) if v == opcode}
 
@@ -522,7 +522,7 @@ def _subtracted_union(node):
     """node: the second operand of a SUBTRACT2. -> its members, re-framed and negated, when it is a hard UNION (bare, with
     at most a transform of its own) of at least as many members as the chain kernels take; else None."""
     from .cores.combine import BINARY_OPS, NARY_OPS
-    if os_environ_flag("SDFK_NO_FLATTEN") or not _is_geometry(node):
+    if _env_flag("SDFK_NO_FLATTEN") or not _is_geometry(node):
         return None
     inner = node.modified_object
     if not isinstance(inner, CombineSDF) or inner.parametric:
@@ -590,7 +590,7 @@ def _push_transform_into_members(node):
     when the rules of _flatten_hard do not apply or the combination is smaller than the chain kernels' minimum."""
     from ._mods import VALUE_OPS
     from .cores.combine import BINARY_OPS, NARY_OPS
-    if isinstance(node, _Reframed) or os_environ_flag("SDFK_NO_FLATTEN"):
+    if isinstance(node, _Reframed) or _env_flag("SDFK_NO_FLATTEN"):
         return None
     R = np.asarray(node.rotation_matrix, dtype=np.float64)
     t = np.asarray(node.center, dtype=np.float64).reshape(-1)
@@ -650,7 +650,8 @@ def _push_transform_into_members(node):
     return expr
 
 
-def os_environ_flag(name):
+def _env_flag(name):
+    """An experiment switch of the lowering (SDFK_NO_FLATTEN): set and not "0"."""
     import os
     return os.environ.get(name, "") not in ("", "0")
 
