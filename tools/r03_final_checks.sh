@@ -20,7 +20,7 @@ if [ "$part" = fuzz1 ] || [ "$part" = all ]; then
   run 400 python tests/fuzz_random_trees.py 41000 200 3
   run 300 python tests/fuzz_random_trees.py 42000 80 4
   run 300 python tests/fuzz_row_layouts.py 200
-  run 400 python tests/fuzz_chain_select.py 43000 80
+  run 1000 python tests/fuzz_chain_select.py 43000 70
 fi
 if [ "$part" = fuzz2 ] || [ "$part" = all ]; then
   run 400 python tests/fuzz_prims.py gpu 44000 400
