@@ -547,6 +547,23 @@ def _large_hard_union(node):
         return None
     op = getattr(inner.owner, "operation_type", None)
     opcode = NARY_OPS.get(op) or BINARY_OPS.get(op)
+    if opcode == "VSUBTRACT" and len(inner.children) == 2 and not _holds_combiner(inner.children[0]):
+        # a simple body minus a large union: the INTERSECT of the body and the negated members (see _lower_combine), here
+        # framed by the operand's own transform (a positive scale commutes with max and with the negation)
+        holes = _subtracted_union(inner.children[1])
+        s = node.scale
+        try:
+            ok = holes is not None and bool(np.isfinite(s)) and s > 0
+        except TypeError:
+            ok = False
+        if not ok:
+            return None
+        members = (inner.children[0],) + holes
+        R = np.asarray(node.rotation_matrix, dtype=np.float64)
+        t = np.asarray(node.center, dtype=np.float64).reshape(-1)
+        if not (R.shape == (3, 3) and np.array_equal(R, np.eye(3)) and s == 1 and t.size == 3 and not np.any(t)):
+            members = tuple(_Reframed(node, m) for m in members)
+        return "VMAX", members
     if opcode not in ("VMIN", "VMAX"):
         return None
     members = _flatten_hard((node,), opcode, always=True)

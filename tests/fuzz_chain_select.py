@@ -146,6 +146,20 @@ def main(first=9000, count=40):
         chain = prog.chain_members > 0
         chain_seen += chain
         msg = []
+        if not chain and low.code.shape[0] > 600:
+            # a large program that is no chain: its specialised kernels inline every member (minutes of hiprtc per flavour);
+            # AUTO mode serves it from the interpreter kernel — compared with the oracle only
+            out = device_eval(_engine, prog, co32, _engine.MODE_INTERPRET)
+            pick = rng.choice(n, size=min(n, 4000), replace=False)
+            with np.errstate(all="ignore"):
+                ref, mag = sdf_oracle.evaluate_with_magnitude(tree, co32[:, pick].astype(np.float64))
+            err = np.abs(out[pick].astype(np.float64) - ref) / np.maximum(np.maximum(1.0, np.abs(ref)), mag)
+            n_off = int((~(err <= 1e-6)).sum())
+            if n_off > max(1, int(0.005 * pick.size)):
+                bad.append((seed, ["%d of %d sampled points off the oracle (interpreter)" % (n_off, pick.size)]))
+            print("seed %d: %d children, NO chain, %d instr: interpreter only, max scaled err %.2e" % (
+                seed, children, low.code.shape[0], np.nanmax(err)), flush=True)
+            continue
         plain = device_eval(_engine, prog, co32, _engine.MODE_NOCULL)
         for hint, shift in ((row_len, 0), (row_len, 1), (None, 0)):   # row blocks (aligned / shifted pointers), line bricks or plain
             culled = device_eval(_engine, prog, co32, _engine.MODE_SPECIALIZED, row_len=hint, flat=flat and hint is not None, misalign=shift)
