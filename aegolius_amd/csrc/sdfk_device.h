@@ -100,7 +100,10 @@ SDFK_DEV V3P sd_join(V3 a, V3 b) { V3P r = {{a.x, b.x}, {a.y, b.y}, {a.z, b.z}};
 // (Round 3, measured on the modification-chain config at 1025^3, four variants in one process: a branch-free form of
 //  the fix-ups — sign folded in with xor, no scalar branch on d — has fewer instructions in the listing but executes
 //  more of them, 3.64 against 3.50 ms; sincos / atan2 on packed pairs (v_pk_fma for reduction and polynomials) 3.73 ms:
-//  the packed forms need their constants in SGPR pairs and cost 1.3 plain issues each. Both were removed again.)
+//  the packed forms need their constants in SGPR pairs and cost 1.3 plain issues each. Both were removed again. A native
+//  pair form of op_infrep — packed add / mul / fma, fix-ups as additions of d, -d or 0 — is bit-identical and exactly as
+//  fast as the pair wrapper around this scalar function, 3.45 vs 3.45 ms in alternation: the compiler pairs the two
+//  scalar calls by itself.)
 SDFK_DEV float sd_mod(float a, float d, float inv_d) {
     float q = __builtin_floorf(a * inv_d);
     float r = sd_fma(-q, d, a);
