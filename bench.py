@@ -441,6 +441,7 @@ def main():
     # field was never checked, or whose headline is missing, is a failed run).
     printed = threading.Event()
     extra = Extras(line)
+    state = {}                                                   # what the watchdog needs to know on every rank
 
     def emit():
         if rank == 0 and not printed.is_set():
@@ -456,8 +457,8 @@ def main():
         sys.stderr.write("[bench] rank %d: extras did not return within %.0f s (in flight: %s)\n"
                          % (rank, args.extras_timeout, extra.in_flight))
         sys.stderr.flush()
-        ok = "verified" in extra.seconds and isinstance(line.get("verified"), dict) and line["verified"].get("violations") == 0 \
-            and line.get("value") is not None
+        v = state.get("verified")                                # (every rank holds the all-reduced verdict; `line` is rank 0's)
+        ok = isinstance(v, dict) and v.get("violations") == 0 and "error" not in v
         os._exit(0 if ok else 3)
     timer = None
     if world > 1 and not args.no_extras:
@@ -474,7 +475,7 @@ def main():
             v["max_rel_err"], v["violations"] = float(t[0]), int(t[1])
             v["what"] += " (every rank samples its own slab; worst rank reported)"
         return v
-    extra("verified", verified)
+    state["verified"] = extra("verified", verified)
 
     if not args.no_extras:
         lib = _engine.lib()
