@@ -70,7 +70,7 @@ def chunk_bounds(count, chunks, unit=1):
 
 
 def evaluate_gathered_overlapped(evaluate_chunk, full, n_total, unit=1, chunks=4, group=None, schedule="direct",
-                                 chunk_unit=None, local=None):
+                                 chunk_unit=None, local=None, exercise_transport=False):
     """Evaluate this rank's slab and reassemble the field in `full` (an (n_total,) tensor on every rank) WHILE it is
     being computed.
 
@@ -92,7 +92,10 @@ def evaluate_gathered_overlapped(evaluate_chunk, full, n_total, unit=1, chunks=4
     same calls in program order; DEVICE tensors over gloo (several ranks rehearsing on one GPU: gloo's TCP transport
     reads host memory only — handing it device pointers is what stalled the round-2 rehearsal) are staged through host
     copies piece by piece, with the same control flow, streams and events around them.
-    Ranks are GROUP-local throughout (`group_peer` / `group_src`), so a sub-group works."""
+    Ranks are GROUP-local throughout (`group_peer` / `group_src`), so a sub-group works.
+    `exercise_transport` (tests): a world of ONE still issues its calls — the per-piece all-gather of "collective", a
+    send-to-self / receive-from-self batch for "direct" whose payload then overwrites the piece in the field — so that
+    the RCCL communicator, its stream and the event choreography run on a one-GPU box."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -129,7 +132,17 @@ def evaluate_gathered_overlapped(evaluate_chunk, full, n_total, unit=1, chunks=4
         if mine is not None:                                   # the rank's own piece into its place in the field
             o, c = mine
             full[start + o:start + o + c].copy_(local[o:o + c])
-        if world == 1:
+        if world == 1 and not exercise_transport:
+            return
+        if world == 1 and schedule == "direct":
+            if mine is not None:                               # the piece travels rank -> rank and lands in the field again
+                o, c = mine
+                back = torch.full((c,), float("nan"), dtype=full.dtype, device=full.device)
+                reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, local[o:o + c], group=group, group_peer=rank),
+                                               dist.P2POp(dist.irecv, back, group=group, group_peer=rank)])
+                for w in reqs:
+                    w.wait()
+                full[start + o:start + o + c].copy_(back)
             return
         if schedule == "direct":
             ops, landed = [], []

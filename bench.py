@@ -106,13 +106,24 @@ def cpu_baseline(workload, axes, budget_s):
         # (a ProcessPoolExecutor: a worker that cannot start raises BrokenProcessPool instead of being respawned for ever;
         #  spawn, not fork: this process holds a GPU)
         from concurrent.futures import ProcessPoolExecutor
-        with ProcessPoolExecutor(cores, mp_context=mp.get_context("spawn")) as pool:
+        pool = ProcessPoolExecutor(cores, mp_context=mp.get_context("spawn"))
+        try:
             warm = [(workload, planes[0], axes[1], axes[2])] * cores
             list(pool.map(_cpu_plane_worker, warm, timeout=120 + 20 * t1))                   # imports, tree: not timed
             t0 = time.perf_counter()
             busy = list(pool.map(_cpu_plane_worker, [(workload, x, axes[1], axes[2]) for x in planes], chunksize=1,
-                                 timeout=120 + 3 * budget_s))
+                                 timeout=60 + 3 * budget_s))
             wall = time.perf_counter() - t0
+            pool.shutdown(wait=True)
+        except BaseException:
+            # a worker that stalls must not hold this process in shutdown(wait=True): end the workers, then leave
+            for proc in list(getattr(pool, "_processes", {}).values()):
+                try:
+                    proc.kill()
+                except Exception:  # noqa: BLE001
+                    pass
+            pool.shutdown(wait=False, cancel_futures=True)
+            raise
     finally:
         for k, v in saved.items():
             if v is None:
@@ -169,7 +180,7 @@ print(json.dumps(dict(first_create_s=t1 - t0, second_create_s=t2 - t1, hiprtc_bu
 """
 
 
-def first_call_latency(workload):
+def first_call_latency(workload, budget_s=120.0):
     """Program creation -> first field, in fresh processes (no torch import), on the 129^3 grid through the drop-in
     API (`tree.create(co)` on a generate_grid array): cold with the disk cache off (AUTO: the interpreter kernel
     serves the call while hiprtc builds in the background), cold when the call has to wait for the specialised kernel
@@ -177,12 +188,18 @@ def first_call_latency(workload):
     import tempfile
     script = _FIRST_CALL.format(root=ROOT, workload=workload)
     out = {"grid": "129^3 via tree.create(generate_grid(...))"}
+    deadline = time.perf_counter() + budget_s                    # one budget for the four processes together
 
     def run(tag, **env):
         e = dict(os.environ)
         e.update(env)
+        left = deadline - time.perf_counter()
+        if left < 5.0:
+            out[tag] = {"skipped": "first_call budget of %.0f s spent" % budget_s}
+            return
         try:
-            res = subprocess.run([sys.executable, "-c", script], env=e, capture_output=True, text=True, timeout=300)
+            res = subprocess.run([sys.executable, "-c", script], env=e, capture_output=True, text=True,
+                                 timeout=min(60.0, left))
             out[tag] = json.loads(res.stdout.strip().splitlines()[-1])
         except Exception as exc:  # noqa: BLE001
             out[tag] = {"error": repr(exc)}
@@ -252,7 +269,7 @@ class Run:
 
 
 def reassembly_legs(torch, dist, sdist, local, n_total, start, count, row_len, evaluate_chunk, fence, red_dev,
-                    compute_s, chunks=8, chunk_rows=32):
+                    compute_s, chunks=8, chunk_rows=32, exercise_transport=False):
     """The three ways of putting the whole field on every rank, each warmed up once and timed once (MAX over ranks),
     never part of `value`: the plain all-gather after the evaluation and the two schedules of
     distributed.evaluate_gathered_overlapped, with a check that the rank's own slab arrived intact.
@@ -280,7 +297,8 @@ def reassembly_legs(torch, dist, sdist, local, n_total, start, count, row_len, e
         try:
             def once():
                 sdist.evaluate_gathered_overlapped(evaluate_chunk, full, n_total, unit=row_len, chunks=chunks,
-                                                   schedule=schedule, chunk_unit=chunk_rows * row_len, local=local)
+                                                   schedule=schedule, chunk_unit=chunk_rows * row_len, local=local,
+                                                   exercise_transport=exercise_transport)
             full.fill_(float("nan"))
             once()                                                    # warm-up
             fence()
@@ -309,6 +327,7 @@ class Extras:
 
     def __init__(self, line):
         self.line, self.in_flight, self.seconds = line, None, {}
+        self.lock = threading.Lock()          # `line` is written here and serialised by the watchdog thread
 
     def __call__(self, name, fn):
         self.in_flight = name
@@ -317,13 +336,19 @@ class Extras:
             val = fn()
         except Exception as exc:  # noqa: BLE001
             val = {"error": repr(exc)}
-        self.seconds[name] = round(time.perf_counter() - t0, 3)
-        self.in_flight = None
-        if self.line is not None:
-            if val is not None:
-                self.line[name] = val
-            self.line["extras_s"] = self.seconds
+        with self.lock:
+            self.seconds[name] = round(time.perf_counter() - t0, 3)
+            self.in_flight = None
+            if self.line is not None:
+                if val is not None:
+                    self.line[name] = val
+                self.line["extras_s"] = dict(self.seconds)
         return val
+
+    def snapshot(self):
+        """-> (JSON text of the line as it stands, name of the extra in flight): what the watchdog prints."""
+        with self.lock:
+            return (json.dumps(self.line) if self.line is not None else None), self.in_flight
 
 
 def main():
@@ -435,10 +460,12 @@ def main():
             "first_kernel_build_s": t_build,
         }
 
-    # N > 1: whatever happens in the collective extras, rank 0 prints the headline line and every rank leaves. The line says
-    # which extra was in flight (`extras_timeout`). Exit code: 0 only when the timed region's result stands on its own —
-    # the headline is in the line AND its `verified` sample came back clean before the stall; otherwise 3 (a run whose
-    # field was never checked, or whose headline is missing, is a failed run).
+    # Whatever happens in the extras, rank 0 prints the headline line and every rank leaves: a watchdog thread stays armed
+    # from here until the line has been printed (N > 1: `--extras-timeout` for the collective extras, re-armed for rank 0's
+    # solo extras; N = 1: one generous limit for everything). When it fires the line says which extra was in flight
+    # (`extras_timeout`) and the process exits NON-ZERO whatever the state of the headline — a rank may be holding a GPU
+    # with a collective in flight, and that must never read as a successful run: 3 when the headline is in the line and
+    # its `verified` sample had come back clean (the timed region's number stands on its own), 4 otherwise.
     printed = threading.Event()
     extra = Extras(line)
     state = {}                                                   # what the watchdog needs to know on every rank
@@ -448,23 +475,34 @@ def main():
             printed.set()
             print(json.dumps(line), flush=True)
 
-    def watchdog():
-        if rank == 0:
-            line["extras_timeout"] = {"in_flight": extra.in_flight, "after_s": args.extras_timeout,
-                                      "finished": dict(extra.seconds)}
-        emit()
-        sys.stdout.flush()
-        sys.stderr.write("[bench] rank %d: extras did not return within %.0f s (in flight: %s)\n"
-                         % (rank, args.extras_timeout, extra.in_flight))
-        sys.stderr.flush()
-        v = state.get("verified")                                # (every rank holds the all-reduced verdict; `line` is rank 0's)
-        ok = isinstance(v, dict) and v.get("violations") == 0 and "error" not in v
-        os._exit(0 if ok else 3)
+    def watchdog(limit_s):
+        code = 4
+        try:
+            v = state.get("verified")                            # (every rank holds the all-reduced verdict; `line` is rank 0's)
+            if isinstance(v, dict) and v.get("violations") == 0 and "error" not in v:
+                code = 3
+            if rank == 0 and not printed.is_set():
+                with extra.lock:
+                    line["extras_timeout"] = {"in_flight": extra.in_flight, "after_s": limit_s,
+                                              "finished": dict(extra.seconds), "exit_code": code}
+                text, _ = extra.snapshot()
+                printed.set()
+                print(text, flush=True)
+            sys.stderr.write("[bench] rank %d: extras did not return within %.0f s (in flight: %s); exit code %d\n"
+                             % (rank, limit_s, extra.in_flight, code))
+            sys.stderr.flush()
+        finally:
+            os._exit(code)                                       # always reached, whatever the serialisation did
+
+    def arm(limit_s):
+        # (ranks other than 0 fire 5 s later: the launcher ends every rank once one has left, and rank 0 prints first)
+        t = threading.Timer(limit_s + (0.0 if rank == 0 else 5.0), watchdog, args=(limit_s,))
+        t.daemon = True
+        t.start()
+        return t
     timer = None
-    if world > 1 and not args.no_extras:
-        timer = threading.Timer(args.extras_timeout, watchdog)
-        timer.daemon = True
-        timer.start()
+    if not args.no_extras or world > 1:
+        timer = arm(args.extras_timeout if world > 1 else max(args.extras_timeout, 900.0))
 
     # ---- the field the timed steps wrote, against the oracle (every rank checks its slab; rank 0 reports) ----
     def verified():
@@ -701,19 +739,25 @@ def main():
         extra("allgather", lambda: reassembly_legs(torch, dist, sdist, run.out[:count], n_total, start, count, row_len,
                                                    evaluate_chunk, run.fence, red_dev, elapsed / args.steps))
 
+    # ---- N > 1: the last collective is the closing barrier; the process group is taken down BEFORE rank 0's solo extras, so
+    # that no peer sits in an RCCL barrier (whose own watchdog would abort it, and torchrun rank 0 with it) while rank 0 times
+    # the CPU baseline. The watchdog stays armed over barrier and teardown.
+    if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+        dist.destroy_process_group()
     if timer is not None:
         timer.cancel()
     if rank == 0:
-        # rank 0 alone from here on (the other ranks wait in the closing barrier): no collectives below
+        # rank 0 alone from here on: no collectives below, every leg bounded by its own time-outs, and a watchdog of its own
+        # over the two of them (first_call <= 4 fresh processes, cpu_baseline ~ --cpu-seconds + imports)
+        solo = arm(240.0 + 4.0 * args.cpu_seconds)
         if not args.no_extras:
             extra("first_call", lambda: first_call_latency(args.workload))
         if args.cpu_seconds > 0:
             extra("cpu_baseline", lambda: cpu_baseline(args.workload, axes, args.cpu_seconds))
         emit()
-
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        solo.cancel()
 
 
 if __name__ == "__main__":

@@ -5,7 +5,7 @@
 set -u
 part=${1:-all}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; cd $R
-run () { echo "== $*" >> $O/r03_fuzz_raw.txt; timeout -k 10 "$1" "${@:2}" 2>&1 | grep -v amdgpu.ids | tail -4 >> $O/r03_fuzz_raw.txt; echo "rc=$?" >> $O/r03_fuzz_raw.txt; echo "done: ${*:2}"; }
+run () { echo "== $*" >> $O/r03_fuzz_raw.txt; timeout -k 10 "$1" "${@:2}" 2>&1 | grep -v amdgpu.ids | tail -4 >> $O/r03_fuzz_raw.txt; echo "rc=${PIPESTATUS[0]}" >> $O/r03_fuzz_raw.txt; echo "done: ${*:2}"; }
 if [ "$part" = rehearse ] || [ "$part" = all ]; then
   for n in 2 4; do
     SDFK_BENCH_REHEARSE=1 timeout -k 10 420 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 \

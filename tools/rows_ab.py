@@ -80,9 +80,16 @@ def main():
         if not any(k in defs for k in ("ABLATE_EVAL", "ABLATE_STORE", "ABLATE_EDGE", "ABLATE_BARRIER")):
             exact = bool(torch.equal(out[:n].view(torch.int32), ref[:n].view(torch.int32)) or
                          torch.equal(out[:n], ref[:n]))            # (flat grids: the sign of a zero may differ)
+        # >= 30 ms of warm-up, then >= args.reps launches and >= 60 ms of them (sub-millisecond kernels: the clocks settle)
+        w0, w1 = _engine.Event(), _engine.Event()
+        w0.record(stream)
         step()
+        w1.record(stream)
+        one = max(w0.elapsed_ms(w1), 1e-3)
+        for _ in range(int(min(200, 30.0 / one))):
+            step()
         times = []
-        for _ in range(args.reps):
+        for _ in range(int(max(args.reps, min(300, 60.0 / one)))):
             e0, e1 = _engine.Event(), _engine.Event()
             e0.record(stream)
             step()

@@ -1,0 +1,100 @@
+// Developer tool (GPU box): calibration of the VALU roof and of the SQ counters that DESIGN.md / tools/pmc_summarize.py
+// read it from. Kernels with a KNOWN number of independent VALU wave-instructions and nothing else, at 1 / 2 / 4 / 8
+// waves per SIMD, timed with HIP events; run it plain for the wall-clock rates and under
+//   rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv
+// for the counter readings of the same launches (kernel names carry KIND and waves per SIMD).
+//   hipcc -O3 --offload-arch=gfx950 tools/valu_calib.hip -o tools/bin/valu_calib
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define KEEP8(a, b, c, d, e, f, g, h) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h))
+#define UNROLL 8            // 8 groups of 8 instructions per trip
+// KIND: 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_sqrt_f32, 3 v_rcp_f32, 4 v_sin_f32, 5 v_max_f32, 6 v_cndmask (select), 7 mix 6 fma : 1 sqrt : 1 rcp
+template <int KIND, int WPS>
+__global__ __launch_bounds__(256) void calib(float* out, const float* __restrict__ prm, int trips) {
+    float x0 = threadIdx.x * 1e-3f + 1.f, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    f2 p0 = {x0, x1}, p1 = {x2, x3}, p2 = {x4, x5}, p3 = {x6, x7}, p4 = {x1, x0}, p5 = {x3, x2}, p6 = {x5, x4}, p7 = {x7, x6};
+    const float a = prm[0], b = prm[1];
+    f2 av = {x0 * 0 + a, x0 * 0 + a};
+    for (int i = 0; i < trips; ++i) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            if (KIND == 0) {
+                x0 = __builtin_fmaf(x0, a, b); x1 = __builtin_fmaf(x1, a, b); x2 = __builtin_fmaf(x2, a, b); x3 = __builtin_fmaf(x3, a, b);
+                x4 = __builtin_fmaf(x4, a, b); x5 = __builtin_fmaf(x5, a, b); x6 = __builtin_fmaf(x6, a, b); x7 = __builtin_fmaf(x7, a, b);
+                KEEP8(x0, x1, x2, x3, x4, x5, x6, x7);
+            } else if (KIND == 1) {
+                p0 = __builtin_elementwise_fma(p0, av, p1); p1 = __builtin_elementwise_fma(p1, av, p2);
+                p2 = __builtin_elementwise_fma(p2, av, p3); p3 = __builtin_elementwise_fma(p3, av, p4);
+                p4 = __builtin_elementwise_fma(p4, av, p5); p5 = __builtin_elementwise_fma(p5, av, p6);
+                p6 = __builtin_elementwise_fma(p6, av, p7); p7 = __builtin_elementwise_fma(p7, av, p0);
+                KEEP8(p0, p1, p2, p3, p4, p5, p6, p7);
+            } else if (KIND == 2) {
+                x0 = __builtin_amdgcn_sqrtf(x0); x1 = __builtin_amdgcn_sqrtf(x1); x2 = __builtin_amdgcn_sqrtf(x2); x3 = __builtin_amdgcn_sqrtf(x3);
+                x4 = __builtin_amdgcn_sqrtf(x4); x5 = __builtin_amdgcn_sqrtf(x5); x6 = __builtin_amdgcn_sqrtf(x6); x7 = __builtin_amdgcn_sqrtf(x7);
+                KEEP8(x0, x1, x2, x3, x4, x5, x6, x7);
+            } else if (KIND == 3) {
+                x0 = __builtin_amdgcn_rcpf(x0); x1 = __builtin_amdgcn_rcpf(x1); x2 = __builtin_amdgcn_rcpf(x2); x3 = __builtin_amdgcn_rcpf(x3);
+                x4 = __builtin_amdgcn_rcpf(x4); x5 = __builtin_amdgcn_rcpf(x5); x6 = __builtin_amdgcn_rcpf(x6); x7 = __builtin_amdgcn_rcpf(x7);
+                KEEP8(x0, x1, x2, x3, x4, x5, x6, x7);
+            } else if (KIND == 4) {
+                x0 = __builtin_amdgcn_sinf(x0); x1 = __builtin_amdgcn_sinf(x1); x2 = __builtin_amdgcn_sinf(x2); x3 = __builtin_amdgcn_sinf(x3);
+                x4 = __builtin_amdgcn_sinf(x4); x5 = __builtin_amdgcn_sinf(x5); x6 = __builtin_amdgcn_sinf(x6); x7 = __builtin_amdgcn_sinf(x7);
+                KEEP8(x0, x1, x2, x3, x4, x5, x6, x7);
+            } else if (KIND == 5) {
+                x0 = __builtin_fmaxf(x0, a); x1 = __builtin_fmaxf(x1, a); x2 = __builtin_fmaxf(x2, a); x3 = __builtin_fmaxf(x3, a);
+                x4 = __builtin_fmaxf(x4, a); x5 = __builtin_fmaxf(x5, a); x6 = __builtin_fmaxf(x6, a); x7 = __builtin_fmaxf(x7, a);
+                KEEP8(x0, x1, x2, x3, x4, x5, x6, x7);
+            } else if (KIND == 6) {
+                x0 = x0 > a ? x1 : b; x1 = x1 > a ? x2 : b; x2 = x2 > a ? x3 : b; x3 = x3 > a ? x4 : b;     // v_cmp + v_cndmask: 2 each
+                KEEP8(x0, x1, x2, x3, x4, x5, x6, x7);
+            } else {
+                x0 = __builtin_fmaf(x0, a, b); x1 = __builtin_fmaf(x1, a, b); x2 = __builtin_fmaf(x2, a, b); x3 = __builtin_fmaf(x3, a, b);
+                x4 = __builtin_fmaf(x4, a, b); x5 = __builtin_fmaf(x5, a, b); x6 = __builtin_amdgcn_sqrtf(x6); x7 = __builtin_amdgcn_rcpf(x7);
+                KEEP8(x0, x1, x2, x3, x4, x5, x6, x7);
+            }
+        }
+    }
+    float r = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y + p4.x + p4.y +
+              p5.x + p5.y + p6.x + p6.y + p7.x + p7.y;
+    if (r == 12345.678f) out[0] = r;
+}
+
+static float* g_out;
+static float* g_prm;
+
+template <int KIND, int WPS>
+void run(const char* name, int trips) {
+    const int blocks = 256 * WPS;          // one 4-wave workgroup per CU and per wave-per-SIMD step
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((calib<KIND, WPS>), dim3(blocks), dim3(256), 0, 0, g_out, g_prm, trips);
+    (void)hipEventRecord(e0);
+    const int reps = 5;
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL((calib<KIND, WPS>), dim3(blocks), dim3(256), 0, 0, g_out, g_prm, trips);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    const double per_wave = (double)trips * UNROLL * 8.0;
+    const double wave_instr = per_wave * 4.0 * blocks;                  // whole launch
+    const double per_simd = per_wave * WPS;                            // instructions one SIMD issues
+    // cycles at 2.4 GHz nominal; the real clock comes from GRBM_GUI_ACTIVE of the counter run
+    printf("{\"kind\": \"%s\", \"waves_per_simd\": %d, \"ms\": %.4f, \"wave_instructions\": %.0f, \"ns_per_instr_per_simd\": %.4f, "
+           "\"cycles_per_instr_at_2400MHz\": %.3f}\n", name, WPS, ms, wave_instr, ms * 1e6 / per_simd, ms * 1e6 / per_simd * 2.4);
+}
+
+template <int KIND>
+void sweep(const char* name, int trips) {
+    run<KIND, 1>(name, trips); run<KIND, 2>(name, trips); run<KIND, 4>(name, trips); run<KIND, 8>(name, trips);
+}
+
+int main(int argc, char** argv) {
+    int trips = argc > 1 ? atoi(argv[1]) : 4096;
+    (void)hipMalloc(&g_out, 4); (void)hipMalloc(&g_prm, 8);
+    float h[2] = {0.9999f, 1.0e-4f};
+    (void)hipMemcpy(g_prm, h, 8, hipMemcpyHostToDevice);
+    sweep<0>("v_fma_f32", trips); sweep<1>("v_pk_fma_f32", trips); sweep<2>("v_sqrt_f32", trips); sweep<3>("v_rcp_f32", trips);
+    sweep<4>("v_sin_f32", trips); sweep<5>("v_max_f32", trips); sweep<6>("v_cmp+v_cndmask x4", trips); sweep<7>("mix 6 fma 1 sqrt 1 rcp", trips);
+    return 0;
+}
