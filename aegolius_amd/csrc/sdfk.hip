@@ -34,7 +34,6 @@
 #include <dlfcn.h>
 #include <spawn.h>
 #include <sys/wait.h>
-#include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/time.h>
 #include <unistd.h>
@@ -579,14 +578,7 @@ static int tile_points() { return tile_waves() * tile_wbricks() * 128; }
 // union), whose whole-tree probe is better shared by 16 bricks per workgroup than by 8 (measured -11 %)
 // waves per workgroup of the row-block kernel: 2 — many small workgroups interleave their memory and VALU phases
 // best (north-star tree -0.5 %, 50-primitive flat union -10 % against 4 waves)
-static std::atomic<int> g_rwaves_override{0}, g_vtiles_override{0};
-// tiles of 1024 points one workgroup of the plain array kernel (sdfk_spec_v4) walks with the next tile's loads in flight
-// (sdfk_codegen.cpp, SDFK_VTILES); 1 = one tile per workgroup, no loop
-static int v4_tiles() {
-    static int v = [] { const char* e = getenv("SDFK_VTILES"); int t = e ? atoi(e) : 0; return (t >= 1 && t <= 4096) ? t : 1; }();
-    const int o = g_vtiles_override.load();
-    return o ? o : v;
-}
+static std::atomic<int> g_rwaves_override{0};
 static int rows_waves(const sdfk_program*) {
     if (const int o = g_rwaves_override.load()) return o;
     return 2;
@@ -779,7 +771,7 @@ static std::string g_rtc_defs = [] { const char* e = getenv("SDFK_RTC_DEFS"); re
 extern "C" void sdfk_debug_set_rtc_defs(const char* defs) {
     std::lock_guard<std::mutex> lk(g_defs_mu);
     std::string rest;
-    int tw = 0, rwb = 0, rwv = 0, vt = 0;
+    int tw = 0, rwb = 0, rwv = 0;
     const std::string all = defs ? defs : "";
     size_t pos = 0;
     while (pos < all.size()) {
@@ -789,14 +781,12 @@ extern "C" void sdfk_debug_set_rtc_defs(const char* defs) {
         if (tok.compare(0, 14, "-DSDFK_TWAVES=") == 0) tw = atoi(tok.c_str() + 14);
         else if (tok.compare(0, 16, "-DSDFK_RWBRICKS=") == 0) rwb = atoi(tok.c_str() + 16);
         else if (tok.compare(0, 14, "-DSDFK_RWAVES=") == 0) rwv = atoi(tok.c_str() + 14);
-        else if (tok.compare(0, 14, "-DSDFK_VTILES=") == 0) vt = atoi(tok.c_str() + 14);
         else if (!tok.empty()) rest += tok + " ";
         pos = sp + 1;
     }
     g_twaves_override = (tw >= 1 && tw <= 16) ? tw : 0;
     g_rwbricks_override = (rwb >= 1 && rwb <= 15) ? rwb : 0;
     g_rwaves_override = (rwv >= 1 && rwv <= 16) ? rwv : 0;
-    g_vtiles_override = (vt >= 1 && vt <= 4096) ? vt : 0;
     g_rtc_defs = rest;
 }
 // geo: bricks per wave | waves per workgroup << 4 of the row-block kernel (rows_geo)
@@ -810,8 +800,7 @@ static std::vector<std::string> rtc_options(int geo) {
                                   // instead of 490 KB, 10 s of compile instead of 15 s, 1.19 vs 1.22 ms at 16385^2
                                   "-fno-honor-nans", "-mno-amdgpu-ieee",
                                   "-DSDFK_TWAVES=" + std::to_string(tile_waves()), "-DSDFK_WBRICKS=" + std::to_string(tile_wbricks()),
-                                  "-DSDFK_RWBRICKS=" + std::to_string(rwb), "-DSDFK_RWAVES=" + std::to_string(rwaves),
-                                  "-DSDFK_VTILES=" + std::to_string(v4_tiles())};
+                                  "-DSDFK_RWBRICKS=" + std::to_string(rwb), "-DSDFK_RWAVES=" + std::to_string(rwaves)};
     std::string all;
     {
         std::lock_guard<std::mutex> lk(g_defs_mu);
@@ -1390,9 +1379,7 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
             if (n4) {
                 long long off = 0;
                 void* args[] = {&prm, &tab, &co, &stride, &off, &n4, &d_out, &aux, &aux_stride, &d_flags, &thr_key};
-                // (the field build walks v4_tiles() tiles per workgroup; the flag build has no loop)
-                const unsigned vt = d_flags ? 1u : (unsigned)v4_tiles();
-                HIPCHK(hipModuleLaunchKernel(sk->fn[0], (blocks_for(n4, 4) + vt - 1) / vt, 1, 1, SDFK_BLOCK, 1, 1, 0, stream, args,
+                HIPCHK(hipModuleLaunchKernel(sk->fn[0], blocks_for(n4, 4), 1, 1, SDFK_BLOCK, 1, 1, 0, stream, args,
                                              nullptr));
             }
             if (tail) {
@@ -1904,41 +1891,6 @@ static int eval_host_impl(sdfk_program* p, const void* co, int co_dtype, int64_t
         sl.pending_start = -1;
         return 0;
     };
-    // The caller's result array is usually fresh memory (numpy.empty: an anonymous mapping nothing has touched yet): its
-    // first-touch page faults — 4 KiB at a time inside the copy-out of every chunk — cost a third of the whole call in a
-    // plain process and more than half next to a HIP context with registered memory (measured, tools/host_path_ab.py:
-    // 47 -> 31 ms for 100 M points with a result array touched before, 64 -> 28 ms inside a process that has torch
-    // loaded). A helper thread therefore faults the array in AHEAD of the pipeline, huge pages where the kernel grants
-    // them, with an atomic OR of zero per page: a write access that cannot change a byte the copy-out has already stored.
-    std::vector<std::thread> prefault;
-    std::atomic<bool> prefault_stop{false};
-    if (!out_on_device && n >= ((int64_t)1 << 21)) {
-        const uintptr_t lo = reinterpret_cast<uintptr_t>(out), hi = lo + (uintptr_t)n * sizeof(float);
-        const uintptr_t huge = (uintptr_t)1 << 21;
-        const uintptr_t hlo = (lo + huge - 1) & ~(huge - 1), hhi = hi & ~(huge - 1);
-        if (hhi > hlo) (void)madvise(reinterpret_cast<void*>(hlo), hhi - hlo, MADV_HUGEPAGE);   // (refused: 4 KiB pages)
-        const int nt = std::max(1, std::min(4, host_threads() / 2));
-        for (int j = 0; j < nt; ++j)
-            prefault.emplace_back([lo, hi, huge, j, nt, &prefault_stop] {
-                // 2 MiB blocks dealt round-robin, so that the front of the array — what the pipeline needs first — advances
-                // at the rate of all helpers together
-                const uintptr_t first = lo & ~(huge - 1);
-                for (uintptr_t blk = first + (uintptr_t)j * huge; blk < hi; blk += (uintptr_t)nt * huge) {
-                    if (prefault_stop.load(std::memory_order_relaxed)) return;
-                    for (uintptr_t a = std::max(blk, (lo + 3) & ~(uintptr_t)3); a < std::min(blk + huge, hi); a = (a & ~(uintptr_t)4095) + 4096)
-                        __atomic_fetch_or(reinterpret_cast<unsigned*>(a), 0u, __ATOMIC_RELAXED);
-                }
-            });
-    }
-    struct PrefaultJoin {
-        std::vector<std::thread>& t;
-        std::atomic<bool>& stop;
-        ~PrefaultJoin() {
-            stop.store(true);
-            for (std::thread& x : t)
-                if (x.joinable()) x.join();
-        }
-    } prefault_join{prefault, prefault_stop};
     int k = 0;
     for (int64_t s = 0; s < n && rc == 0; s += chunk, ++k) {
         HostSlot& sl = st->slot[k & 1];

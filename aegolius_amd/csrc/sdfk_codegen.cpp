@@ -13,8 +13,6 @@
 std::string sdfk_vector_prelude() { return std::string(kEmbeddedDevice) + "\n" + kEmbeddedVecdev + "\n"; }
 
 static const char kWrappers[] = R"SDFKW(
-template <typename SRC> struct sdfk_src_is_array { static constexpr bool value = false; };
-template <> struct sdfk_src_is_array<SrcArray> { static constexpr bool value = true; };
 template <int VEC, typename SRC>
 static __device__ __forceinline__ void sdfk_body(const float* __restrict__ PRM, const float* __restrict__ TAB,
                                                  const SRC& src, long long off, long long n,
@@ -45,55 +43,6 @@ static __device__ __forceinline__ void sdfk_body(const float* __restrict__ PRM, 
         return;
     }
 #endif
-#if defined(SDFK_VTILES) && SDFK_VTILES > 1
-    // Software-pipelined form (arrays, 4 points per lane): a workgroup walks SDFK_VTILES tiles that lie one launch width
-    // apart, and the three coordinate loads of tile t + 1 are issued BEFORE tile t is evaluated — every resident wave has
-    // 3 KiB of loads in flight while it computes, so a VALU-heavy tree and its HBM stream overlap instead of taking
-    // turns (one-shot waves alternate "wait for 3 loads" and "600 instructions"; 8 waves per SIMD do not cover both).
-    // The host launches ceil(tiles / SDFK_VTILES) workgroups (sdfk.hip: v4_tiles()).
-    if constexpr (VEC == 4 && sdfk_src_is_array<SRC>::value) {
-        const long long ntiles = (n + (SDFK_BLOCK * 4 - 1)) / (SDFK_BLOCK * 4);
-        const long long nblk = (ntiles + SDFK_VTILES - 1) / SDFK_VTILES;
-        const float* __restrict__ cx = src.co + off + lane_off;
-        const float* __restrict__ cy = cx + src.stride;
-        const float* __restrict__ cz = cy + src.stride;
-        const long long step = nblk * (SDFK_BLOCK * 4);
-        // two register sets, A and B, used in turn (the loop body is written out twice): no copies between the sets, and
-        // every wait sits at the first use of a set, with the other set's loads and the last store still in flight
-        // (loads are UNCONDITIONAL — a lane without a point re-reads the array's last quad —: behind a branch the compiler
-        //  can no longer count what is in flight and waits for everything, the prefetch included, before each evaluation)
-        const long long safe = n - 4 - (long long)lane_off;
-        auto fetch = [&](long long b, bool a, float4& X, float4& Y, float4& Z) {
-            const long long bb = a ? b : safe;
-            X = sdfk_stream_load4(cx + bb); Y = sdfk_stream_load4(cy + bb); Z = sdfk_stream_load4(cz + bb);
-        };
-        auto eval = [&](long long b, bool a, const float4& X, const float4& Y, const float4& Z) {
-            if (a) {
-                const V3 p0 = {X.x, Y.x, Z.x}, p1 = {X.y, Y.y, Z.y}, p2 = {X.z, Y.z, Z.z}, p3 = {X.w, Y.w, Z.w};
-                const float* ax = aux + (off + b + lane_off);
-                const f2 ra = sdfk_point<f2>(sd_join(p0, p1), PRM, TAB, ax, aux_stride);
-                const f2 rb = sdfk_point<f2>(sd_join(p2, p3), PRM, TAB, ax + 2, aux_stride);
-                sdfk_stream_store4(out + off + b + lane_off, ra.x, ra.y, rb.x, rb.y);
-            }
-        };
-        float4 XA, YA, ZA, XB, YB, ZB;
-        long long bA = (long long)sdfk_bx() * (SDFK_BLOCK * 4), bB;
-        bool aA = bA + lane_off < n, aB;
-        fetch(bA, aA, XA, YA, ZA);
-#pragma unroll 1
-        for (int t = 0; t < SDFK_VTILES; t += 2) {
-            bB = bA + step;
-            aB = t + 1 < SDFK_VTILES && bB + lane_off < n;
-            fetch(bB, aB, XB, YB, ZB);
-            eval(bA, aA, XA, YA, ZA);
-            bA = bB + step;
-            aA = t + 2 < SDFK_VTILES && bA + lane_off < n;
-            fetch(bA, aA, XA, YA, ZA);
-            eval(bB, aB, XB, YB, ZB);
-        }
-        return;
-    }
-#endif
     if (block_base + lane_off >= n) return;
     V3 p[VEC];
     sdfk_load<VEC>(src, off + block_base, lane_off, p);
@@ -112,12 +61,7 @@ static __device__ __forceinline__ void sdfk_body(const float* __restrict__ PRM, 
 }
 )SDFKW";
 static const char kWrappersArray[] = R"SDFKW(
-#ifdef SDFK_V4_WPE
-#define SDFK_V4_ATTR __attribute__((amdgpu_waves_per_eu(SDFK_V4_WPE, SDFK_V4_WPE)))
-#else
-#define SDFK_V4_ATTR
-#endif
-extern "C" __global__ __launch_bounds__(SDFK_BLOCK) SDFK_V4_ATTR void sdfk_spec_v4(
+extern "C" __global__ __launch_bounds__(SDFK_BLOCK) void sdfk_spec_v4(
     const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
     long long off, long long n, float* __restrict__ out, const float* __restrict__ aux, long long aux_stride,
     unsigned* __restrict__ flags, unsigned thr) {
