@@ -1870,6 +1870,12 @@ static int eval_host_impl(sdfk_program* p, const void* co, int co_dtype, int64_t
     int64_t chunk = std::min<int64_t>(n, max_chunk);
     bool flat = false;
     int64_t plane_rows = 0;
+    // SDFK_HOST_TRACE=1: where the call's time goes (stderr, one line per call)
+    static const bool trace = [] { const char* e = getenv("SDFK_HOST_TRACE"); return e && e[0] == '1'; }();
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
+    const clk::time_point t_call = clk::now();
+    double t_stage_in = 0.0, t_wait = 0.0, t_copy_out = 0.0, t_enqueue = 0.0;
     const int64_t row_len = p->sites.empty() ? 0
                             : co_dtype == 0 ? detect_row_len(static_cast<const float*>(co), n, row_stride, &flat, &plane_rows)
                                             : detect_row_len(static_cast<const double*>(co), n, row_stride, &flat, &plane_rows);
@@ -1882,11 +1888,15 @@ static int eval_host_impl(sdfk_program* p, const void* co, int co_dtype, int64_t
     // the first call of a program builds its kernel: do that before anything is in flight (the build may take seconds)
     auto hand_over = [&](HostSlot& sl) -> int {             // wait for the slot's chunk and give its field to the caller
         if (sl.pending_start < 0) return 0;
+        clk::time_point t0 = clk::now();
         HIPCHK(hipEventSynchronize(sl.done));
+        t_wait += ms_since(t0);
         if (!out_on_device) {
+            t0 = clk::now();
             const float* src = sl.h_out;
             float* dst = out + sl.pending_start;
             parallel_ranges(sl.pending_count, [=](int64_t lo, int64_t hi) { memcpy(dst + lo, src + lo, (size_t)(hi - lo) * sizeof(float)); });
+            t_copy_out += ms_since(t0);
         }
         sl.pending_start = -1;
         return 0;
@@ -1898,6 +1908,7 @@ static int eval_host_impl(sdfk_program* p, const void* co, int co_dtype, int64_t
         if (rc) break;
         const int64_t m = std::min(chunk, n - s);
         float* h = sl.h_co;
+        const clk::time_point t_in = clk::now();
         if (co_dtype == 0) {
             const float* base = static_cast<const float*>(co) + s;
             parallel_ranges(m, [=](int64_t lo, int64_t hi) {
@@ -1913,6 +1924,8 @@ static int eval_host_impl(sdfk_program* p, const void* co, int co_dtype, int64_t
                 }
             });
         }
+        t_stage_in += ms_since(t_in);
+        const clk::time_point t_enq = clk::now();
         for (int r = 0; r < 3 && rc == 0; ++r)
             if (hipMemcpyAsync(sl.d_co + r * stride, h + r * stride, (size_t)m * sizeof(float), hipMemcpyHostToDevice, sl.stream) != hipSuccess)
                 rc = fail(-6, "sdfk_eval_host: host-to-device copy failed");
@@ -1932,6 +1945,7 @@ static int eval_host_impl(sdfk_program* p, const void* co, int co_dtype, int64_t
             sl.pending_start = s;
             sl.pending_count = m;
         }
+        t_enqueue += ms_since(t_enq);
     }
     for (HostSlot& sl : st->slot) {                         // drain (also on errors: nothing of this call stays in flight)
         if (rc == 0) rc = hand_over(sl);
@@ -1940,6 +1954,10 @@ static int eval_host_impl(sdfk_program* p, const void* co, int co_dtype, int64_t
             sl.pending_start = -1;
         }
     }
+    if (trace)
+        fprintf(stderr, "[sdfk host] %lld points, %d chunks of %lld: total %.2f ms = stage-in %.2f + enqueue %.2f + wait %.2f + copy-out %.2f (+ %.2f other)\n",
+                (long long)n, k, (long long)chunk, ms_since(t_call), t_stage_in, t_enqueue, t_wait, t_copy_out,
+                ms_since(t_call) - t_stage_in - t_enqueue - t_wait - t_copy_out);
     return rc;
 }
 

@@ -19,6 +19,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     planes = int(sys.argv[1]) if len(sys.argv) > 1 else 96
+    os.environ.setdefault("SDFK_HOST_TRACE", "1")             # one breakdown line per call on stderr
     import aegolius_amd.cores as ns
     from aegolius_amd import _engine, workloads
     from aegolius_amd._lower import lower_geometry
@@ -46,6 +47,17 @@ def main():
             tag, ts[0] * 1e3, ts[len(ts) // 2] * 1e3, m / ts[0] / 1e6, 16.0 * m / ts[0] / 1e9), flush=True)
 
     report("fresh", lambda: prog.eval_host(hco, mode=mode))
+    keep = []
+    report("keep", lambda: keep.append(prog.eval_host(hco, mode=mode)))       # the previous result is NOT unmapped inside the call
+    t0 = time.perf_counter()
+    keep.clear()
+    print("freeing 5 results: %.1f ms" % ((time.perf_counter() - t0) * 1e3), flush=True)
+
+    def alloc_touch_free():
+        a = np.empty(m, dtype=np.float32)
+        a[::1024] = 0.0
+        del a
+    report("alloc", alloc_touch_free)
     out = np.zeros(m, dtype=np.float32)
 
     def reuse():
@@ -64,6 +76,9 @@ def main():
         f64()
         ts.append(time.perf_counter() - t0)
     print("f64      min %.1f ms  %.0f Mpoints/s (half the points, result buffer reused)" % (min(ts) * 1e3, m / 2 / min(ts) / 1e6), flush=True)
+    print("-- one traced call each: fresh, reuse", flush=True)
+    prog.eval_host(hco, mode=mode)
+    reuse()
     import torch
     big = torch.empty(2 * 1024 ** 3, dtype=torch.float32, device="cuda")
     big.zero_()

@@ -49,10 +49,32 @@ __global__ __launch_bounds__(256) void calib(float* out, const float* __restrict
             } else if (KIND == 6) {
                 x0 = x0 > a ? x1 : b; x1 = x1 > a ? x2 : b; x2 = x2 > a ? x3 : b; x3 = x3 > a ? x4 : b;     // v_cmp + v_cndmask: 2 each
                 KEEP8(x0, x1, x2, x3, x4, x5, x6, x7);
-            } else {
+            } else if (KIND == 7) {
                 x0 = __builtin_fmaf(x0, a, b); x1 = __builtin_fmaf(x1, a, b); x2 = __builtin_fmaf(x2, a, b); x3 = __builtin_fmaf(x3, a, b);
                 x4 = __builtin_fmaf(x4, a, b); x5 = __builtin_fmaf(x5, a, b); x6 = __builtin_amdgcn_sqrtf(x6); x7 = __builtin_amdgcn_rcpf(x7);
                 KEEP8(x0, x1, x2, x3, x4, x5, x6, x7);
+            } else {
+                // exact instruction forms (inline asm), 8 independent chains
+#define A8(INS) asm volatile(INS(0) INS(1) INS(2) INS(3) INS(4) INS(5) INS(6) INS(7) \
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(av.x), "v"(av.y))
+#define I_ADD(k) "v_add_f32_e32 %" #k ", %8, %" #k "\n"
+#define I_MUL(k) "v_mul_f32_e32 %" #k ", %8, %" #k "\n"
+#define I_MOV(k) "v_mov_b32_e32 %" #k ", %8\n"
+#define I_AND(k) "v_and_b32_e32 %" #k ", %8, %" #k "\n"
+#define I_CND(k) "v_cndmask_b32_e32 %" #k ", %8, %" #k ", vcc\n"
+#define I_FMAC(k) "v_fmac_f32_e32 %" #k ", %8, %9\n"
+#define I_CMP(k) "v_cmp_gt_f32_e32 vcc, %8, %" #k "\n"
+#define I_MAX(k) "v_max_f32_e32 %" #k ", %8, %" #k "\n"
+#define I_XOR(k) "v_xor_b32_e32 %" #k ", %8, %" #k "\n"
+                if (KIND == 8) A8(I_ADD);
+                else if (KIND == 9) A8(I_MUL);
+                else if (KIND == 10) A8(I_MOV);
+                else if (KIND == 11) A8(I_AND);
+                else if (KIND == 12) A8(I_CND);
+                else if (KIND == 13) A8(I_FMAC);
+                else if (KIND == 14) A8(I_CMP);
+                else if (KIND == 15) A8(I_MAX);
+                else A8(I_XOR);
             }
         }
     }
@@ -96,5 +118,8 @@ int main(int argc, char** argv) {
     (void)hipMemcpy(g_prm, h, 8, hipMemcpyHostToDevice);
     sweep<0>("v_fma_f32", trips); sweep<1>("v_pk_fma_f32", trips); sweep<2>("v_sqrt_f32", trips); sweep<3>("v_rcp_f32", trips);
     sweep<4>("v_sin_f32", trips); sweep<5>("v_max_f32", trips); sweep<6>("v_cmp+v_cndmask x4", trips); sweep<7>("mix 6 fma 1 sqrt 1 rcp", trips);
+    sweep<8>("v_add_f32_e32", trips); sweep<9>("v_mul_f32_e32", trips); sweep<10>("v_mov_b32_e32", trips); sweep<11>("v_and_b32_e32", trips);
+    sweep<12>("v_cndmask_b32_e32", trips); sweep<13>("v_fmac_f32_e32", trips); sweep<14>("v_cmp_gt_f32_e32", trips); sweep<15>("v_max_f32_e32", trips);
+    sweep<16>("v_xor_b32_e32", trips);
     return 0;
 }
