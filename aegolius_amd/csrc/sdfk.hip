@@ -186,11 +186,19 @@ static int fail(int code, const std::string& msg) {
         }                                                                                         \
     } while (0)
 
+// candidate lists of one evaluation in flight (chain mode, csrc/sdfk_codegen.cpp "sdfk_spec_cells"): cell spheres, list
+// spans, the pool the lists are allocated from and its head — one set per STREAM, because calls on different streams
+// (the two slots of the host pipeline) run side by side on one program
+struct CellScratch {
+    char* buf = nullptr;
+    size_t bytes = 0;
+};
 struct DevState {
     uint2* d_code = nullptr;
     float* d_params = nullptr;
     float* d_tables = nullptr;
     unsigned long long params_version = 0;
+    std::map<hipStream_t, CellScratch> cells;
 };
 
 // One hiprtc translation unit = (program topology, kernel flavour, build options). The code object is built once
@@ -428,6 +436,8 @@ static void free_dev_state(sdfk_program* p) {
         if (kv.second.d_code) (void)hipFree(kv.second.d_code);
         if (kv.second.d_params) (void)hipFree(kv.second.d_params);
         if (kv.second.d_tables) (void)hipFree(kv.second.d_tables);
+        for (auto& cs : kv.second.cells)
+            if (cs.second.buf) (void)hipFree(cs.second.buf);
     }
     if (have) (void)hipSetDevice(cur);
     p->dev.clear();
@@ -609,7 +619,8 @@ struct RowGeom {           // mirrors sdfk_rowgeom of the generated source
 // plane_rows: rows per grid plane (0 / >= R: one plane — blocks of 16 consecutive rows throughout);
 // plane_phase: index within its plane of the first row. Both are layout hints like row_len: they only decide which
 // 16 rows form a block (a block of rows from two planes has a bounding sphere as wide as the grid and culls nothing).
-static bool rows_geometry(long long n, long long row_len, RowGeom* g, long long plane_rows = 0, long long plane_phase = 0) {
+static bool rows_geometry(long long n, long long row_len, RowGeom* g, long long plane_rows = 0, long long plane_phase = 0,
+                          bool planes_on = false) {
     if (row_len < 32 || row_len > 0x7fffffffLL || n <= 0 || n % row_len != 0) return false;
     const long long R = n / row_len, brows = 16;
     // windows of 32 points aligned in the flat array: one more than ceil(L / 32) can overlap a row
@@ -619,7 +630,7 @@ static bool rows_geometry(long long n, long long row_len, RowGeom* g, long long 
     // costs as much as the one straddling block it replaces saves (513^3: 0.413 vs 0.401 ms, 1025^3 equal) — so the hint
     // is honoured only on request (SDFK_PLANE_BLOCKS=1); the default is blocks of 16 consecutive rows throughout.
     static const bool plane_blocks = [] { const char* e = getenv("SDFK_PLANE_BLOCKS"); return e && e[0] == '1'; }();
-    if (!plane_blocks || prow <= 0 || prow >= R || prow > 0x7fffffffLL) {
+    if (!(plane_blocks || planes_on) || prow <= 0 || prow >= R || prow > 0x7fffffffLL) {
         prow = R > 0x7fffffffLL ? 0 : R;                       // one plane
         if (prow == 0) return false;
     } else if (plane_phase > 0) {
@@ -1196,6 +1207,14 @@ static std::shared_ptr<SpecModule> get_module(sdfk_program* p, int device, int f
         }
         for (int i = 0; i < 2 && he == hipSuccess; ++i)
             if (kFlavourFn[flavour][i]) he = hipModuleGetFunction(&m->fn[i], m->mod, kFlavourFn[flavour][i]);
+        if (he == hipSuccess && p->chain_mode && !kFlavourFn[flavour][1]) {
+            // chain-mode row-block kernels come with the pre-pass of their candidate lists (absent from -DSDFK_NO_CELLS builds)
+            const bool grid_fl = flavour == SDFK_FL_ROWS_GRID || flavour == SDFK_FL_ROWS2D_GRID;
+            if (hipModuleGetFunction(&m->fn[1], m->mod, grid_fl ? "sdfk_spec_cellsg" : "sdfk_spec_cells") != hipSuccess) {
+                m->fn[1] = nullptr;
+                (void)hipGetLastError();
+            }
+        }
         if (he == hipSuccess) break;
         // A code object that came from the on-disk cache and does not load (another driver / compiler generation, a
         // damaged file that still passed the checksum): delete the file, forget the blob and build from source once.
@@ -1261,6 +1280,119 @@ static inline unsigned blocks_for(long long n, int vec) {
     return (unsigned)((n + (long long)SDFK_BLOCK * vec - 1) / ((long long)SDFK_BLOCK * vec));
 }
 
+// ---- candidate lists of chain-mode programs (sdfk_codegen.cpp: sdfk_cells / sdfk_cellpass / sdfk_spec_cells) ------------------
+struct CellLevelH {           // mirrors sdfk_celllevel
+    unsigned lx, ly, lz, ncx, ncy, ncz, xoff, pad;
+};
+struct CellsArg {             // mirrors sdfk_cells
+    CellLevelH lv;
+    const void *sph, *span, *cand;
+    unsigned enabled, pad;
+};
+struct CellPassArg {          // mirrors sdfk_cellpass
+    CellLevelH lv, parent;
+    void *sph, *span;
+    const void *psph, *pspan;
+    void* cand;
+    unsigned* head;
+    unsigned cap, ncells;
+    float inflate, pad;
+};
+static bool parse3(const char* e, unsigned* v) {
+    int a = 0, b = 0, c = 0;
+    if (!e || sscanf(e, "%d,%d,%d", &a, &b, &c) != 3 || a < 0 || b < 0 || c < 0 || a > 12 || b > 12 || c > 12) return false;
+    v[0] = (unsigned)a; v[1] = (unsigned)b; v[2] = (unsigned)c;
+    return true;
+}
+static CellLevelH cell_level(const RowGeom& rg, const unsigned l[3]) {
+    CellLevelH lv{};
+    lv.lx = l[0]; lv.ly = l[1]; lv.lz = l[2];
+    const long long planes = rg.prow ? ((rg.R - rg.seg0) + rg.prow - 1) / rg.prow : 0;
+    lv.xoff = rg.seg0 > 0 ? (1u << lv.lx) : 0u;
+    lv.ncx = planes > 0 ? (unsigned)(((long long)lv.xoff + planes - 1) >> lv.lx) + 1u : 1u;
+    lv.ncy = ((std::max(rg.bpp, rg.nb0) - 1u) >> lv.ly) + 1u;
+    lv.ncz = ((rg.nchunk - 1u) >> lv.lz) + 1u;
+    return lv;
+}
+// Lists for this launch: sizes the levels, (re)allocates the stream's scratch, enqueues the pre-pass (coarse level, then
+// fine) on `stream` and fills what the row-block kernel is handed. cells_fn: sdfk_spec_cells / sdfk_spec_cellsg of the
+// module, `src`: its first kernel arguments after PRM / TAB (array: co, stride; grid: the SrcGrid), n_src of them.
+static int prepare_cells(sdfk_program* p, DevState* d, hipFunction_t cells_fn, const RowGeom& rg, void** src, int n_src,
+                         const float* prm, const float* tab, hipStream_t stream, CellsArg* out) {
+    memset(out, 0, sizeof *out);
+    static const int min_members = [] { const char* e = getenv("SDFK_CELLS_MIN"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 17; }();
+    static const bool off = [] { const char* e = getenv("SDFK_CELLS"); return e && e[0] == '0'; }();
+    if (!cells_fn || off || p->chain_members < min_members) return 0;
+    const bool is3d = rg.prow < (unsigned long long)rg.R;
+    unsigned lf[3] = {is3d ? 3u : 0u, is3d ? 1u : 2u, is3d ? 0u : 1u};            // 8 planes x 32 rows x 32 points | 64 rows x 64 points
+    unsigned lc[3] = {lf[0] + (is3d ? 2u : 0u), lf[1] + 2u, lf[2] + 2u};          // 4 x 4 x 4 (4 x 4) fine cells
+    static const char* e_fine = getenv("SDFK_CELL_FINE");
+    static const char* e_coarse = getenv("SDFK_CELL_COARSE");
+    (void)parse3(e_fine, lf);
+    bool coarse = p->chain_members >= 128;
+    if (e_coarse) coarse = parse3(e_coarse, lc);
+    if (coarse && (lc[0] < lf[0] || lc[1] < lf[1] || lc[2] < lf[2])) coarse = false;
+    const CellLevelH fine = cell_level(rg, lf);
+    const CellLevelH crs = coarse ? cell_level(rg, lc) : CellLevelH{};
+    const unsigned long long nf = (unsigned long long)fine.ncx * fine.ncy * fine.ncz;
+    const unsigned long long nc = coarse ? (unsigned long long)crs.ncx * crs.ncy * crs.ncz : 0ull;
+    if (nf == 0 || nf > 0x3fffffffull || nc > 0x3fffffffull) return 0;
+    // pool: room for 48 entries per fine cell and 1024 per coarse cell (measured lists: a handful / a few hundred); a cell
+    // that finds the pool full makes its bricks probe every member — slower, never wrong
+    const unsigned long long cap = std::min<unsigned long long>(0x7fffffffull, 48ull * nf + 1024ull * nc + 4ull * (unsigned)p->chain_members);
+    const size_t o_fsph = 0, o_fspan = o_fsph + 16 * nf, o_csph = o_fspan + 8 * nf, o_cspan = o_csph + 16 * nc,
+                 o_head = (o_cspan + 8 * nc + 15) & ~(size_t)15, o_pool = o_head + 16, total = o_pool + 2 * cap + 64;
+    CellScratch* cs;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        cs = &d->cells[stream];
+    }
+    if (cs->bytes < total) {
+        if (cs->buf) {
+            HIPCHK(hipStreamSynchronize(stream));              // (the stream's earlier launches read the old buffer)
+            (void)hipFree(cs->buf);
+            cs->buf = nullptr;
+            cs->bytes = 0;
+        }
+        if (hipMalloc(&cs->buf, total + total / 4) != hipSuccess) { (void)hipGetLastError(); return 0; }   // (no lists: still correct)
+        cs->bytes = total + total / 4;
+    }
+    char* b = cs->buf;
+    HIPCHK(hipMemsetAsync(b + o_head, 0, 16, stream));
+    CellPassArg cp{};
+    cp.cand = b + o_pool;
+    cp.head = reinterpret_cast<unsigned*>(b + o_head);
+    cp.cap = (unsigned)cap;
+    if (coarse) {
+        // a coarse cell answers for 1.3 x its circumsphere: room for the circumspheres of the fine cells inside it
+        cp.lv = crs; cp.parent = CellLevelH{}; cp.sph = b + o_csph; cp.span = b + o_cspan; cp.psph = nullptr; cp.pspan = nullptr;
+        cp.ncells = (unsigned)nc; cp.inflate = 1.3f;
+        std::vector<void*> args = {(void*)&prm, (void*)&tab};
+        for (int i = 0; i < n_src; ++i) args.push_back(src[i]);
+        RowGeom g2 = rg;
+        args.push_back(&g2);
+        args.push_back(&cp);
+        HIPCHK(hipModuleLaunchKernel(cells_fn, (unsigned)((nc + 3) / 4), 1, 1, 256, 1, 1, 0, stream, args.data(), nullptr));
+    }
+    cp.lv = fine; cp.parent = coarse ? crs : CellLevelH{}; cp.sph = b + o_fsph; cp.span = b + o_fspan;
+    cp.psph = coarse ? b + o_csph : nullptr; cp.pspan = coarse ? b + o_cspan : nullptr;
+    cp.ncells = (unsigned)nf; cp.inflate = 1.0f;
+    {
+        std::vector<void*> args = {(void*)&prm, (void*)&tab};
+        for (int i = 0; i < n_src; ++i) args.push_back(src[i]);
+        RowGeom g2 = rg;
+        args.push_back(&g2);
+        args.push_back(&cp);
+        HIPCHK(hipModuleLaunchKernel(cells_fn, (unsigned)((nf + 3) / 4), 1, 1, 256, 1, 1, 0, stream, args.data(), nullptr));
+    }
+    out->lv = fine;
+    out->sph = b + o_fsph;
+    out->span = b + o_fspan;
+    out->cand = b + o_pool;
+    out->enabled = 1u;
+    return 0;
+}
+
 // flat: the caller states that the rows of the array are rows of a flat grid (z = 0, rows along y); grids know it
 static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long long n, float* d_out, void* stream_,
                int mode, bool vec_ok, long long row_len = 0, const float* aux = nullptr, long long aux_stride = 0,
@@ -1302,12 +1434,13 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
     int flavour = arr ? SDFK_FL_PLAIN_ARRAY : SDFK_FL_PLAIN_GRID;
     const long long grow = grid ? (grid->n2 > 1 ? (long long)grid->n2 : (long long)grid->n1) : 0;
     if (!p->sites.empty() && mode != SDFK_MODE_NOCULL && mode != SDFK_MODE_INTERPRET) {
-        if (arr && rows_geometry(n, row_len, &rg, (flat || d_flags) ? 0 : plane_rows, plane_phase))
+        // (chain mode: row blocks of ONE plane each — the cells of its candidate lists are boxes of the grid)
+        if (arr && rows_geometry(n, row_len, &rg, (flat || d_flags) ? 0 : plane_rows, plane_phase, p->chain_mode))
             flavour = flat ? SDFK_FL_ROWS2D_ARRAY : SDFK_FL_ROWS_ARRAY;   // rows need no alignment beyond 4 bytes
         else if (arr && vec_ok && !p->chain_mode && !d_flags) flavour = SDFK_FL_TILE_ARRAY;
         else if (grid && grid->start % grow == 0 &&
                  rows_geometry(n, grow, &rg, (grid->n2 > 1 && !d_flags) ? (long long)grid->n1 : 0,    // (flags: the slot layout
-                               grid->n2 > 1 ? (grid->start / grow) % (long long)grid->n1 : 0))         //  knows blocks of 16 rows)
+                               grid->n2 > 1 ? (grid->start / grow) % (long long)grid->n1 : 0, p->chain_mode))   //  knows blocks of 16 rows)
             flavour = grid->n2 > 1 ? SDFK_FL_ROWS_GRID : SDFK_FL_ROWS2D_GRID;
         else if (grid && vec_ok && !p->chain_mode && !d_flags) flavour = SDFK_FL_TILE_GRID;
     }
@@ -1342,10 +1475,18 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
             const unsigned per_tile = (unsigned)(rows_waves(p) * rows_wbricks(p));
             const unsigned tiles = ((rg.nbricks + per_tile - 1) / per_tile + 127u) & ~127u;   // whole rounds of 8 XCDs x SDFK_XGROUP = 16 tiles (sdfk_codegen.cpp)
             const unsigned rthreads = 64u * (unsigned)rows_waves(p);
+            // (chain-mode builds take one more argument, their candidate lists: prepare_cells; fn[1] = the pre-pass kernel)
+            CellsArg cells{};
+            const bool with_cells = p->chain_mode && sk->fn[1] != nullptr;
             if (arr) {
                 const float* co = arr->co;
                 long long stride = arr->stride;
-                void* args[] = {&prm, &tab, &co, &stride, &rg, &d_out, &d_flags, &thr_key};
+                if (with_cells) {
+                    void* src[] = {&co, &stride};
+                    rc = prepare_cells(p, d, sk->fn[1], rg, src, 2, prm, tab, stream, &cells);
+                    if (rc) return rc;
+                }
+                void* args[] = {&prm, &tab, &co, &stride, &rg, &d_out, &d_flags, &thr_key, &cells};
                 HIPCHK(hipModuleLaunchKernel(sk->fn[0], tiles, 1, 1, rthreads, 1, 1, 0, stream, args, nullptr));
             } else {
                 // whole grid rows (x-slabs of a sharded evaluation always are); rows along the third axis, or along
@@ -1353,7 +1494,12 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
                 SrcGrid g = *grid;
                 rg.row0 = grid->start / grow;
                 rg.yrows = grid->n2 > 1 ? 0 : 1;
-                void* args[] = {&prm, &tab, &g, &rg, &d_out, &d_flags, &thr_key};
+                if (with_cells) {
+                    void* src[] = {&g};
+                    rc = prepare_cells(p, d, sk->fn[1], rg, src, 1, prm, tab, stream, &cells);
+                    if (rc) return rc;
+                }
+                void* args[] = {&prm, &tab, &g, &rg, &d_out, &d_flags, &thr_key, &cells};
                 HIPCHK(hipModuleLaunchKernel(sk->fn[0], tiles, 1, 1, rthreads, 1, 1, 0, stream, args, nullptr));
             }
             return 0;

@@ -443,18 +443,29 @@ static_assert(SDFK_RNBRICK <= 64 * SDFK_RWAVES, "one probe lane per brick");
 
 typedef float sdfk_f4u __attribute__((ext_vector_type(4), aligned(4)));
 
+#ifdef SDFK_CELLS
+#ifndef SDFK_ALIST_CAP
+#define SDFK_ALIST_CAP (SDFK_NLEAF < 128 ? SDFK_NLEAF : 128)     // survivors a brick's list holds (more: nalive = ALL)
+#endif
+#define SDFK_ALL_ALIVE 0xffffffffu
+#endif
 struct sdfk_rowmeta {
     float z[SDFK_RNBRICK][SDFK_RBRICK];         // [row of the brick][point of the window]
     float2 xy[SDFK_RNBRICK][SDFK_RROWS];
     float4 bound[SDFK_RNBRICK];
     unsigned long long mask0[SDFK_RNBRICK], mask1[SDFK_RNBRICK];
     unsigned uniform[SDFK_RNBRICK];
-#ifdef SDFK_SIMT
+#if defined(SDFK_SIMT) && !defined(SDFK_CELLS)
     float4 cen[SDFK_NCEN];                      // probe centres (x, y, z, radius): SDFK_NSUB per brick
     float leafval[SDFK_NLEAF * SDFK_NCEN];      // [leaf][centre]: every leaf of the tree at every centre
 #endif
 #ifdef SDFK_CHAIN
+#ifdef SDFK_CELLS
+    unsigned short alist[SDFK_RNBRICK][SDFK_ALIST_CAP];                // the children that run, in order (more: nalive = ALL)
+    unsigned inside[SDFK_RNBRICK];                                     // every point of the brick lies in its cell's sphere
+#else
     unsigned short alist[SDFK_RNBRICK][SDFK_NLEAF];                    // the children that run, in order
+#endif
     unsigned nalive[SDFK_RNBRICK];
 #if SDFK_CHAIN_STAGED
     float cprm[SDFK_RNBRICK][SDFK_CHUNK][SDFK_NPLMAX];                  // parameters of the chunk of children being evaluated
@@ -474,6 +485,29 @@ struct sdfk_rowgeom {
                                                 // bpp blocks per plane: a block never holds rows of two planes
     unsigned inv_nchunk, inv_bpp;               // floor(2^32 / nchunk), floor(2^32 / bpp): divisions as one v_mul_hi
 };
+#ifdef SDFK_CELLS
+// Candidate lists (chain mode). The bricks are grouped into CELLS in index space — 2^lx plane slots x 2^ly row blocks x
+// 2^lz windows — and a pre-pass (sdfk_spec_cells) leaves per cell a bounding sphere, derived from the coordinates of the
+// cell's eight corner points, and the LIST of members that can be the minimum somewhere in that sphere (the global-minimum
+// rule of sdfk_chain_fold at the cell's radius; cells of a coarser level first, so that a fine cell only looks at its
+// parent's list). A brick then probes the members on its cell's list instead of all of them — after checking, point by
+// point, that it really lies inside the sphere: the corner points bound the cell only if the array is the lattice its
+// layout hints say it is, and a brick that fails the check (or whose cell ran out of list space) probes every member,
+// as before. Whatever the input, a member that is dropped cannot be the minimum at any point of the brick.
+struct sdfk_celllevel {
+    unsigned lx, ly, lz;                        // log2 of the cell size in plane slots, row blocks, windows
+    unsigned ncx, ncy, ncz;                     // cells along each of them
+    unsigned xoff;                              // slot number of the first whole plane (2^lx when a partial plane leads, else 0)
+    unsigned pad;
+};
+struct sdfk_cells {
+    sdfk_celllevel lv;                          // the level the bricks look at (the finest)
+    const float4* __restrict__ sph;             // per cell: centre, radius (< 0: no such cell)
+    const uint2* __restrict__ span;             // per cell: first entry, entries (SDFK_ALL_ALIVE: no list — probe every member)
+    const unsigned short* __restrict__ cand;    // the lists
+    unsigned enabled, pad;
+};
+#endif
 // a / d for wave-uniform a, with inv = floor(2^32 / d) from the host: the estimate is never too large and at most a few
 // units too small (a * (2^32 - inv * d) < 2^32 * d for every brick count the host accepts), the loop repairs it.
 // (A plain 32-bit division is ~35 vector instructions; this kernel has two per brick.)
@@ -483,16 +517,21 @@ static __device__ __forceinline__ unsigned sdfk_udiv(unsigned a, unsigned d, uns
     return __builtin_amdgcn_readfirstlane(q);
 }
 // rows [r0, rend) of row block rb (wave-uniform): 16 consecutive rows of ONE plane, fewer at the end of a plane
-static __device__ __forceinline__ void sdfk_block_rows(const sdfk_rowgeom& g, unsigned rb, long long& r0, long long& rend) {
+// (slot, blk: plane slot — 0 = the leading partial plane, whole planes from 0 as well; the caller adds its offset — and the
+//  block's index within it)
+static __device__ __forceinline__ void sdfk_block_rows(const sdfk_rowgeom& g, unsigned rb, long long& r0, long long& rend,
+                                                       unsigned* slot = nullptr, unsigned* blk = nullptr) {
     if (rb < g.nb0) {
         r0 = (long long)rb * SDFK_RROWS;
         rend = g.seg0;
+        if (slot) { *slot = 0xffffffffu; *blk = rb; }
     } else {
         const unsigned k = rb - g.nb0;
         const unsigned pl = sdfk_udiv(k, g.bpp, g.inv_bpp);
         const long long base = (long long)g.seg0 + (long long)pl * g.prow;
         r0 = base + (long long)(k - pl * g.bpp) * SDFK_RROWS;
         rend = base + g.prow < g.R ? base + g.prow : g.R;
+        if (slot) { *slot = pl; *blk = k - pl * g.bpp; }
     }
 }
 
@@ -579,12 +618,22 @@ static __device__ __forceinline__ void sdfk_rows_load(const SRC& s, const sdfk_r
     }
 }
 // phase A, part 2: z and the row heads to LDS, "every row has one x and one y", bounding sphere
-static __device__ __forceinline__ void sdfk_rows_bounds(const sdfk_rowregs& r, int lane, sdfk_rowmeta* meta, int b) {
+// (SDFK_CELLS: S = sphere of the brick's cell, with y and z swapped for SDFK_FLAT like the registers; the brick also learns
+//  whether every one of its points lies inside it)
+#ifdef SDFK_CELLS
+#define SDFK_CELL_ARG , float4 S
+#else
+#define SDFK_CELL_ARG
+#endif
+static __device__ __forceinline__ void sdfk_rows_bounds(const sdfk_rowregs& r, int lane, sdfk_rowmeta* meta, int b SDFK_CELL_ARG) {
 #ifdef SDFK_ABLATE_BOUNDS
     *reinterpret_cast<float4*>(&meta->z[b][(lane >> 3) * SDFK_RZ + 4 * (lane & 7)]) = r.Z[0];
     if (SDFK_RLOADS > 1) *reinterpret_cast<float4*>(&meta->z[b][(8 + (lane >> 3)) * SDFK_RZ + 4 * (lane & 7)]) = r.Z[SDFK_RLOADS - 1];
     if ((lane & 7) == 0) { meta->xy[b][lane >> 3] = make_float2(r.X[0].x, r.Y[0].x); meta->xy[b][SDFK_RROWS - 8 + (lane >> 3)] = make_float2(r.X[SDFK_RLOADS - 1].x, r.Y[SDFK_RLOADS - 1].x); }
     if (lane == 0) { meta->bound[b] = make_float4(0.f, 0.f, 0.f, 1.f); meta->uniform[b] = 1u; }
+#ifdef SDFK_CELLS
+    if (lane == 0) meta->inside[b] = S.w > 0.0f ? 1u : 0u;
+#endif
     return;
 #endif
     bool uni = true;
@@ -617,6 +666,9 @@ static __device__ __forceinline__ void sdfk_rows_bounds(const sdfk_rowregs& r, i
     const float cy = 0.5f * (sdfk_lane(r.Y[0].x, 0) + sdfk_lane(r.Y[SDFK_RLOADS - 1].w, 63));
     const float cz = 0.5f * (sdfk_lane(r.Z[0].x, 0) + sdfk_lane(r.Z[SDFK_RLOADS - 1].w, 63));
     float d2 = 0.0f;
+#ifdef SDFK_CELLS
+    float d2s = 0.0f;                                // the same maximum about the CELL's centre
+#endif
     if (uniform) {                                   // one x, y per row segment: |p - c|^2 = dxy^2 + max |z - cz|^2
 #pragma unroll
         for (int t = 0; t < SDFK_RLOADS; ++t) {
@@ -624,6 +676,12 @@ static __device__ __forceinline__ void sdfk_rows_bounds(const sdfk_rowregs& r, i
             const float zm = sd_rawmax(sd_rawmax(sd_abs(r.Z[t].x - cz), sd_abs(r.Z[t].y - cz)),
                                        sd_rawmax(sd_abs(r.Z[t].z - cz), sd_abs(r.Z[t].w - cz)));
             d2 = sd_rawmax(d2, sd_fma(zm, zm, sd_fma(dx, dx, dy * dy)));
+#ifdef SDFK_CELLS
+            const float ex = r.X[t].x - S.x, ey = r.Y[t].x - S.y;
+            const float em = sd_rawmax(sd_rawmax(sd_abs(r.Z[t].x - S.z), sd_abs(r.Z[t].y - S.z)),
+                                       sd_rawmax(sd_abs(r.Z[t].z - S.z), sd_abs(r.Z[t].w - S.z)));
+            d2s = sd_rawmax(d2s, sd_fma(em, em, sd_fma(ex, ex, ey * ey)));
+#endif
         }
     } else {
 #pragma unroll
@@ -633,9 +691,19 @@ static __device__ __forceinline__ void sdfk_rows_bounds(const sdfk_rowregs& r, i
             const f2 ax = xa - cx, ay = ya - cy, az = za - cz, bx = xb - cx, by = yb - cy, bz = zb - cz;
             const f2 da = sd_fma(ax, ax, sd_fma(ay, ay, az * az)), db = sd_fma(bx, bx, sd_fma(by, by, bz * bz));
             d2 = sd_rawmax(d2, sd_rawmax(sd_rawmax(da.x, da.y), sd_rawmax(db.x, db.y)));
+#ifdef SDFK_CELLS
+            const f2 ex = xa - S.x, ey = ya - S.y, ez = za - S.z, fx = xb - S.x, fy = yb - S.y, fz = zb - S.z;
+            const f2 ea = sd_fma(ex, ex, sd_fma(ey, ey, ez * ez)), eb = sd_fma(fx, fx, sd_fma(fy, fy, fz * fz));
+            d2s = sd_rawmax(d2s, sd_rawmax(sd_rawmax(ea.x, ea.y), sd_rawmax(eb.x, eb.y)));
+#endif
         }
     }
     const float r2 = sdfk_wave_max(d2);
+#ifdef SDFK_CELLS
+    // inside: max |p - S| <= radius of S, with room for the rounding of the distances (relative 1e-5; S.w < 0: no cell)
+    const float rs2 = sdfk_wave_max(d2s);
+    if (lane == 0) meta->inside[b] = (S.w > 0.0f && 1.00002f * sqrtf(rs2) <= S.w) ? 1u : 0u;
+#endif
     if (lane == 0) {
 #ifdef SDFK_FLAT
         meta->bound[b] = make_float4(cx, cz, cy, 1.00001f * sqrtf(r2) + 1e-30f);
@@ -698,7 +766,7 @@ static __device__ __forceinline__ float4 sdfk_sub_centre(const sdfk_rowmeta* met
 }
 #endif
 
-#ifdef SDFK_CHAIN
+#if defined(SDFK_CHAIN) && !defined(SDFK_CELLS)
 // Chain mode, one WAVE per brick: which children run on this brick, from the leaf values at its centre. A hard min (max:
 // signs flipped, e_k = +-d_k) is exact, associative and commutative, so the ORDER of the chain does not matter for a
 // decision: child k can be dropped wherever some other child j stays below it on the whole brick, and with j = the child
@@ -735,11 +803,90 @@ static __device__ __forceinline__ void sdfk_chain_fold(sdfk_rowmeta* meta, int b
 }
 #endif
 
+#ifdef SDFK_CELLS
+// rows of row block rb plus the cell of brick (rb, window c) and that cell's sphere (wave-uniform; scalar loads)
+static __device__ __forceinline__ void sdfk_brick_cell(const sdfk_rowgeom& g, const sdfk_cells& cl, unsigned rb, unsigned c,
+                                                       long long& r0, long long& rend, unsigned& cell, float4& S) {
+    unsigned slot, blk;
+    sdfk_block_rows(g, rb, r0, rend, &slot, &blk);
+    const unsigned sx = slot == 0xffffffffu ? 0u : cl.lv.xoff + slot;
+    cell = ((sx >> cl.lv.lx) * cl.lv.ncy + (blk >> cl.lv.ly)) * cl.lv.ncz + (c >> cl.lv.lz);
+    S = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+    if (cl.enabled) {
+        const float4 t = cl.sph[cell];
+#ifdef SDFK_FLAT
+        S = make_float4(t.x, t.z, t.y, t.w);                   // (the registers of phase A hold (x, z, y))
+#else
+        S = t;
+#endif
+    }
+}
+#endif
+#if defined(SDFK_CHAIN) && defined(SDFK_CELLS)
+// The same decision from the CELL's candidate list: one member per lane, evaluated at the brick's centre on the spot (no
+// table of leaf values in LDS) — the first 64 stay in a register, longer lists are evaluated a second time for the
+// comparison. A brick that is not inside its cell's sphere, or whose cell has no list, takes every member.
+static __device__ __forceinline__ void sdfk_chain_fold_cells(sdfk_rowmeta* meta, int b, int lane, const sdfk_cells& cl, unsigned cell,
+                                                             const float* __restrict__ PRM, const float* __restrict__ TAB) {
+    const float4 cc = meta->bound[b];
+    const V3T<float> ctr = {cc.x, cc.y, cc.z};
+    const float rho = cc.w, cmag = 1e-6f * (fabsf(cc.x) + fabsf(cc.y) + fabsf(cc.z) + rho);
+    unsigned off = 0u, cnt = SDFK_NLEAF;
+    bool listed = false;
+    if (cl.enabled && __builtin_amdgcn_readfirstlane(meta->inside[b]) != 0u) {
+        const uint2 sp = cl.span[cell];
+        const unsigned s0 = __builtin_amdgcn_readfirstlane(sp.x), s1 = __builtin_amdgcn_readfirstlane(sp.y);
+        if (s1 != SDFK_ALL_ALIVE) { off = s0; cnt = s1; listed = true; }
+    }
+    float m = 3.0e38f, e0 = 3.0e38f;
+    unsigned k0 = 0u;
+#pragma unroll 1
+    for (unsigned j0 = 0u; j0 < cnt; j0 += 64u) {
+        const unsigned j = j0 + (unsigned)lane;
+        const bool in = j < cnt;
+        const unsigned k = in ? (listed ? (unsigned)cl.cand[off + j] : j) : 0u;
+        float e = 3.0e38f;
+        if (in) e = SDFK_CHAIN_SGN * sdfk_leaf<float>(k, ctr, PRM, TAB);
+        if (j0 == 0u) { e0 = e; k0 = k; }
+        m = fminf(m, e);
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) m = fminf(m, __shfl_xor(m, o));
+    const float thr0 = 1.0001f * SDFK_CHAIN_KMAX * rho + SDFK_CHAIN_KMAX * cmag + 1e-6f * (1.0f + fabsf(m));
+    unsigned n_out = 0u;
+#pragma unroll 1
+    for (unsigned j0 = 0u; j0 < cnt; j0 += 64u) {
+        const unsigned j = j0 + (unsigned)lane;
+        const bool in = j < cnt;
+        unsigned k = k0;
+        float e = e0;
+        if (j0 != 0u) {
+            k = in ? (listed ? (unsigned)cl.cand[off + j] : j) : 0u;
+            e = 3.0e38f;
+            if (in) e = SDFK_CHAIN_SGN * sdfk_leaf<float>(k, ctr, PRM, TAB);
+        }
+        const bool run = in && !(e - m >= thr0 + 1e-6f * fabsf(e));
+        const unsigned long long bits = __ballot(run);
+        const unsigned pos = n_out + (unsigned)__builtin_popcountll(bits & ((1ull << lane) - 1ull));
+        if (run && pos < SDFK_ALIST_CAP) meta->alist[b][pos] = (unsigned short)k;
+        n_out += (unsigned)__builtin_popcountll(bits);
+    }
+    if (lane == 0) meta->nalive[b] = n_out <= SDFK_ALIST_CAP ? n_out : SDFK_ALL_ALIVE;
+}
+#endif
+
 // phases A and B of the tile of this workgroup; returns this wave's first brick (row block, window)
+#ifdef SDFK_CELLS
+#define SDFK_CELLS_PARAM , const sdfk_cells& cl
+#define SDFK_CELLS_PASS , cl
+#else
+#define SDFK_CELLS_PARAM
+#define SDFK_CELLS_PASS
+#endif
 template <typename SRC>
 static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict__ PRM, const float* __restrict__ TAB,
                                                          const SRC& s, const sdfk_rowgeom& g, sdfk_rowmeta* meta,
-                                                         unsigned tile, unsigned& rb0, unsigned& c0) {
+                                                         unsigned tile, unsigned& rb0, unsigned& c0 SDFK_CELLS_PARAM) {
     const int lane = sdfk_tx() & 63, wave = __builtin_amdgcn_readfirstlane(sdfk_tx() >> 6);
     const unsigned q0 = tile * SDFK_RNBRICK + wave * SDFK_RWBRICKS;            // first brick of this wave
     rb0 = sdfk_udiv(q0, g.nchunk, g.inv_nchunk);                // (back in an SGPR: what is derived from it stays scalar)
@@ -750,23 +897,45 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
     // two-wave workgroups on the north-star grid; with four bricks per wave the registers this takes cost more)
     sdfk_rowregs hregs[SDFK_RWBRICKS];
     bool live[SDFK_RWBRICKS];
+#ifdef SDFK_CELLS
+    unsigned cellid[SDFK_RWBRICKS];
+    float4 csph[SDFK_RWBRICKS];
+#endif
 #pragma unroll
     for (int j = 0; j < SDFK_RWBRICKS; ++j) {
         long long r0, rend;
+#ifdef SDFK_CELLS
+        sdfk_brick_cell(g, cl, rb, c, r0, rend, cellid[j], csph[j]);
+#else
         sdfk_block_rows(g, rb, r0, rend);
+#endif
         live[j] = q0 + j < g.nbricks && r0 < rend;               // (blocks of the last plane beyond the slab: nothing)
         if (live[j]) sdfk_rows_load(s, g, r0, rend, c, lane, hregs[j]);
         if (++c == g.nchunk) { c = 0; ++rb; }
     }
 #pragma unroll
     for (int j = 0; j < SDFK_RWBRICKS; ++j)
+#ifdef SDFK_CELLS
+        if (live[j]) sdfk_rows_bounds(hregs[j], lane, meta, wave * SDFK_RWBRICKS + j, csph[j]);
+#else
         if (live[j]) sdfk_rows_bounds(hregs[j], lane, meta, wave * SDFK_RWBRICKS + j);
+#endif
         else if (lane == 0) { meta->bound[wave * SDFK_RWBRICKS + j] = make_float4(0.0f, 0.0f, 0.0f, 1.0f); meta->uniform[wave * SDFK_RWBRICKS + j] = 0u; }   // (masks: never read)
 #else
+#ifdef SDFK_CELLS
+    bool live[SDFK_RWBRICKS];
+    unsigned cellid[SDFK_RWBRICKS];
+#endif
 #pragma unroll
     for (int j = 0; j < SDFK_RWBRICKS; ++j) {
         long long r0, rend;
+#ifdef SDFK_CELLS
+        float4 csph;
+        sdfk_brick_cell(g, cl, rb, c, r0, rend, cellid[j], csph);
+        live[j] = q0 + j < g.nbricks && r0 < rend;
+#else
         sdfk_block_rows(g, rb, r0, rend);
+#endif
 #ifdef SDFK_ABLATE_EDGE
         if (q0 + j < g.nbricks && r0 < rend && sdfk_interior(g.L, c)) {
 #else
@@ -774,7 +943,11 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
 #endif
             sdfk_rowregs regs;
             sdfk_rows_load(s, g, r0, rend, c, lane, regs);
+#ifdef SDFK_CELLS
+            sdfk_rows_bounds(regs, lane, meta, wave * SDFK_RWBRICKS + j, csph);
+#else
             sdfk_rows_bounds(regs, lane, meta, wave * SDFK_RWBRICKS + j);
+#endif
         } else if (lane == 0) {                                   // a dead brick still meets a probe lane: harmless values
             meta->bound[wave * SDFK_RWBRICKS + j] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
             meta->uniform[wave * SDFK_RWBRICKS + j] = 0u;
@@ -783,7 +956,23 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
     }
 #endif
     __syncthreads();
-#ifdef SDFK_SIMT
+#if defined(SDFK_CHAIN) && defined(SDFK_CELLS)
+    // every wave folds ITS bricks from their cells' lists: nothing crosses waves any more (no probe centres, no table of
+    // leaf values, two barriers fewer than the path below)
+#pragma unroll 1
+    for (int j = 0; j < SDFK_RWBRICKS; ++j) {
+        const int b = wave * SDFK_RWBRICKS + j;
+#ifdef SDFK_ABLATE_PROBE
+        if (lane == 0) { meta->alist[b][0] = 0; meta->nalive[b] = live[j] ? 1u : 0u; }
+#else
+        if (live[j]) sdfk_chain_fold_cells(meta, b, lane, cl, cellid[j], PRM, TAB);
+        else if (lane == 0) meta->nalive[b] = 0u;
+#endif
+    }
+    __syncthreads();
+    return;
+#endif
+#if defined(SDFK_SIMT) && !defined(SDFK_CELLS)
     // lane-parallel probe: probe centres -> every leaf at every centre (all lanes) -> one fold lane per centre ANDs its
     // skip decisions into the brick's mask (a subtree is skipped only if every sub-brick allows it)
     if (sdfk_tx() < SDFK_NCEN) {
@@ -838,7 +1027,7 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
 template <typename SRC>
 static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict__ PRM, const float* __restrict__ TAB,
                                                         const SRC& s, const sdfk_rowgeom& g, float* __restrict__ out,
-                                                        unsigned* __restrict__ flags, unsigned thr) {
+                                                        unsigned* __restrict__ flags, unsigned thr SDFK_CELLS_PARAM) {
     __shared__ __attribute__((aligned(16))) sdfk_rowmeta meta;
 #ifdef SDFK_LDSPAD
     if (g.L == 0xffffffffu) meta.pad[sdfk_tx()] = 1.0f;
@@ -865,7 +1054,7 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
     if (tile * SDFK_RNBRICK >= g.nbricks) break;
     if (tt) __syncthreads();
     unsigned rb, c;
-    sdfk_rows_prepare(PRM, TAB, s, g, &meta, tile, rb, c);
+    sdfk_rows_prepare(PRM, TAB, s, g, &meta, tile, rb, c SDFK_CELLS_PASS);
     const unsigned q0 = tile * SDFK_RNBRICK + wave * SDFK_RWBRICKS;
 #pragma unroll 1
     for (int j = 0; j < SDFK_RWBRICKS; ++j) {
@@ -941,7 +1130,16 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
             // was bound by memory latency (4200 cycles per child at 1000 children: 3.5 of 4.5 ms). So the wave first GATHERS
             // the next SDFK_CHUNK children lane-parallel — a lane per (child, parameter) — into LDS, and then evaluates them
             // from there: the latency is paid once per chunk.
+#ifdef SDFK_CELLS
+            // (more survivors than the list holds — nalive = ALL —: every member, in order, straight from its index)
+            const unsigned nal = __builtin_amdgcn_readfirstlane(meta.nalive[b]);
+            const bool all_alive = nal == SDFK_ALL_ALIVE;
+            const unsigned cnt = all_alive ? (unsigned)SDFK_NLEAF : nal;
+#define SDFK_ALIST(i) (all_alive ? (unsigned)(i) : (unsigned)meta.alist[b][i])
+#else
             const unsigned cnt = __builtin_amdgcn_readfirstlane(meta.nalive[b]);
+#define SDFK_ALIST(i) ((unsigned)meta.alist[b][i])
+#endif
             f2 acc[SDFK_NP];
 #if SDFK_CHAIN_STAGED
             if (cnt <= SDFK_STAGE_MIN)
@@ -951,7 +1149,7 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
                 // parameters in SGPRs beat parameters read back from LDS — straight from the table
 #pragma unroll 1
                 for (unsigned i = 0; i < cnt; ++i) {
-                    const unsigned kk = __builtin_amdgcn_readfirstlane((unsigned)meta.alist[b][i]);
+                    const unsigned kk = __builtin_amdgcn_readfirstlane(SDFK_ALIST(i));
                     f2 val[SDFK_NP];
                     SDFK_EACH val[q] = sdfk_leaf<f2>(kk, P[q], PRM, TAB);
                     if (i == 0u) { SDFK_EACH acc[q] = val[q]; }
@@ -968,7 +1166,7 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
 #pragma unroll 1
                 for (unsigned it = (unsigned)lane; it < nc * SDFK_NPLMAX; it += 64u) {
                     const unsigned ch = it / SDFK_NPLMAX, w = it - ch * SDFK_NPLMAX;
-                    const unsigned kk = meta.alist[b][c0 + ch];
+                    const unsigned kk = SDFK_ALIST(c0 + ch);
                     const unsigned at = sdfk_leaf_base[kk] + w;
                     meta.cprm[b][ch][w] = PRM[at < SDFK_NPARAMS ? at : SDFK_NPARAMS - 1u];
                     if (w == 0u) meta.cgrp[b][ch] = sdfk_leaf_grp[kk];
@@ -1036,23 +1234,185 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
 #else
 #define SDFK_ROWS_ATTR
 #endif
+#ifdef SDFK_CELLS
+#define SDFK_CELLS_KARG , sdfk_cells cl
+// ---- the pre-pass: one WAVE per cell ------------------------------------------------------------------------------
+struct sdfk_cellpass {
+    sdfk_celllevel lv, parent;                  // parent.ncx == 0: no coarser level — the candidates are all members
+    float4* __restrict__ sph;                   // this level's cells: sphere ...
+    uint2* __restrict__ span;                   // ... and list
+    const float4* __restrict__ psph;            // the parent level's
+    const uint2* __restrict__ pspan;
+    unsigned short* __restrict__ cand;          // the pool both levels allocate from
+    unsigned* __restrict__ head;                // its next free entry
+    unsigned cap, ncells;
+    float inflate, pad;                         // factor on the radius the LIST is computed for (coarse level: > 1, see below)
+};
+// point z of local row `row`
+static __device__ __forceinline__ float3 sdfk_cell_point(const SrcArray& s, const sdfk_rowgeom& g, long long row, unsigned z) {
+    const float* p = s.co + row * (long long)g.L + z;
+    return make_float3(p[0], p[s.stride], p[2 * s.stride]);
+}
+static __device__ __forceinline__ float3 sdfk_cell_point(const SrcGrid& s, const sdfk_rowgeom& g, long long row, unsigned z) {
+    const unsigned long long g0 = (unsigned long long)(g.row0 + row);
+    if (g.yrows) return make_float3(s.ax0[g0], s.ax1[z], s.ax2[0]);
+    const unsigned long long ix = g0 / s.n1;
+    return make_float3(s.ax0[ix], s.ax1[(unsigned)(g0 - ix * s.n1)], s.ax2[z]);
+}
+// rows [r0, rend) and blocks of plane slot sl of a level (slot 0 = the leading partial plane when lv.xoff > 0)
+static __device__ __forceinline__ bool sdfk_slot_rows(const sdfk_rowgeom& g, const sdfk_celllevel& lv, unsigned sl, long long& r0,
+                                                      long long& rend) {
+    if (lv.xoff > 0u && sl == 0u) { r0 = 0; rend = g.seg0; return g.seg0 > 0u; }
+    if (sl < lv.xoff) return false;
+    r0 = (long long)g.seg0 + (long long)(sl - lv.xoff) * g.prow;
+    rend = r0 + g.prow < g.R ? r0 + g.prow : g.R;
+    return r0 < g.R;
+}
+template <typename SRC>
+static __device__ __forceinline__ void sdfk_cells_kernel(const float* __restrict__ PRM, const float* __restrict__ TAB, const SRC& s,
+                                                         const sdfk_rowgeom& g, const sdfk_cellpass& cp) {
+    const int lane = sdfk_tx() & 63;
+    const unsigned cell = __builtin_amdgcn_readfirstlane(sdfk_bx() * 4u + (sdfk_tx() >> 6));
+    if (cell >= cp.ncells) return;
+    const sdfk_celllevel lv = cp.lv;
+    const unsigned cz = cell % lv.ncz, t0 = cell / lv.ncz, cy = t0 % lv.ncy, cx = t0 / lv.ncy;
+    // what the cell covers in index space: slots [sA, sB], blocks [b0, b1], points [zlo, zhi] of a row
+    const unsigned sA = cx << lv.lx;
+    unsigned sB = ((cx + 1u) << lv.lx) - 1u;
+    long long ra0, ra1, rb0, rb1;
+    bool some = sdfk_slot_rows(g, lv, sA, ra0, ra1);
+    if (lv.xoff > 0u && cx == 0u) sB = 0u;
+    while (some && sB > sA && !sdfk_slot_rows(g, lv, sB, rb0, rb1)) --sB;
+    if (sB == sA) { rb0 = ra0; rb1 = ra1; }
+    const long long lo = (long long)(cy << lv.ly) * SDFK_RROWS, hi = (long long)((cy + 1u) << lv.ly) * SDFK_RROWS;
+    some = some && ra0 + lo < ra1;
+    const unsigned w0 = cz << lv.lz, w1 = ((cz + 1u) << lv.lz) < g.nchunk ? ((cz + 1u) << lv.lz) - 1u : g.nchunk - 1u;
+    some = some && w0 < g.nchunk;
+    if (!some) {                                                // no brick maps here
+        if (lane == 0) { cp.sph[cell] = make_float4(0.0f, 0.0f, 0.0f, -1.0f); cp.span[cell] = make_uint2(0u, 0u); }
+        return;
+    }
+    // windows are aligned in the FLAT array: window k of a row starts up to 31 points before point 32 k of that row
+    const unsigned zlo = 32u * w0 > 31u ? 32u * w0 - 31u : 0u;
+    const unsigned zhi = 32u * w1 + 31u < g.L ? 32u * w1 + 31u : g.L - 1u;
+    // the eight corner points (a lattice cell is their convex hull): lanes 0..7
+    const long long rowsel[4] = {ra0 + lo, (ra0 + hi < ra1 ? ra0 + hi : ra1) - 1, (rb0 + lo < rb1 ? rb0 + lo : rb1 - 1),
+                                 (rb0 + hi < rb1 ? rb0 + hi : rb1) - 1};
+    const float3 pt = sdfk_cell_point(s, g, rowsel[(lane >> 1) & 3], (lane & 1) ? zhi : zlo);
+    float mnx = pt.x, mxx = pt.x, mny = pt.y, mxy = pt.y, mnz = pt.z, mxz = pt.z;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        mnx = fminf(mnx, __shfl_xor(mnx, o)); mxx = fmaxf(mxx, __shfl_xor(mxx, o));
+        mny = fminf(mny, __shfl_xor(mny, o)); mxy = fmaxf(mxy, __shfl_xor(mxy, o));
+        mnz = fminf(mnz, __shfl_xor(mnz, o)); mxz = fmaxf(mxz, __shfl_xor(mxz, o));
+    }
+    const V3T<float> ctr = {0.5f * (mnx + mxx), 0.5f * (mny + mxy), 0.5f * (mnz + mxz)};
+    const float dx = pt.x - ctr.x, dy = pt.y - ctr.y, dz = pt.z - ctr.z;
+    float r2 = dx * dx + dy * dy + dz * dz;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) r2 = fmaxf(r2, __shfl_xor(r2, o));
+    r2 = __shfl(r2, 0);
+    const float cxs = __shfl(ctr.x, 0), cys = __shfl(ctr.y, 0), czs = __shfl(ctr.z, 0);
+    const V3T<float> c = {cxs, cys, czs};
+    // the radius the cell ANSWERS for: bricks test their points against it. A coarse level answers for more than its own
+    // sphere (cp.inflate): the circumsphere of a fine cell can reach beyond the circumsphere of the coarse cell it lies in
+    // (fine box at a corner, boxes of different proportions), and a fine cell may only start from its parent's list if its
+    // whole sphere lies inside what that list answers for.
+    const float rho = (1.0001f * sqrtf(r2) + 1e-30f) * cp.inflate;
+    if (lane == 0) cp.sph[cell] = make_float4(c.x, c.y, c.z, rho);
+    // candidates: the parent's list if this cell's sphere lies inside the parent's answer, else every member
+    unsigned off = 0u, cnt = SDFK_NLEAF;
+    bool listed = false;
+    if (cp.parent.ncx != 0u) {
+        unsigned pcx = 0u;
+        if (!(lv.xoff > 0u && cx == 0u)) pcx = (cp.parent.xoff + (sA - lv.xoff)) >> cp.parent.lx;
+        const unsigned pcell = (pcx * cp.parent.ncy + (cy >> (cp.parent.ly - lv.ly))) * cp.parent.ncz + (cz >> (cp.parent.lz - lv.lz));
+        const float4 ps = cp.psph[pcell];
+        const uint2 sp = cp.pspan[pcell];
+        const float ex = c.x - ps.x, ey = c.y - ps.y, ez = c.z - ps.z;
+        if (ps.w > 0.0f && sp.y != SDFK_ALL_ALIVE && 1.00002f * (sqrtf(ex * ex + ey * ey + ez * ez) + rho) <= ps.w) {
+            off = sp.x; cnt = sp.y; listed = true;
+        }
+    }
+    const float cmag = 1e-6f * (fabsf(c.x) + fabsf(c.y) + fabsf(c.z) + rho);
+    float m = 3.0e38f;
+#pragma unroll 1
+    for (unsigned j0 = 0u; j0 < cnt; j0 += 64u) {
+        const unsigned j = j0 + (unsigned)lane;
+        if (j < cnt) m = fminf(m, SDFK_CHAIN_SGN * sdfk_leaf<float>(listed ? (unsigned)cp.cand[off + j] : j, c, PRM, TAB));
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) m = fminf(m, __shfl_xor(m, o));
+    const float thr0 = 1.0001f * SDFK_CHAIN_KMAX * rho + SDFK_CHAIN_KMAX * cmag + 1e-6f * (1.0f + fabsf(m));
+    unsigned total = 0u;
+#pragma unroll 1
+    for (unsigned j0 = 0u; j0 < cnt; j0 += 64u) {
+        const unsigned j = j0 + (unsigned)lane;
+        bool run = false;
+        if (j < cnt) {
+            const float e = SDFK_CHAIN_SGN * sdfk_leaf<float>(listed ? (unsigned)cp.cand[off + j] : j, c, PRM, TAB);
+            run = !(e - m >= thr0 + 1e-6f * fabsf(e));
+        }
+        total += (unsigned)__builtin_popcountll(__ballot(run));
+    }
+    unsigned at = 0u;
+    if (lane == 0) at = atomicAdd(cp.head, total);
+    at = __shfl(at, 0);
+    if (at > cp.cap || total > cp.cap - at) {                   // the pool is full: bricks of this cell probe every member
+        if (lane == 0) cp.span[cell] = make_uint2(0u, SDFK_ALL_ALIVE);
+        return;
+    }
+    unsigned n_out = 0u;
+#pragma unroll 1
+    for (unsigned j0 = 0u; j0 < cnt; j0 += 64u) {
+        const unsigned j = j0 + (unsigned)lane;
+        bool run = false;
+        unsigned k = 0u;
+        if (j < cnt) {
+            k = listed ? (unsigned)cp.cand[off + j] : j;
+            const float e = SDFK_CHAIN_SGN * sdfk_leaf<float>(k, c, PRM, TAB);
+            run = !(e - m >= thr0 + 1e-6f * fabsf(e));
+        }
+        const unsigned long long bits = __ballot(run);
+        if (run) cp.cand[at + n_out + (unsigned)__builtin_popcountll(bits & ((1ull << lane) - 1ull))] = (unsigned short)k;
+        n_out += (unsigned)__builtin_popcountll(bits);
+    }
+    if (lane == 0) cp.span[cell] = make_uint2(at, total);
+}
+#else
+#define SDFK_CELLS_KARG
+#endif
 )SDFKR";
 static const char kRowsArray[] = R"SDFKR(
 extern "C" __global__ __launch_bounds__(64 * SDFK_RWAVES) SDFK_ROWS_ATTR void sdfk_spec_r(
     const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
-    sdfk_rowgeom g, float* __restrict__ out, unsigned* __restrict__ flags, unsigned thr) {
+    sdfk_rowgeom g, float* __restrict__ out, unsigned* __restrict__ flags, unsigned thr SDFK_CELLS_KARG) {
     const SrcArray s = {co, stride};
-    sdfk_rows_kernel(PRM, TAB, s, g, out, flags, thr);
+    sdfk_rows_kernel(PRM, TAB, s, g, out, flags, thr SDFK_CELLS_PASS);
 }
+#ifdef SDFK_CELLS
+extern "C" __global__ __launch_bounds__(256) void sdfk_spec_cells(
+    const float* __restrict__ PRM, const float* __restrict__ TAB, const float* __restrict__ co, long long stride,
+    sdfk_rowgeom g, sdfk_cellpass cp) {
+    const SrcArray s = {co, stride};
+    sdfk_cells_kernel(PRM, TAB, s, g, cp);
+}
+#endif
 )SDFKR";
 static const char kRowsGrid[] = R"SDFKR(
 // the same on a regular grid expanded from three per-axis tables (no coordinate array: 4 B/point); the slab
 // starts at a row boundary and out[0] is its first point
 extern "C" __global__ __launch_bounds__(64 * SDFK_RWAVES) void sdfk_spec_rg(
     const float* __restrict__ PRM, const float* __restrict__ TAB, SrcGrid s, sdfk_rowgeom g, float* __restrict__ out,
-    unsigned* __restrict__ flags, unsigned thr) {
-    sdfk_rows_kernel(PRM, TAB, s, g, out, flags, thr);
+    unsigned* __restrict__ flags, unsigned thr SDFK_CELLS_KARG) {
+    sdfk_rows_kernel(PRM, TAB, s, g, out, flags, thr SDFK_CELLS_PASS);
 }
+#ifdef SDFK_CELLS
+extern "C" __global__ __launch_bounds__(256) void sdfk_spec_cellsg(
+    const float* __restrict__ PRM, const float* __restrict__ TAB, SrcGrid s, sdfk_rowgeom g, sdfk_cellpass cp) {
+    sdfk_cells_kernel(PRM, TAB, s, g, cp);
+}
+#endif
 )SDFKR";
 static const char kRowsMask[] = R"SDFKR(
 // test aid: the skip masks (two 64-bit words per brick: sites 0-31, 32-63; bit 2k = first operand of site k
@@ -2032,6 +2392,7 @@ std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32
             if (flat2) g.s += "\n#define SDFK_FLAT 1\n";
             g.s += "\n#define SDFK_NP 4\n#define SDFK_EACH _Pragma(\"unroll\") for (int q = 0; q < SDFK_NP; ++q)\n"
                    "#define SDFK_SIMT 1\n#define SDFK_NSUB 1\n"
+                   "#ifndef SDFK_NO_CELLS\n#define SDFK_CELLS 1         // candidate lists per cell (sdfk_spec_cells; -DSDFK_NO_CELLS: the probe of every member)\n#endif\n"
                    "#ifndef SDFK_LEAF_UNROLL\n#define SDFK_LEAF_UNROLL _Pragma(\"unroll 4\")\n#endif\n";
             g.s += kSimtGeometry;
             // (a lane per LEAF walking the centres pays off once there are more leaves than lanes; below that a lane per
