@@ -19,6 +19,7 @@ MODE_AUTO, MODE_INTERPRET, MODE_SPECIALIZED, MODE_NOCULL = 0, 1, 2, 3
 (FLAVOUR_PLAIN_ARRAY, FLAVOUR_PLAIN_GRID, FLAVOUR_TILE_ARRAY, FLAVOUR_TILE_GRID, FLAVOUR_TILE_MASK, FLAVOUR_ROWS_ARRAY,
  FLAVOUR_ROWS_GRID, FLAVOUR_ROWS_MASK, FLAVOUR_ROWS2D_ARRAY, FLAVOUR_ROWS2D_GRID) = range(10)
 FLAVOUR_FLAGS = 0x100      # OR-ed onto a PLAIN / ROWS / ROWS2D flavour: its flag-writing build (fused selection)
+FLAVOUR_XY = 0x200         # OR-ed onto PLAIN_ARRAY / ROWS2D_ARRAY: the build for two-row coordinates (z = 0 by contract)
 
 _c = ctypes
 _vp, _i64, _int, _sz = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t
@@ -44,6 +45,7 @@ SIGNATURES = {
     "sdfk_eval_device": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _int]),
     "sdfk_eval_device_rows": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int]),
     "sdfk_eval_device_rows2d": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int]),
+    "sdfk_eval_device_rows2d_xy": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int]),
     "sdfk_eval_device_rows3d": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int]),
     "sdfk_debug_row_masks": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _c.POINTER(_i64), _c.POINTER(_int), _vp]),
     "sdfk_eval_grid_sharded": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _int, _vp, _vp, _int]),
@@ -271,6 +273,11 @@ class Program:
             return
         check(lib().sdfk_eval_device(self._h, _vp(d_co), n, row_stride, _vp(d_out), _vp(stream or 0), mode),
               "sdfk_eval_device")
+
+    def eval_device_xy(self, d_xy, n, row_stride, d_out, stream=None, mode=MODE_AUTO, row_len=None):
+        """Two coordinate rows (x, y) of a flat grid, z = 0 by contract: 12 instead of 16 bytes per point."""
+        check(lib().sdfk_eval_device_rows2d_xy(self._h, _vp(d_xy), n, row_stride, int(row_len or 0), _vp(d_out),
+                                               _vp(stream or 0), mode), "sdfk_eval_device_rows2d_xy")
 
     def eval_grid(self, axes, start, count, d_out, stream=None, mode=MODE_AUTO):
         ax = [np.ascontiguousarray(a, dtype=np.float32) for a in axes]

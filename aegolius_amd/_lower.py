@@ -706,9 +706,46 @@ def _staged(L, fields, stop_at, probe_axis):
     return L
 
 
+def _deep(fn):
+    """Run fn(); a tree nested deeper than the interpreter's recursion limit allows (a left-deep chain of hundreds of
+    pairwise combinations: the lowering recurses a few frames per level, as the reference's nested closures do when they are
+    called) is lowered again on a thread with a large stack and no practical limit."""
+    try:
+        return fn()
+    except RecursionError:
+        pass
+    import sys
+    import threading
+    box = {}
+
+    def work():
+        old = sys.getrecursionlimit()
+        sys.setrecursionlimit(1000000)
+        try:
+            box["value"] = fn()
+        except BaseException as exc:  # noqa: BLE001
+            box["error"] = exc
+        finally:
+            sys.setrecursionlimit(old)
+    old_size = threading.stack_size(512 * 1024 * 1024)
+    try:
+        t = threading.Thread(target=work)
+        t.start()
+        t.join()
+    finally:
+        threading.stack_size(old_size)
+    if "error" in box:
+        raise box["error"]
+    return box["value"]
+
+
 def lower_geometry(node, fields=None, stop_at=None, probe_axis=None):
     """Lower `node.create(co)` to a program. `fields` / `stop_at` / `probe_axis`: stage programs of a tree with
     grid-neighbourhood operators (see _eval._run_staged)."""
+    return _deep(lambda: _lower_geometry(node, fields, stop_at, probe_axis))
+
+
+def _lower_geometry(node, fields, stop_at, probe_axis):
     L = _staged(Lowerer(), fields, stop_at, probe_axis)
     try:
         v = L.lower_node(node, 0, OWNED)
@@ -733,6 +770,10 @@ class _ExprNode:
 
 
 def lower_expression(expr, params, fields=None, stop_at=None, probe_axis=None):
+    return _deep(lambda: _lower_expression(expr, params, fields, stop_at, probe_axis))
+
+
+def _lower_expression(expr, params, fields, stop_at, probe_axis):
     # a bare closure call gets the caller's array itself (no private copy): OWNED is safe because the
     # register is loaded from memory and the caller's array is never written
     L = _staged(Lowerer(), fields, stop_at, probe_axis)

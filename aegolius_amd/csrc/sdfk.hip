@@ -1098,11 +1098,13 @@ static std::shared_ptr<CodeObject> code_get(const std::string& key, MakeSource m
 }
 // with_flags: the build of a flavour that writes one flag bit per point (value <= threshold) instead of the field — a
 // translation unit of its own (#define SDFK_FLAGS), so the field kernels carry none of it.
-static std::string flavour_key(const sdfk_program* p, int flavour, int rwb, bool with_flags = false) {
-    return p->key + "|f" + std::to_string(flavour) + (with_flags ? "s|" : "|") + rtc_option_key(rwb);
+// with_flags is a set of build VARIANTS: bit 0 = flag-writing build (SDFK_FLAGS), bit 1 = two-row coordinates, z = 0 by
+// contract (SDFK_XY: the array kernels never read a third row — sdfk_eval_device_rows2d_xy)
+static std::string flavour_key(const sdfk_program* p, int flavour, int rwb, int with_flags = 0) {
+    return p->key + "|f" + std::to_string(flavour) + ((with_flags & 1) ? "s" : "") + ((with_flags & 2) ? "x" : "") + "|" + rtc_option_key(rwb);
 }
-static std::string flavour_source(const sdfk_program* p, int flavour, bool with_flags = false) {
-    return (with_flags ? "#define SDFK_FLAGS 1\n" : "") +
+static std::string flavour_source(const sdfk_program* p, int flavour, int with_flags = 0) {
+    return std::string((with_flags & 1) ? "#define SDFK_FLAGS 1\n" : "") + ((with_flags & 2) ? "#define SDFK_XY 1\n" : "") +
            sdfk_generate_source(g_ops, SDFK_OP_COUNT, p->code.data(), p->code.size() / 2, p->result_reg, p->sites, flavour,
                                 &p->sites_all);
 }
@@ -1128,12 +1130,16 @@ extern "C" int sdfk_program_compile_check(sdfk_program* p, size_t* code_size) {
 /* Build (or fetch) ONE flavour without a GPU: 0 + seconds the build took (0 when it was already there). */
 extern "C" int sdfk_program_compile_flavour(sdfk_program* p, int flavour, size_t* code_size, double* seconds) {
     if (!p) return fail(-1, "null program");
-    const bool with_flags = flavour >= 0 && (flavour & SDFK_FLAVOUR_FLAGS);          // the flag-writing build of the flavour
-    if (with_flags) flavour &= ~SDFK_FLAVOUR_FLAGS;
+    int with_flags = 0;                                                              // build variants (see flavour_key)
+    if (flavour >= 0 && (flavour & SDFK_FLAVOUR_FLAGS)) with_flags |= 1;             // the flag-writing build of the flavour
+    if (flavour >= 0 && (flavour & SDFK_FLAVOUR_XY)) with_flags |= 2;                // two-row coordinates
+    if (flavour >= 0) flavour &= ~(SDFK_FLAVOUR_FLAGS | SDFK_FLAVOUR_XY);
     if (flavour < 0 || flavour >= SDFK_FL_COUNT) return fail(-1, "sdfk_program_compile_flavour: unknown flavour");
     if (p->sites.empty() && flavour != SDFK_FL_PLAIN_ARRAY && flavour != SDFK_FL_PLAIN_GRID)
         return fail(-2, "sdfk_program_compile_flavour: the program has no cull sites");
-    if (with_flags && (flavour == SDFK_FL_TILE_ARRAY || flavour == SDFK_FL_TILE_GRID || flavour == SDFK_FL_TILE_MASK ||
+    if ((with_flags & 2) && flavour != SDFK_FL_PLAIN_ARRAY && flavour != SDFK_FL_ROWS2D_ARRAY)
+        return fail(-2, "sdfk_program_compile_flavour: two-row coordinates exist for the plain and the flat row-block array kernels");
+    if ((with_flags & 1) && (flavour == SDFK_FL_TILE_ARRAY || flavour == SDFK_FL_TILE_GRID || flavour == SDFK_FL_TILE_MASK ||
                        flavour == SDFK_FL_ROWS_MASK))
         return fail(-2, "sdfk_program_compile_flavour: this flavour has no flag-writing build");
     const int rwb = rows_geo(p);
@@ -1163,7 +1169,7 @@ extern "C" int sdfk_debug_compile_external(sdfk_program* p, int flavour, size_t*
 // The module of one flavour on one device. wait = false: nullptr while the code object is still being built in the
 // background (the caller serves this call from the interpreter kernel — same bits). *err is set on failure.
 static std::shared_ptr<SpecModule> get_module(sdfk_program* p, int device, int flavour, bool wait, std::string* err,
-                                              bool with_flags = false) {
+                                              int with_flags = 0) {
     const int rwb = rows_geo(p);
     const std::string key = flavour_key(p, flavour, rwb, with_flags);
     std::shared_ptr<SpecModule> m;
@@ -1397,7 +1403,7 @@ static int prepare_cells(sdfk_program* p, DevState* d, hipFunction_t cells_fn, c
 static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long long n, float* d_out, void* stream_,
                int mode, bool vec_ok, long long row_len = 0, const float* aux = nullptr, long long aux_stride = 0,
                bool flat = false, long long plane_rows = 0, long long plane_phase = 0, unsigned* d_flags = nullptr,
-               unsigned thr_key = 0) {
+               unsigned thr_key = 0, bool xy = false) {
     if (!p) return fail(-1, "null program");
     if (n < 0) return fail(-1, "negative point count");
     if (p->n_aux > 0 && (!aux || aux_stride < n))
@@ -1407,6 +1413,12 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
     // flags instead of the field (fused selection): the specialised plain / row-block kernels only — the call waits for
     // their build instead of starting on the interpreter kernel
     if (d_flags && (mode == SDFK_MODE_AUTO || mode == SDFK_MODE_INTERPRET)) mode = SDFK_MODE_SPECIALIZED;
+    // two-row coordinates (z = 0 by contract): builds of the plain and the flat row-block array kernels that never touch a
+    // third row; the interpreter kernel has no such build, so these calls wait for the specialised kernel too
+    if (xy) {
+        if (!arr || p->n_aux > 0) return fail(-1, "two-row coordinates: array source, no auxiliary fields");
+        if (mode == SDFK_MODE_AUTO || mode == SDFK_MODE_INTERPRET) mode = SDFK_MODE_SPECIALIZED;
+    }
     hipStream_t stream = (hipStream_t)stream_;
     int device = 0;
     HIPCHK(hipGetDevice(&device));
@@ -1436,8 +1448,8 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
     if (!p->sites.empty() && mode != SDFK_MODE_NOCULL && mode != SDFK_MODE_INTERPRET) {
         // (chain mode: row blocks of ONE plane each — the cells of its candidate lists are boxes of the grid)
         if (arr && rows_geometry(n, row_len, &rg, (flat || d_flags) ? 0 : plane_rows, plane_phase, p->chain_mode))
-            flavour = flat ? SDFK_FL_ROWS2D_ARRAY : SDFK_FL_ROWS_ARRAY;   // rows need no alignment beyond 4 bytes
-        else if (arr && vec_ok && !p->chain_mode && !d_flags) flavour = SDFK_FL_TILE_ARRAY;
+            flavour = (flat || xy) ? SDFK_FL_ROWS2D_ARRAY : SDFK_FL_ROWS_ARRAY;   // rows need no alignment beyond 4 bytes
+        else if (arr && vec_ok && !p->chain_mode && !d_flags && !xy) flavour = SDFK_FL_TILE_ARRAY;
         else if (grid && grid->start % grow == 0 &&
                  rows_geometry(n, grow, &rg, (grid->n2 > 1 && !d_flags) ? (long long)grid->n1 : 0,    // (flags: the slot layout
                                grid->n2 > 1 ? (grid->start / grow) % (long long)grid->n1 : 0, p->chain_mode))   //  knows blocks of 16 rows)
@@ -1452,7 +1464,7 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
         static const bool async_jit = [] { const char* e = getenv("SDFK_ASYNC_JIT"); return !(e && e[0] == '0'); }();
         const bool wait = mode != SDFK_MODE_AUTO || !p->interp_ok || !async_jit;
         std::string err;
-        sk = get_module(p, device, flavour, wait, &err, d_flags != nullptr);
+        sk = get_module(p, device, flavour, wait, &err, (d_flags ? 1 : 0) | (xy ? 2 : 0));
         if (sk && sk->failed) {
             if (mode == SDFK_MODE_SPECIALIZED || !p->interp_ok)
                 return fail(-3, "specialised kernel unavailable: " + err);
@@ -1600,6 +1612,18 @@ extern "C" int sdfk_eval_device_rows(sdfk_program* p, const float* d_co, int64_t
     SrcArray a = {d_co, (long long)row_stride};
     bool vec_ok = aligned16(d_co) && aligned16(d_out) && (row_stride % 4 == 0);
     return run(p, &a, nullptr, n, d_out, stream, mode, vec_ok, row_len);
+}
+
+/* include/sdfk.h: two coordinate rows, z = 0 by contract */
+extern "C" int sdfk_eval_device_rows2d_xy(sdfk_program* p, const float* d_xy, int64_t n, int64_t row_stride, int64_t row_len,
+                                          float* d_out, void* stream, int mode) {
+    if (!d_xy || !d_out) return fail(-1, "sdfk_eval_device_rows2d_xy: null device pointer");
+    if (row_stride < n) return fail(-1, "sdfk_eval_device_rows2d_xy: row stride smaller than the point count");
+    if (row_len < 0 || (row_len > 0 && n > 0 && n % row_len != 0))
+        return fail(-1, "sdfk_eval_device_rows2d_xy: the point count is not a multiple of the row length");
+    SrcArray a = {d_xy, (long long)row_stride};
+    bool vec_ok = aligned16(d_xy) && aligned16(d_out) && (row_stride % 4 == 0);
+    return run(p, &a, nullptr, n, d_out, stream, mode, vec_ok, row_len, nullptr, 0, row_len > 0, 0, 0, nullptr, 0, true);
 }
 
 extern "C" int sdfk_eval_device_rows3d(sdfk_program* p, const float* d_co, int64_t n, int64_t row_stride, int64_t row_len,

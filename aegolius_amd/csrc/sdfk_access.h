@@ -42,14 +42,22 @@ static __device__ __forceinline__ void sdfk_load(const SrcArray& s, long long bl
     if constexpr (VEC == 4) {
         const float4 x = sdfk_stream_load4(s.co + i);
         const float4 y = sdfk_stream_load4(s.co + s.stride + i);
+#ifdef SDFK_XY                                                   // two-row coordinates: z = 0 by contract, no third row
+        const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#else
         const float4 z = sdfk_stream_load4(s.co + 2 * s.stride + i);
+#endif
         p[0] = {x.x, y.x, z.x};
         p[1] = {x.y, y.y, z.y};
         p[2] = {x.z, y.z, z.z};
         p[3] = {x.w, y.w, z.w};
     } else {
 #pragma unroll
+#ifdef SDFK_XY
+        for (int v = 0; v < VEC; ++v) p[v] = {s.co[i + v], s.co[s.stride + i + v], 0.0f};
+#else
         for (int v = 0; v < VEC; ++v) p[v] = {s.co[i + v], s.co[s.stride + i + v], s.co[2 * s.stride + i + v]};
+#endif
     }
 }
 

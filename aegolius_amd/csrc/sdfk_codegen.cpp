@@ -561,7 +561,11 @@ static __device__ __forceinline__ void sdfk_rows_fetch(const SrcArray& s, const 
     const int last = (int)g.L - 1;
     X = sdfk_win_quad(p, z, last, interior);
     Y = sdfk_win_quad(p + s.stride, z, last, interior);
+#ifdef SDFK_XY                                                    // two-row coordinates (z = 0 by contract): 12 B/point
+    Z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#else
     Z = sdfk_win_quad(p + 2 * s.stride, z, last, interior);
+#endif
 }
 // regular grid: row -> (ix, iy) with one wave-uniform division per brick; z from the third axis table
 static __device__ __forceinline__ void sdfk_rows_fetch(const SrcGrid& s, const sdfk_rowgeom& g, long long r0, int dr, int z,
@@ -1251,7 +1255,11 @@ struct sdfk_cellpass {
 // point z of local row `row`
 static __device__ __forceinline__ float3 sdfk_cell_point(const SrcArray& s, const sdfk_rowgeom& g, long long row, unsigned z) {
     const float* p = s.co + row * (long long)g.L + z;
+#ifdef SDFK_XY
+    return make_float3(p[0], p[s.stride], 0.0f);
+#else
     return make_float3(p[0], p[s.stride], p[2 * s.stride]);
+#endif
 }
 static __device__ __forceinline__ float3 sdfk_cell_point(const SrcGrid& s, const sdfk_rowgeom& g, long long row, unsigned z) {
     const unsigned long long g0 = (unsigned long long)(g.row0 + row);

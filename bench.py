@@ -230,11 +230,16 @@ class Run:
         self.out = torch.empty((self.stride,), dtype=torch.float32, device=dev)
         self.stream = torch.cuda.current_stream().cuda_stream
         self.use_rows = use_rows
+        self.xy = False
         self.no_planes = os.environ.get("SDFK_BENCH_NO_PLANES") == "1"      # A/B: blocks of 16 rows regardless of planes
         engine.grid_fill(self.co.data_ptr(), self.stride, axes, self.start, self.count, stream=self.stream)
 
     def step(self):
         flat = self.axes[2].size == 1
+        if self.xy:                                             # two-row call: z = 0 by contract, 12 B/point (flat grids)
+            self.prog.eval_device_xy(self.co.data_ptr(), self.count, self.stride, self.out.data_ptr(), stream=self.stream,
+                                     mode=self.mode, row_len=self.row_len if self.use_rows else None)
+            return
         self.prog.eval_device(self.co.data_ptr(), self.count, self.stride, self.out.data_ptr(), stream=self.stream,
                               mode=self.mode, row_len=self.row_len if self.use_rows else None, flat=flat,
                               plane_rows=None if flat or self.no_planes else int(self.axes[1].size),
@@ -598,6 +603,21 @@ def main():
                                              "violations": v["violations"]}}
                     if note:
                         res[key]["note"] = note
+                    if ax[2].size == 1:
+                        # the same flat grid WITHOUT its z row (sdfk_eval_device_rows2d_xy: z = 0 is the call's contract):
+                        # 12 B/point — its own line with its own roofline, never mixed with the 16 B/point one above
+                        keep = r.out.clone()
+                        r.xy = True
+                        r.step()
+                        torch.cuda.synchronize()
+                        e2, k2, med2, mn2 = r.timed(steps_o, int(min(50, max(5, round(0.03 / one)))))
+                        res[key + "_xy"] = {"workload": t_desc + " — x and y rows only (z = 0 by contract)", "points": pts,
+                                            "steps": steps_o, "value": pts * steps_o / e2 / 1e6, "unit": "Mpoints/s",
+                                            "ms_per_step": e2 / steps_o * 1e3, "kernel_ms": k2, "kernel_ms_median": med2,
+                                            "kernel_ms_min": mn2, "bytes_per_point": 12,
+                                            "roofline_frac": 12.0 * pts / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                            "same_field_as_the_three_row_call": bool(torch.equal(keep[:r.count], r.out[:r.count]))}
+                        del keep
                     del r, t_prog
                     torch.cuda.empty_cache()
                 except Exception as exc:  # noqa: BLE001

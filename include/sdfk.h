@@ -99,6 +99,8 @@ int sdfk_program_compile_check(sdfk_program* prog, size_t* code_size);
    the field — what sdfk_eval_device_select / sdfk_eval_grid_select launch). A translation unit of its own: the field
    kernels carry none of it (as a run-time branch it cost the 20-primitive tree 10 % at 1025^3). */
 #define SDFK_FLAVOUR_FLAGS 0x100
+/* OR-ed onto PLAIN_ARRAY / ROWS2D_ARRAY: the build for two-row coordinates (z = 0 by contract: sdfk_eval_device_rows2d_xy) */
+#define SDFK_FLAVOUR_XY 0x200
 /* Build (or fetch from the caches) ONE flavour, GPU or not: its code-object size and the seconds this call took. */
 int sdfk_program_compile_flavour(sdfk_program* prog, int flavour, size_t* code_size, double* seconds);
 /* Test aid: build one flavour the way BACKGROUND builds are run — in a child process (aegolius_amd/sdfk_rtc_helper,
@@ -147,6 +149,14 @@ int sdfk_eval_device_rows3d(sdfk_program* prog, const float* d_co, int64_t n, in
  * a zero). */
 int sdfk_eval_device_rows2d(sdfk_program* prog, const float* d_co, int64_t n, int64_t row_stride, int64_t row_len,
                             float* d_out, void* stream, int mode);
+/* Flat grids WITHOUT their z row: d_xy is a (2, n) array — row 0 = x, row 1 = y, row pitch row_stride elements — and
+ * z = 0 is the CONTRACT of the call, not something the kernel reads (the reference's 2-D generate_grid,
+ * cores/helper_functions.py:63-75, always appends a row of zeros; streaming it costs a quarter of the traffic: 12
+ * instead of 16 bytes per point). row_len as for sdfk_eval_device_rows2d (0: no layout hint — the plain kernel). The
+ * field is bit-identical to sdfk_eval_device_rows2d on the same x, y with a zero z row. Waits for the specialised kernel
+ * (the interpreter kernel has no two-row build); programs that read auxiliary fields are refused. */
+int sdfk_eval_device_rows2d_xy(sdfk_program* prog, const float* d_xy, int64_t n, int64_t row_stride, int64_t row_len,
+                               float* d_out, void* stream, int mode);
 /* Host-buffer convenience: stages co (dtype 0 = fp32, 1 = fp64; (3, n) with row stride in elements)
  * through device memory in chunks, evaluates and copies the fp32 field back. */
 int sdfk_eval_host(sdfk_program* prog, const void* co, int co_dtype, int64_t n, int64_t row_stride, float* out,

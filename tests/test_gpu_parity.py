@@ -1043,6 +1043,50 @@ def test_flat_baseline_grid_16385_squared(engine):
     assert torch.equal(win, out[w0:w0 + wn])
 
 
+@pytest.mark.parametrize("shape", [(513, 513), (700, 333), (64, 4100)])
+def test_two_row_coordinates_equal_the_three_row_path(shape, engine):
+    """sdfk_eval_device_rows2d_xy — x and y rows only, z = 0 by contract (12 B/point) — against the three-row calls on the
+    same x, y with a row of zeros: the chain-mode flat kernel (50-child union), a mask kernel (9-child union below the
+    chain threshold), a program without cull sites (plain kernel), with and without the row hint; equal as floats (the
+    sign of a zero may differ between the flat and the general transform: the existing rule for flat grids)."""
+    import torch
+    n0, n1 = shape
+    n = n0 * n1
+    stride = (n + 255) // 256 * 256
+    rng = np.random.default_rng(n0 * 7 + n1)
+    ax0 = np.linspace(-5, 5, n0).astype(np.float32)
+    ax1 = np.linspace(-5, 5, n1).astype(np.float32)
+    co = torch.zeros((3, stride), dtype=torch.float32, device="cuda")
+    co[0, :n] = torch.from_numpy(np.repeat(ax0, n1)).cuda()
+    co[1, :n] = torch.from_numpy(np.tile(ax1, n0)).cuda()
+    small = ns.CombineGeometry("UNION").combine(*[_placed2d(rng) for _ in range(9)])
+    single = ns.Circle(0.8)
+    single.onion(0.1)
+    single.rotate(0.4, (0, 0, 1))
+    single.move((0.3, -0.2, 0))
+    outs = [torch.empty((stride,), dtype=torch.float32, device="cuda") for _ in range(2)]
+    for tree in (scenes.cfg4_scene2d(ns), small, single):
+        prog = engine.Program.from_lowered(lower_geometry(tree))
+        for row_len in (n1, None):
+            prog.eval_device(co.data_ptr(), n, stride, outs[0].data_ptr(), mode=engine.MODE_SPECIALIZED, row_len=row_len,
+                             flat=row_len is not None)
+            outs[1].fill_(float("nan"))
+            prog.eval_device_xy(co.data_ptr(), n, stride, outs[1].data_ptr(), mode=engine.MODE_SPECIALIZED, row_len=row_len)
+            torch.cuda.synchronize()
+            assert torch.equal(outs[0][:n], outs[1][:n]), (shape, row_len)
+        # un-culled two-row kernel too
+        prog.eval_device_xy(co.data_ptr(), n, stride, outs[1].data_ptr(), mode=engine.MODE_NOCULL)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0][:n], outs[1][:n])
+
+
+def _placed2d(rng):
+    o = [ns.Circle(0.4), ns.Rectangle(0.8, 0.5), ns.NGon(0.4, 6)][int(rng.integers(0, 3))]
+    o.rotate(float(rng.uniform(0, np.pi)), (0, 0, 1))
+    o.move((float(rng.uniform(-4, 4)), float(rng.uniform(-4, 4)), 0))
+    return o
+
+
 def test_apply_and_generic_geometry_variants(engine, golden_inputs):
     """EuclideanTransform.apply / apply_ec_transforms (reference cores/transformations.py:232-264) and the
     GenericGeometry2D / 3D classes evaluate like the object protocol they are part of."""
