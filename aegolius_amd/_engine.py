@@ -46,6 +46,7 @@ SIGNATURES = {
     "sdfk_eval_device_rows": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int]),
     "sdfk_eval_device_rows2d": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int]),
     "sdfk_eval_device_rows2d_xy": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int]),
+    "sdfk_debug_cells_stats": (None, [_int, _c.POINTER(_c.c_longlong)]),
     "sdfk_eval_device_rows3d": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int]),
     "sdfk_debug_row_masks": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _c.POINTER(_i64), _c.POINTER(_int), _vp]),
     "sdfk_eval_grid_sharded": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _int, _vp, _vp, _int]),

@@ -59,7 +59,7 @@ V_VV = {
 }
 # combiners at which a whole operand subtree can be skipped
 CULLABLE = ("VMIN", "VMAX", "VSUBTRACT", "SMIN2", "SMIN3", "SMAX3", "SSUB3")
-MAX_SITES = 4095   # what sdfk_program_set_cull takes; the mask kernels use the 64 widest (the flat tile kernel 31), long
+MAX_SITES = 32767  # what sdfk_program_set_cull takes; the mask kernels use the 64 widest (the flat tile kernel 31), long
                    # n-ary chains run table-driven with every site (csrc/sdfk_codegen.cpp, "chain mode")
 
 

@@ -506,7 +506,7 @@ static bool is_cullable_op(unsigned op) {
 
 extern "C" int sdfk_program_set_cull(sdfk_program* p, const uint32_t* rows, size_t n_sites, const float* k) {
     if (!p) return fail(-1, "null program");
-    if (n_sites > 4095) return fail(-2, "sdfk_program_set_cull: at most 4095 sites");
+    if (n_sites > 32767) return fail(-2, "sdfk_program_set_cull: at most 32767 sites");
     if (n_sites && (!rows || !k)) return fail(-1, "sdfk_program_set_cull: null arrays");
     std::lock_guard<std::mutex> lk(p->mu);
     if (!p->source.empty() || !p->dev.empty())
@@ -1286,6 +1286,18 @@ static inline unsigned blocks_for(long long n, int vec) {
     return (unsigned)((n + (long long)SDFK_BLOCK * vec - 1) / ((long long)SDFK_BLOCK * vec));
 }
 
+// test aid: statistics of the candidate lists of the last chain-mode launch (sdfk_debug_cells_stats)
+static std::atomic<bool> g_cells_stats_on{false};
+static std::mutex g_cells_stats_mu;
+static long long g_cells_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+extern "C" void sdfk_debug_cells_stats(int enable, long long* out8) {
+    g_cells_stats_on.store(enable != 0);
+    if (out8) {
+        std::lock_guard<std::mutex> lk(g_cells_stats_mu);
+        for (int i = 0; i < 8; ++i) out8[i] = g_cells_stats[i];
+        for (int i = 0; i < 8; ++i) g_cells_stats[i] = 0;
+    }
+}
 // ---- candidate lists of chain-mode programs (sdfk_codegen.cpp: sdfk_cells / sdfk_cellpass / sdfk_spec_cells) ------------------
 struct CellLevelH {           // mirrors sdfk_celllevel
     unsigned lx, ly, lz, ncx, ncy, ncz, xoff, pad;
@@ -1345,9 +1357,16 @@ static int prepare_cells(sdfk_program* p, DevState* d, hipFunction_t cells_fn, c
     if (nf == 0 || nf > 0x3fffffffull || nc > 0x3fffffffull) return 0;
     // pool: room for 48 entries per fine cell and 1024 per coarse cell (measured lists: a handful / a few hundred); a cell
     // that finds the pool full makes its bricks probe every member — slower, never wrong
-    const unsigned long long cap = std::min<unsigned long long>(0x7fffffffull, 48ull * nf + 1024ull * nc + 4ull * (unsigned)p->chain_members);
+    // the coarse level can never run out (every cell could keep every member: members x cells entries, a few MB); the fine
+    // level gets what is left of a budget that covers 256 entries per cell (measured lists: a handful to a few dozen)
+    const unsigned long long members = (unsigned long long)p->chain_members;
+    unsigned long long cap = std::min<unsigned long long>(0x3fffffffull, nc * members + std::min(nf * members, 256ull * nf + (16ull << 20)));
+    if (const char* e = getenv("SDFK_CELLS_POOL")) {             // (tests: a pool too small for the lists)
+        const long long v = atoll(e);
+        if (v > 0) cap = std::min<unsigned long long>(cap, (unsigned long long)v);
+    }
     const size_t o_fsph = 0, o_fspan = o_fsph + 16 * nf, o_csph = o_fspan + 8 * nf, o_cspan = o_csph + 16 * nc,
-                 o_head = (o_cspan + 8 * nc + 15) & ~(size_t)15, o_pool = o_head + 16, total = o_pool + 2 * cap + 64;
+                 o_head = (o_cspan + 8 * nc + 15) & ~(size_t)15, o_pool = o_head + 16, total = o_pool + 4 * cap + 64;
     CellScratch* cs;
     {
         std::lock_guard<std::mutex> lk(p->mu);
@@ -1390,6 +1409,28 @@ static int prepare_cells(sdfk_program* p, DevState* d, hipFunction_t cells_fn, c
         args.push_back(&g2);
         args.push_back(&cp);
         HIPCHK(hipModuleLaunchKernel(cells_fn, (unsigned)((nf + 3) / 4), 1, 1, 256, 1, 1, 0, stream, args.data(), nullptr));
+    }
+    static const bool trace = [] { const char* e = getenv("SDFK_CELLS_TRACE"); return e && e[0] == '1'; }();
+    if (trace || g_cells_stats_on.load()) {                      // (debug: synchronises and reads the lists' statistics back)
+        HIPCHK(hipStreamSynchronize(stream));
+        std::vector<uint2> sp(nf);
+        unsigned head = 0;
+        HIPCHK(hipMemcpy(sp.data(), b + o_fspan, 8 * nf, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&head, b + o_head, 4, hipMemcpyDeviceToHost));
+        unsigned long long sum = 0, all = 0, empty = 0, mx = 0;
+        for (const uint2& x : sp) {
+            if (x.y == 0xffffffffu) ++all;
+            else { sum += x.y; mx = std::max<unsigned long long>(mx, x.y); if (x.y == 0) ++empty; }
+        }
+        {
+            std::lock_guard<std::mutex> lk(g_cells_stats_mu);
+            g_cells_stats[0] = (long long)nf; g_cells_stats[1] = (long long)nc; g_cells_stats[2] = (long long)head;
+            g_cells_stats[3] = (long long)cap; g_cells_stats[4] = (long long)sum; g_cells_stats[5] = (long long)mx;
+            g_cells_stats[6] = (long long)all; g_cells_stats[7] = (long long)empty;
+        }
+        if (trace) fprintf(stderr, "[sdfk cells] %d members: fine %ux%ux%u = %llu cells (2^%u planes x 2^%u blocks x 2^%u windows), coarse %llu; pool %u of %llu entries; "
+                "fine lists: mean %.1f max %llu, %llu without a list, %llu empty\n", p->chain_members, fine.ncx, fine.ncy, fine.ncz, nf, fine.lx, fine.ly, fine.lz, nc,
+                head, cap, (double)sum / (double)std::max<unsigned long long>(1, nf - all - empty), mx, all, empty);
     }
     out->lv = fine;
     out->sph = b + o_fsph;

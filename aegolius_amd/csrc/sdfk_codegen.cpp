@@ -461,7 +461,7 @@ struct sdfk_rowmeta {
 #endif
 #ifdef SDFK_CHAIN
 #ifdef SDFK_CELLS
-    unsigned short alist[SDFK_RNBRICK][SDFK_ALIST_CAP];                // the children that run, in order (more: nalive = ALL)
+    unsigned alist[SDFK_RNBRICK][SDFK_ALIST_CAP];                      // RECORDS of the children that run, in order (more: nalive = ALL)
     unsigned inside[SDFK_RNBRICK];                                     // every point of the brick lies in its cell's sphere
 #else
     unsigned short alist[SDFK_RNBRICK][SDFK_NLEAF];                    // the children that run, in order
@@ -504,7 +504,7 @@ struct sdfk_cells {
     sdfk_celllevel lv;                          // the level the bricks look at (the finest)
     const float4* __restrict__ sph;             // per cell: centre, radius (< 0: no such cell)
     const uint2* __restrict__ span;             // per cell: first entry, entries (SDFK_ALL_ALIVE: no list — probe every member)
-    const unsigned short* __restrict__ cand;    // the lists
+    const unsigned* __restrict__ cand;          // the lists: one RECORD per member (sdfk_member_record: kind and parameter block)
     unsigned enabled, pad;
 };
 #endif
@@ -810,13 +810,16 @@ static __device__ __forceinline__ void sdfk_chain_fold(sdfk_rowmeta* meta, int b
 #ifdef SDFK_CELLS
 // rows of row block rb plus the cell of brick (rb, window c) and that cell's sphere (wave-uniform; scalar loads)
 static __device__ __forceinline__ void sdfk_brick_cell(const sdfk_rowgeom& g, const sdfk_cells& cl, unsigned rb, unsigned c,
-                                                       long long& r0, long long& rend, unsigned& cell, float4& S) {
+                                                       long long& r0, long long& rend, uint2& span, float4& S) {
     unsigned slot, blk;
     sdfk_block_rows(g, rb, r0, rend, &slot, &blk);
     const unsigned sx = slot == 0xffffffffu ? 0u : cl.lv.xoff + slot;
-    cell = ((sx >> cl.lv.lx) * cl.lv.ncy + (blk >> cl.lv.ly)) * cl.lv.ncz + (c >> cl.lv.lz);
+    const unsigned cell = ((sx >> cl.lv.lx) * cl.lv.ncy + (blk >> cl.lv.ly)) * cl.lv.ncz + (c >> cl.lv.lz);
     S = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+    span = make_uint2(0u, SDFK_ALL_ALIVE);
     if (cl.enabled) {
+        const uint2 sp = cl.span[cell];
+        span = make_uint2(__builtin_amdgcn_readfirstlane(sp.x), __builtin_amdgcn_readfirstlane(sp.y));
         const float4 t = cl.sph[cell];
 #ifdef SDFK_FLAT
         S = make_float4(t.x, t.z, t.y, t.w);                   // (the registers of phase A hold (x, z, y))
@@ -830,28 +833,30 @@ static __device__ __forceinline__ void sdfk_brick_cell(const sdfk_rowgeom& g, co
 // The same decision from the CELL's candidate list: one member per lane, evaluated at the brick's centre on the spot (no
 // table of leaf values in LDS) — the first 64 stay in a register, longer lists are evaluated a second time for the
 // comparison. A brick that is not inside its cell's sphere, or whose cell has no list, takes every member.
-static __device__ __forceinline__ void sdfk_chain_fold_cells(sdfk_rowmeta* meta, int b, int lane, const sdfk_cells& cl, unsigned cell,
-                                                             const float* __restrict__ PRM, const float* __restrict__ TAB) {
+// `sp` (the cell's span) and `first` (this lane's entry of the first batch) were loaded BEFORE the coordinates were waited
+// for, so the only memory round trip left between the bounds and the decision is the members' parameters.
+static __device__ __forceinline__ void sdfk_chain_fold_cells(sdfk_rowmeta* meta, int b, int lane, const sdfk_cells& cl, uint2 sp,
+                                                             unsigned first, const float* __restrict__ PRM,
+                                                             const float* __restrict__ TAB) {
     const float4 cc = meta->bound[b];
     const V3T<float> ctr = {cc.x, cc.y, cc.z};
     const float rho = cc.w, cmag = 1e-6f * (fabsf(cc.x) + fabsf(cc.y) + fabsf(cc.z) + rho);
     unsigned off = 0u, cnt = SDFK_NLEAF;
     bool listed = false;
-    if (cl.enabled && __builtin_amdgcn_readfirstlane(meta->inside[b]) != 0u) {
-        const uint2 sp = cl.span[cell];
-        const unsigned s0 = __builtin_amdgcn_readfirstlane(sp.x), s1 = __builtin_amdgcn_readfirstlane(sp.y);
-        if (s1 != SDFK_ALL_ALIVE) { off = s0; cnt = s1; listed = true; }
+    if (cl.enabled && __builtin_amdgcn_readfirstlane(meta->inside[b]) != 0u && sp.y != SDFK_ALL_ALIVE) {
+        off = sp.x; cnt = sp.y; listed = true;
     }
     float m = 3.0e38f, e0 = 3.0e38f;
-    unsigned k0 = 0u;
+    unsigned r0 = 0u;
 #pragma unroll 1
     for (unsigned j0 = 0u; j0 < cnt; j0 += 64u) {
         const unsigned j = j0 + (unsigned)lane;
         const bool in = j < cnt;
-        const unsigned k = in ? (listed ? (unsigned)cl.cand[off + j] : j) : 0u;
+        unsigned rec = 0u;
+        if (in) rec = listed ? (j0 == 0u ? first : cl.cand[off + j]) : sdfk_member_record(j);
         float e = 3.0e38f;
-        if (in) e = SDFK_CHAIN_SGN * sdfk_leaf<float>(k, ctr, PRM, TAB);
-        if (j0 == 0u) { e0 = e; k0 = k; }
+        if (in) e = SDFK_CHAIN_SGN * sdfk_leaf_rec<float>(rec, ctr, PRM, TAB);
+        if (j0 == 0u) { e0 = e; r0 = rec; }
         m = fminf(m, e);
     }
 #pragma unroll
@@ -862,17 +867,17 @@ static __device__ __forceinline__ void sdfk_chain_fold_cells(sdfk_rowmeta* meta,
     for (unsigned j0 = 0u; j0 < cnt; j0 += 64u) {
         const unsigned j = j0 + (unsigned)lane;
         const bool in = j < cnt;
-        unsigned k = k0;
+        unsigned rec = r0;
         float e = e0;
         if (j0 != 0u) {
-            k = in ? (listed ? (unsigned)cl.cand[off + j] : j) : 0u;
+            rec = in ? (listed ? cl.cand[off + j] : sdfk_member_record(j)) : 0u;
             e = 3.0e38f;
-            if (in) e = SDFK_CHAIN_SGN * sdfk_leaf<float>(k, ctr, PRM, TAB);
+            if (in) e = SDFK_CHAIN_SGN * sdfk_leaf_rec<float>(rec, ctr, PRM, TAB);
         }
         const bool run = in && !(e - m >= thr0 + 1e-6f * fabsf(e));
         const unsigned long long bits = __ballot(run);
         const unsigned pos = n_out + (unsigned)__builtin_popcountll(bits & ((1ull << lane) - 1ull));
-        if (run && pos < SDFK_ALIST_CAP) meta->alist[b][pos] = (unsigned short)k;
+        if (run && pos < SDFK_ALIST_CAP) meta->alist[b][pos] = rec;
         n_out += (unsigned)__builtin_popcountll(bits);
     }
     if (lane == 0) meta->nalive[b] = n_out <= SDFK_ALIST_CAP ? n_out : SDFK_ALL_ALIVE;
@@ -902,14 +907,17 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
     sdfk_rowregs hregs[SDFK_RWBRICKS];
     bool live[SDFK_RWBRICKS];
 #ifdef SDFK_CELLS
-    unsigned cellid[SDFK_RWBRICKS];
+    uint2 cspan[SDFK_RWBRICKS];
+    unsigned cfirst[SDFK_RWBRICKS];
     float4 csph[SDFK_RWBRICKS];
 #endif
 #pragma unroll
     for (int j = 0; j < SDFK_RWBRICKS; ++j) {
         long long r0, rend;
 #ifdef SDFK_CELLS
-        sdfk_brick_cell(g, cl, rb, c, r0, rend, cellid[j], csph[j]);
+        sdfk_brick_cell(g, cl, rb, c, r0, rend, cspan[j], csph[j]);
+        cfirst[j] = 0u;                                          // the lane's entry of the list's first batch: in flight with the coordinates
+        if (cspan[j].y != SDFK_ALL_ALIVE && (unsigned)lane < cspan[j].y) cfirst[j] = cl.cand[cspan[j].x + (unsigned)lane];
 #else
         sdfk_block_rows(g, rb, r0, rend);
 #endif
@@ -928,14 +936,17 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
 #else
 #ifdef SDFK_CELLS
     bool live[SDFK_RWBRICKS];
-    unsigned cellid[SDFK_RWBRICKS];
+    uint2 cspan[SDFK_RWBRICKS];
+    unsigned cfirst[SDFK_RWBRICKS];
 #endif
 #pragma unroll
     for (int j = 0; j < SDFK_RWBRICKS; ++j) {
         long long r0, rend;
 #ifdef SDFK_CELLS
         float4 csph;
-        sdfk_brick_cell(g, cl, rb, c, r0, rend, cellid[j], csph);
+        sdfk_brick_cell(g, cl, rb, c, r0, rend, cspan[j], csph);
+        cfirst[j] = 0u;
+        if (cspan[j].y != SDFK_ALL_ALIVE && (unsigned)lane < cspan[j].y) cfirst[j] = cl.cand[cspan[j].x + (unsigned)lane];
         live[j] = q0 + j < g.nbricks && r0 < rend;
 #else
         sdfk_block_rows(g, rb, r0, rend);
@@ -963,13 +974,13 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
 #if defined(SDFK_CHAIN) && defined(SDFK_CELLS)
     // every wave folds ITS bricks from their cells' lists: nothing crosses waves any more (no probe centres, no table of
     // leaf values, two barriers fewer than the path below)
-#pragma unroll 1
+#pragma unroll
     for (int j = 0; j < SDFK_RWBRICKS; ++j) {
         const int b = wave * SDFK_RWBRICKS + j;
 #ifdef SDFK_ABLATE_PROBE
-        if (lane == 0) { meta->alist[b][0] = 0; meta->nalive[b] = live[j] ? 1u : 0u; }
+        if (lane == 0) { meta->alist[b][0] = sdfk_member_record(0u); meta->nalive[b] = live[j] ? 1u : 0u; }
 #else
-        if (live[j]) sdfk_chain_fold_cells(meta, b, lane, cl, cellid[j], PRM, TAB);
+        if (live[j]) sdfk_chain_fold_cells(meta, b, lane, cl, cspan[j], cfirst[j], PRM, TAB);
         else if (lane == 0) meta->nalive[b] = 0u;
 #endif
     }
@@ -1139,10 +1150,10 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
             const unsigned nal = __builtin_amdgcn_readfirstlane(meta.nalive[b]);
             const bool all_alive = nal == SDFK_ALL_ALIVE;
             const unsigned cnt = all_alive ? (unsigned)SDFK_NLEAF : nal;
-#define SDFK_ALIST(i) (all_alive ? (unsigned)(i) : (unsigned)meta.alist[b][i])
+#define SDFK_AREC(i) (all_alive ? sdfk_member_record(i) : meta.alist[b][i])
 #else
             const unsigned cnt = __builtin_amdgcn_readfirstlane(meta.nalive[b]);
-#define SDFK_ALIST(i) ((unsigned)meta.alist[b][i])
+#define SDFK_AREC(i) sdfk_member_record((unsigned)meta.alist[b][i])
 #endif
             f2 acc[SDFK_NP];
 #if SDFK_CHAIN_STAGED
@@ -1153,9 +1164,9 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
                 // parameters in SGPRs beat parameters read back from LDS — straight from the table
 #pragma unroll 1
                 for (unsigned i = 0; i < cnt; ++i) {
-                    const unsigned kk = __builtin_amdgcn_readfirstlane(SDFK_ALIST(i));
+                    const unsigned rec = __builtin_amdgcn_readfirstlane(SDFK_AREC(i));
                     f2 val[SDFK_NP];
-                    SDFK_EACH val[q] = sdfk_leaf<f2>(kk, P[q], PRM, TAB);
+                    SDFK_EACH val[q] = sdfk_leaf_rec<f2>(rec, P[q], PRM, TAB);
                     if (i == 0u) { SDFK_EACH acc[q] = val[q]; }
                     else { SDFK_EACH acc[q] = SDFK_CHAIN_CMB(acc[q], val[q], PRM); }
                 }
@@ -1170,10 +1181,10 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
 #pragma unroll 1
                 for (unsigned it = (unsigned)lane; it < nc * SDFK_NPLMAX; it += 64u) {
                     const unsigned ch = it / SDFK_NPLMAX, w = it - ch * SDFK_NPLMAX;
-                    const unsigned kk = SDFK_ALIST(c0 + ch);
-                    const unsigned at = sdfk_leaf_base[kk] + w;
+                    const unsigned rec = SDFK_AREC(c0 + ch);
+                    const unsigned at = (rec & 0xffffffu) + w;
                     meta.cprm[b][ch][w] = PRM[at < SDFK_NPARAMS ? at : SDFK_NPARAMS - 1u];
-                    if (w == 0u) meta.cgrp[b][ch] = sdfk_leaf_grp[kk];
+                    if (w == 0u) meta.cgrp[b][ch] = rec >> 24;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -1247,7 +1258,7 @@ struct sdfk_cellpass {
     uint2* __restrict__ span;                   // ... and list
     const float4* __restrict__ psph;            // the parent level's
     const uint2* __restrict__ pspan;
-    unsigned short* __restrict__ cand;          // the pool both levels allocate from
+    unsigned* __restrict__ cand;                // the pool both levels allocate from (records: sdfk_member_record)
     unsigned* __restrict__ head;                // its next free entry
     unsigned cap, ncells;
     float inflate, pad;                         // factor on the radius the LIST is computed for (coarse level: > 1, see below)
@@ -1343,22 +1354,45 @@ static __device__ __forceinline__ void sdfk_cells_kernel(const float* __restrict
         }
     }
     const float cmag = 1e-6f * (fabsf(c.x) + fabsf(c.y) + fabsf(c.z) + rho);
+    // The candidates' values at the centre: the first SDFK_CELL_NB batches of 64 stay in registers (one evaluation per
+    // candidate); what lies beyond is evaluated again for the count and once more for the write.
+#ifndef SDFK_CELL_NB
+#define SDFK_CELL_NB 8
+#endif
+    float ev[SDFK_CELL_NB];
+    unsigned rv[SDFK_CELL_NB];
     float m = 3.0e38f;
-#pragma unroll 1
-    for (unsigned j0 = 0u; j0 < cnt; j0 += 64u) {
+#pragma unroll
+    for (int bt = 0; bt < SDFK_CELL_NB; ++bt) {
+        const unsigned j = 64u * bt + (unsigned)lane;
+        ev[bt] = 3.0e38f;
+        rv[bt] = 0u;
+        if (64u * bt < cnt) {
+            if (j < cnt) {
+                rv[bt] = listed ? cp.cand[off + j] : sdfk_member_record(j);
+                ev[bt] = SDFK_CHAIN_SGN * sdfk_leaf_rec<float>(rv[bt], c, PRM, TAB);
+            }
+            m = fminf(m, ev[bt]);
+        }
+    }
+#pragma unroll 4
+    for (unsigned j0 = 64u * SDFK_CELL_NB; j0 < cnt; j0 += 64u) {
         const unsigned j = j0 + (unsigned)lane;
-        if (j < cnt) m = fminf(m, SDFK_CHAIN_SGN * sdfk_leaf<float>(listed ? (unsigned)cp.cand[off + j] : j, c, PRM, TAB));
+        if (j < cnt) m = fminf(m, SDFK_CHAIN_SGN * sdfk_leaf_rec<float>(listed ? cp.cand[off + j] : sdfk_member_record(j), c, PRM, TAB));
     }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) m = fminf(m, __shfl_xor(m, o));
     const float thr0 = 1.0001f * SDFK_CHAIN_KMAX * rho + SDFK_CHAIN_KMAX * cmag + 1e-6f * (1.0f + fabsf(m));
     unsigned total = 0u;
-#pragma unroll 1
-    for (unsigned j0 = 0u; j0 < cnt; j0 += 64u) {
+#pragma unroll
+    for (int bt = 0; bt < SDFK_CELL_NB; ++bt)
+        if (64u * bt < cnt) total += (unsigned)__builtin_popcountll(__ballot(64u * bt + (unsigned)lane < cnt && !(ev[bt] - m >= thr0 + 1e-6f * fabsf(ev[bt]))));
+#pragma unroll 4
+    for (unsigned j0 = 64u * SDFK_CELL_NB; j0 < cnt; j0 += 64u) {
         const unsigned j = j0 + (unsigned)lane;
         bool run = false;
         if (j < cnt) {
-            const float e = SDFK_CHAIN_SGN * sdfk_leaf<float>(listed ? (unsigned)cp.cand[off + j] : j, c, PRM, TAB);
+            const float e = SDFK_CHAIN_SGN * sdfk_leaf_rec<float>(listed ? cp.cand[off + j] : sdfk_member_record(j), c, PRM, TAB);
             run = !(e - m >= thr0 + 1e-6f * fabsf(e));
         }
         total += (unsigned)__builtin_popcountll(__ballot(run));
@@ -1371,18 +1405,26 @@ static __device__ __forceinline__ void sdfk_cells_kernel(const float* __restrict
         return;
     }
     unsigned n_out = 0u;
-#pragma unroll 1
-    for (unsigned j0 = 0u; j0 < cnt; j0 += 64u) {
+#pragma unroll
+    for (int bt = 0; bt < SDFK_CELL_NB; ++bt)
+        if (64u * bt < cnt) {
+            const bool run = 64u * bt + (unsigned)lane < cnt && !(ev[bt] - m >= thr0 + 1e-6f * fabsf(ev[bt]));
+            const unsigned long long bits = __ballot(run);
+            if (run) cp.cand[at + n_out + (unsigned)__builtin_popcountll(bits & ((1ull << lane) - 1ull))] = rv[bt];
+            n_out += (unsigned)__builtin_popcountll(bits);
+        }
+#pragma unroll 4
+    for (unsigned j0 = 64u * SDFK_CELL_NB; j0 < cnt; j0 += 64u) {
         const unsigned j = j0 + (unsigned)lane;
         bool run = false;
-        unsigned k = 0u;
+        unsigned rec = 0u;
         if (j < cnt) {
-            k = listed ? (unsigned)cp.cand[off + j] : j;
-            const float e = SDFK_CHAIN_SGN * sdfk_leaf<float>(k, c, PRM, TAB);
+            rec = listed ? cp.cand[off + j] : sdfk_member_record(j);
+            const float e = SDFK_CHAIN_SGN * sdfk_leaf_rec<float>(rec, c, PRM, TAB);
             run = !(e - m >= thr0 + 1e-6f * fabsf(e));
         }
         const unsigned long long bits = __ballot(run);
-        if (run) cp.cand[at + n_out + (unsigned)__builtin_popcountll(bits & ((1ull << lane) - 1ull))] = (unsigned short)k;
+        if (run) cp.cand[at + n_out + (unsigned)__builtin_popcountll(bits & ((1ull << lane) - 1ull))] = rec;
         n_out += (unsigned)__builtin_popcountll(bits);
     }
     if (lane == 0) cp.span[cell] = make_uint2(at, total);
@@ -2039,7 +2081,13 @@ struct Gen {
         }
         s += "        default: return sp<T>(0.0f);\n    }\n}\n"
              "template <typename T> static __device__ __forceinline__ T sdfk_leaf(unsigned k, V3T<T> C_0, const float* __restrict__ PRM, "
-             "const float* __restrict__ TAB) {\n    return sdfk_leaf_at<T>(sdfk_leaf_grp[k], C_0, PRM + sdfk_leaf_base[k], TAB);\n}\n";
+             "const float* __restrict__ TAB) {\n    return sdfk_leaf_at<T>(sdfk_leaf_grp[k], C_0, PRM + sdfk_leaf_base[k], TAB);\n}\n"
+             // a member as ONE word — kind << 24 | first parameter —: what the candidate lists and the bricks' survivor lists
+             // carry, so that nothing lies between a list entry and the member's parameters
+             "static __device__ __forceinline__ unsigned sdfk_member_record(unsigned k) { return ((unsigned)sdfk_leaf_grp[k] << 24) | sdfk_leaf_base[k]; }\n"
+             "template <typename T> static __device__ __forceinline__ T sdfk_leaf_rec(unsigned rec, V3T<T> C_0, const float* __restrict__ PRM, "
+             "const float* __restrict__ TAB) {\n    return sdfk_leaf_at<T>(rec >> 24, C_0, PRM + (rec & 0xffffffu), TAB);\n}\n";
+        if (groups.size() > 255 || n_params >= (1u << 24)) s += "#define SDFK_NO_CELLS 1   // (records hold 8 bits of kind, 24 of parameter offset)\n";
         const char* cmb = chain.is_max ? "cmb_max" : "cmb_min";
         // the result modifications, applied to an accumulator of type T
         s += "template <typename T> static __device__ __forceinline__ T sdfk_chain_tail(T V_chain, V3T<T> C_0, const float* __restrict__ PRM, "
@@ -2338,9 +2386,9 @@ static bool chain_analyse(Gen& g, int result_reg, const std::vector<sdfk_cullsit
     const std::vector<sdfk_cullsite>* best = nullptr;
     for (const auto& kv : by_start)
         if (!best || kv.second.size() > best->size()) best = &kv.second;
-    // (at most 4096 leaves — the lowering keeps 4095 sites —: 13 bytes of LDS per leaf and workgroup for the leaf values and
-    //  the lists, 54 KB at 4096: two workgroups per CU)
-    if (!best || best->size() + 1 < chain_min_leaves() || best->size() + 1 > 4096) return false;
+    // (at most 32768 leaves — the lowering keeps 32767 sites; round 3: 4096, when every leaf's value and list slot lived in
+    //  LDS. With candidate lists per cell the workgroup holds 128 survivors per brick whatever the size of the chain.)
+    if (!best || best->size() + 1 < chain_min_leaves() || best->size() + 1 > 32768) return false;
     g.chain_sites = *best;
     std::sort(g.chain_sites.begin(), g.chain_sites.end(), [](const sdfk_cullsite& x, const sdfk_cullsite& y) { return x.comb < y.comb; });
     for (const sdfk_cullsite& t : *sites_all) {                     // a site inside the chain that is not of the chain: no
@@ -2352,6 +2400,7 @@ static bool chain_analyse(Gen& g, int result_reg, const std::vector<sdfk_cullsit
     g.region_lo = g.chain_sites.front().a0;
     g.region_hi = g.chain_sites.back().comb;
     bool ok = g.analyse_leaves() && g.analyse_chain(result_reg) && g.leaves_contiguous();
+    if (ok && g.groups.size() > 255) ok = false;                   // (a member travels as kind << 24 | first parameter)
     // (a member is compiled inline: beyond 4096 members the lowering drops the sites of the first levels, and what they
     //  combined becomes ONE member of hundreds of primitives — minutes of hiprtc; such programs stay where they were)
     for (size_t k = 0; ok && k < g.leaves.size(); ++k)
@@ -2400,7 +2449,12 @@ std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32
             if (flat2) g.s += "\n#define SDFK_FLAT 1\n";
             g.s += "\n#define SDFK_NP 4\n#define SDFK_EACH _Pragma(\"unroll\") for (int q = 0; q < SDFK_NP; ++q)\n"
                    "#define SDFK_SIMT 1\n#define SDFK_NSUB 1\n"
-                   "#ifndef SDFK_NO_CELLS\n#define SDFK_CELLS 1         // candidate lists per cell (sdfk_spec_cells; -DSDFK_NO_CELLS: the probe of every member)\n#endif\n"
+                   // candidate lists per cell (sdfk_spec_cells) for chains of more than 64 members; up to 64 the probe of every
+                   // member by the whole workgroup stays (measured on the 50-child flat union at 16385^2: 0.88 ms against 1.04
+                   // with the per-wave fold and 1.68 with lists — three dependent memory round trips per brick for a probe
+                   // that costs 0.09 ms)
+                   "#ifndef SDFK_CELLS_MIN_LEAVES\n#define SDFK_CELLS_MIN_LEAVES 64\n#endif\n"
+                   "#if !defined(SDFK_NO_CELLS) && SDFK_NLEAF > SDFK_CELLS_MIN_LEAVES\n#define SDFK_CELLS 1\n#endif\n"
                    "#ifndef SDFK_LEAF_UNROLL\n#define SDFK_LEAF_UNROLL _Pragma(\"unroll 4\")\n#endif\n";
             g.s += kSimtGeometry;
             // (a lane per LEAF walking the centres pays off once there are more leaves than lanes; below that a lane per

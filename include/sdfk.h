@@ -61,7 +61,7 @@ sdfk_program* sdfk_program_create(const uint32_t* code, size_t n_instr, const fl
 void sdfk_program_destroy(sdfk_program* prog);
 /* Replace the parameter values of a program in place (same topology, new shape parameters). */
 int sdfk_program_set_params(sdfk_program* prog, const float* params, size_t n_params);
-/* Brick culling (optional, before first use of the program): n_sites rows (at most 4095) {combiner index, a_start,
+/* Brick culling (optional, before first use of the program): n_sites rows (at most 32767) {combiner index, a_start,
  * a_end, b_start, b_end} naming, for min/max-type combiners, the instruction ranges that produce the
  * two operands, and k[i] = L_a + L_b, the sum of the Lipschitz constants of the operand fields with
  * respect to the input point. The specialised kernels then probe the tree per BRICK — 32 points x 16 grid rows when the
@@ -71,7 +71,7 @@ int sdfk_program_set_params(sdfk_program* prog, const float* params, size_t n_pa
  * How the sites are used: up to 64 of them as two mask bits each (the widest, in program order; the line-brick kernel
  * takes 31). The probe runs lane-parallel when every leaf range (a range without a site inside) reads nothing but the
  * input point: all leaves at all probe centres on the lanes of the workgroup, 8 / 4 / 1 centres per brick. A program
- * that holds an n-ary hard min / max over 17 to 4096 such leaves (CombineGeometry("UNION").combine(*many)) runs in
+ * that holds an n-ary hard min / max over 17 to 32768 such leaves (CombineGeometry("UNION").combine(*many)) runs in
  * "chain mode" with all of the chain's sites: one function per kind of leaf, tables of parameter offsets, a list of
  * surviving leaves per brick; it builds in about a second whatever its size. The chain may be the whole program (with
  * value modifications of its result) or an operand of a small program around it — clipped, blended, subtracted: those
@@ -103,6 +103,11 @@ int sdfk_program_compile_check(sdfk_program* prog, size_t* code_size);
 #define SDFK_FLAVOUR_XY 0x200
 /* Build (or fetch from the caches) ONE flavour, GPU or not: its code-object size and the seconds this call took. */
 int sdfk_program_compile_flavour(sdfk_program* prog, int flavour, size_t* code_size, double* seconds);
+/* Test aid: with enable != 0 every chain-mode row-block launch synchronises after the pre-pass of its candidate lists and
+ * records { fine cells, coarse cells, pool entries used, pool capacity, sum of the fine lists' lengths, longest fine list,
+ * fine cells without a list (their bricks probe every member), empty cells }; out8 (nullable) receives the record of the
+ * last such launch and clears it. */
+void sdfk_debug_cells_stats(int enable, long long* out8);
 /* Test aid: build one flavour the way BACKGROUND builds are run — in a child process (aegolius_amd/sdfk_rtc_helper,
  * csrc/sdfk_rtc_helper.c) — and return the code-object size; nothing is cached. While the interpreter kernel serves the
  * first calls of a new tree shape (SDFK_MODE_AUTO) the compiler never runs inside the calling process: hiprtc holds a

@@ -888,18 +888,16 @@ def test_very_large_trees_run_without_a_compile(engine, golden_inputs):
     check("smooth_union_of_100_spheres", smooth, sdf_oracle.evaluate(acc, golden_inputs))
 
 
-def test_the_largest_chain_has_4096_members(engine):
-    """4096 spheres (the lowering keeps 4095 cull sites): still one chain — culled row blocks, the un-culled chain kernel
-    and the interpreter agree bit for bit on a small grid, and with the oracle on a sample; one member more and the
-    program is no chain (mask kernels / interpreter)."""
+def test_chains_of_thousands_of_members(engine):
+    """16,384 spheres: one chain (round 3 stopped at 4096, when every member's value lived in LDS; with candidate lists
+    per cell a workgroup holds 128 survivors per brick whatever the chain's size) — culled row blocks, the un-culled chain
+    kernel and the interpreter agree bit for bit on a small grid, and with the oracle on a sample. 32,768 members is the
+    limit (the lowering keeps 32,767 cull sites); a few members more still run as a chain whose first member is a pair."""
     from aegolius_amd import workloads
-    tree = workloads.sphere_union(ns, 4096, seed=12, radius=0.03)
+    tree = workloads.sphere_union(ns, 16384, seed=12, radius=0.02)
     prog = engine.Program.from_lowered(lower_geometry(tree))
-    assert prog.chain_members == 4096
-    # (a few members more: the lowering drops the sites of the first levels, their operands become one member — a pair, a
-    #  triple; beyond a member of 256 instructions the program is no chain any more: mask kernels / interpreter)
-    assert engine.Program.from_lowered(lower_geometry(workloads.sphere_union(ns, 4098, seed=12, radius=0.03))).chain_members == 4096
-    assert engine.Program.from_lowered(lower_geometry(workloads.sphere_union(ns, 4300, seed=12, radius=0.03))).chain_members == 0
+    assert prog.chain_members == 16384
+    assert engine.Program.from_lowered(lower_geometry(workloads.sphere_union(ns, 4300, seed=12, radius=0.03))).chain_members == 4300
     co, _ = ns.generate_grid((2, 2, 2), (20, 24, 64))
     co32 = co.astype(np.float32)
     n = co32.shape[1]
@@ -1283,6 +1281,75 @@ def test_chain_mode_is_bit_exact(name, engine):
     plain = _device_eval(engine, prog, pts, pts.shape[1], pts.shape[1], 0, engine.MODE_NOCULL)
     rows = _device_eval(engine, prog, pts, pts.shape[1], pts.shape[1], 0, engine.MODE_SPECIALIZED, row_len=48)
     np.testing.assert_array_equal(rows, plain)
+
+
+def _cells_stats(engine, enable=1):
+    rec = (ctypes.c_longlong * 8)()
+    engine.lib().sdfk_debug_cells_stats(enable, rec)
+    keys = ("fine_cells", "coarse_cells", "pool_used", "pool_cap", "sum_lists", "longest", "without_list", "empty")
+    return dict(zip(keys, [int(v) for v in rec]))
+
+
+@pytest.mark.parametrize("members", [100, 300])
+def test_candidate_lists_are_exact_and_used(members, engine, monkeypatch):
+    """Chains of more than 64 members probe, per brick, the CANDIDATE LIST of the brick's cell (pre-pass sdfk_spec_cells:
+    100 members — one level of cells; 300 — a coarse level first). Bit for bit the un-culled chain kernel on: a whole
+    grid with the plane hint, x-slabs that start in the middle of a plane, the same points with the planes in a shuffled
+    order and with jittered coordinates (bricks that are NOT inside the sphere their cell derived from its corner points:
+    they must fall back to every member), a pool too small for the lists (cells without a list), and from axis tables.
+    The statistics show that lists exist, are short, and that the starved pool leaves cells without one."""
+    from aegolius_amd import workloads
+    tree = workloads.sphere_union(ns, members, seed=21, radius=0.07)
+    prog = engine.Program.from_lowered(lower_geometry(tree))
+    assert prog.chain_members == members
+    co, _ = ns.generate_grid((2.1, 2.1, 2.1), (36, 70, 130))
+    co32 = co.astype(np.float32)
+    n0, n1, n2 = [int(a.size) for a in co.grid_axes]
+    n = co32.shape[1]
+    _cells_stats(engine, 1)
+    try:
+        plain = _device_eval(engine, prog, co32, n, n, 0, engine.MODE_NOCULL)
+        rows = _device_eval(engine, prog, co32, n, n, 0, engine.MODE_SPECIALIZED, row_len=n2, plane_rows=n1)
+        np.testing.assert_array_equal(rows, plain)
+        st = _cells_stats(engine)
+        assert st["fine_cells"] > 0 and st["without_list"] == 0 and st["pool_used"] <= st["pool_cap"], st
+        assert (st["coarse_cells"] > 0) == (members >= 128), st
+        filled = st["fine_cells"] - st["empty"]
+        assert 0 < st["sum_lists"] / filled < 0.6 * members, st          # the lists are much shorter than the chain
+        # no plane hint: cells of rows x points only
+        np.testing.assert_array_equal(_device_eval(engine, prog, co32, n, n, 0, engine.MODE_SPECIALIZED, row_len=n2), plain)
+        # x-slabs of whole rows that start inside a plane
+        for first_row, rows_n in ((17, 5 * n1 + 3), (n1 - 1, 2 * n1 + 1), (3, n1 - 10)):
+            a, b = first_row * n2, (first_row + rows_n) * n2
+            part = _device_eval(engine, prog, co32[:, a:b], b - a, b - a, 0, engine.MODE_SPECIALIZED, row_len=n2, plane_rows=n1,
+                                first_row_in_plane=first_row % n1)
+            np.testing.assert_array_equal(part, plain[a:b])
+        # planes in a shuffled order / jittered coordinates: rows still have one x and one y, but a cell's corner points no
+        # longer bound it
+        rng = np.random.default_rng(members)
+        order = rng.permutation(n0)
+        idx = (order[:, None] * (n1 * n2) + np.arange(n1 * n2)[None, :]).ravel()
+        shuffled = _device_eval(engine, prog, co32[:, idx], n, n, 0, engine.MODE_SPECIALIZED, row_len=n2, plane_rows=n1)
+        np.testing.assert_array_equal(shuffled, plain[idx])
+        jit = co32 + rng.normal(0, 0.05, co32.shape).astype(np.float32)
+        np.testing.assert_array_equal(_device_eval(engine, prog, jit, n, n, 0, engine.MODE_SPECIALIZED, row_len=n2, plane_rows=n1),
+                                      _device_eval(engine, prog, jit, n, n, 0, engine.MODE_NOCULL))
+        # axis tables
+        np.testing.assert_array_equal(prog.eval_grid_host([a.astype(np.float32) for a in co.grid_axes]), plain)
+        # a pool that cannot hold the lists: cells without one, same field
+        monkeypatch.setenv("SDFK_CELLS_POOL", "40")
+        _cells_stats(engine)
+        starved = _device_eval(engine, prog, co32, n, n, 0, engine.MODE_SPECIALIZED, row_len=n2, plane_rows=n1)
+        np.testing.assert_array_equal(starved, plain)
+        assert _cells_stats(engine)["without_list"] > 0
+        monkeypatch.delenv("SDFK_CELLS_POOL")
+    finally:
+        _cells_stats(engine, 0)
+    with np.errstate(all="ignore"):
+        pick = np.random.default_rng(3).choice(n, 3000, replace=False)
+        ref = sdf_oracle.evaluate(tree, co32[:, pick].astype(np.float64))
+    err, bad = violations(plain[pick], ref)
+    assert not bad.any(), float(np.nanmax(err))
 
 
 def _clustered_scene(kind="UNION", groups=8, members=25, seed=3, nested=True):
