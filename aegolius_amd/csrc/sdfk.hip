@@ -1305,7 +1305,7 @@ struct CellLevelH {           // mirrors sdfk_celllevel
 struct CellsArg {             // mirrors sdfk_cells
     CellLevelH lv;
     const void *sph, *span, *cand;
-    unsigned enabled, pad;
+    unsigned enabled, ncells;
 };
 struct CellPassArg {          // mirrors sdfk_cellpass
     CellLevelH lv, parent;
@@ -1313,7 +1313,8 @@ struct CellPassArg {          // mirrors sdfk_cellpass
     const void *psph, *pspan;
     void* cand;
     unsigned* head;
-    unsigned cap, ncells;
+    unsigned base, shard_cap;
+    unsigned ncells, pad0;
     float inflate, pad;
 };
 static bool parse3(const char* e, unsigned* v) {
@@ -1357,16 +1358,20 @@ static int prepare_cells(sdfk_program* p, DevState* d, hipFunction_t cells_fn, c
     if (nf == 0 || nf > 0x3fffffffull || nc > 0x3fffffffull) return 0;
     // pool: room for 48 entries per fine cell and 1024 per coarse cell (measured lists: a handful / a few hundred); a cell
     // that finds the pool full makes its bricks probe every member — slower, never wrong
-    // the coarse level can never run out (every cell could keep every member: members x cells entries, a few MB); the fine
-    // level gets what is left of a budget that covers 256 entries per cell (measured lists: a handful to a few dozen)
-    const unsigned long long members = (unsigned long long)p->chain_members;
-    unsigned long long cap = std::min<unsigned long long>(0x3fffffffull, nc * members + std::min(nf * members, 256ull * nf + (16ull << 20)));
+    // Pool of list entries, per level 256 shards with an allocation head each (sdfk_cells_kernel). The coarse level can
+    // never run out — a shard holds every member for each of its cells —; the fine level gets 256 entries per cell plus
+    // slack (measured lists: a handful to a few dozen entries, a few hundred in scenes where thousands of members overlap).
+    const unsigned long long members = (unsigned long long)p->chain_members, shards = 256;
+    unsigned long long cshard = ((nc + shards - 1) / shards) * members;
+    unsigned long long fshard = (std::min(nf * members, 256ull * nf + (16ull << 20)) + shards - 1) / shards;
     if (const char* e = getenv("SDFK_CELLS_POOL")) {             // (tests: a pool too small for the lists)
         const long long v = atoll(e);
-        if (v > 0) cap = std::min<unsigned long long>(cap, (unsigned long long)v);
+        if (v > 0) fshard = std::min<unsigned long long>(fshard, (unsigned long long)v);
     }
+    if (shards * (cshard + fshard) > 0x3fffffffull) return 0;   // (no lists: still correct)
+    const unsigned long long cap = shards * (cshard + fshard);
     const size_t o_fsph = 0, o_fspan = o_fsph + 16 * nf, o_csph = o_fspan + 8 * nf, o_cspan = o_csph + 16 * nc,
-                 o_head = (o_cspan + 8 * nc + 15) & ~(size_t)15, o_pool = o_head + 16, total = o_pool + 4 * cap + 64;
+                 o_head = (o_cspan + 8 * nc + 63) & ~(size_t)63, o_pool = o_head + 2 * 64 * shards, total = o_pool + 4 * cap + 64;
     CellScratch* cs;
     {
         std::lock_guard<std::mutex> lk(p->mu);
@@ -1383,15 +1388,15 @@ static int prepare_cells(sdfk_program* p, DevState* d, hipFunction_t cells_fn, c
         cs->bytes = total + total / 4;
     }
     char* b = cs->buf;
-    HIPCHK(hipMemsetAsync(b + o_head, 0, 16, stream));
+    HIPCHK(hipMemsetAsync(b + o_head, 0, 2 * 64 * shards, stream));
     CellPassArg cp{};
     cp.cand = b + o_pool;
-    cp.head = reinterpret_cast<unsigned*>(b + o_head);
-    cp.cap = (unsigned)cap;
     if (coarse) {
         // a coarse cell answers for 1.3 x its circumsphere: room for the circumspheres of the fine cells inside it
         cp.lv = crs; cp.parent = CellLevelH{}; cp.sph = b + o_csph; cp.span = b + o_cspan; cp.psph = nullptr; cp.pspan = nullptr;
         cp.ncells = (unsigned)nc; cp.inflate = 1.3f;
+        cp.head = reinterpret_cast<unsigned*>(b + o_head);
+        cp.base = 0u; cp.shard_cap = (unsigned)cshard;
         std::vector<void*> args = {(void*)&prm, (void*)&tab};
         for (int i = 0; i < n_src; ++i) args.push_back(src[i]);
         RowGeom g2 = rg;
@@ -1402,6 +1407,8 @@ static int prepare_cells(sdfk_program* p, DevState* d, hipFunction_t cells_fn, c
     cp.lv = fine; cp.parent = coarse ? crs : CellLevelH{}; cp.sph = b + o_fsph; cp.span = b + o_fspan;
     cp.psph = coarse ? b + o_csph : nullptr; cp.pspan = coarse ? b + o_cspan : nullptr;
     cp.ncells = (unsigned)nf; cp.inflate = 1.0f;
+    cp.head = reinterpret_cast<unsigned*>(b + o_head + 64 * shards);
+    cp.base = (unsigned)(shards * cshard); cp.shard_cap = (unsigned)fshard;
     {
         std::vector<void*> args = {(void*)&prm, (void*)&tab};
         for (int i = 0; i < n_src; ++i) args.push_back(src[i]);
@@ -1416,7 +1423,11 @@ static int prepare_cells(sdfk_program* p, DevState* d, hipFunction_t cells_fn, c
         std::vector<uint2> sp(nf);
         unsigned head = 0;
         HIPCHK(hipMemcpy(sp.data(), b + o_fspan, 8 * nf, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(&head, b + o_head, 4, hipMemcpyDeviceToHost));
+        {
+            std::vector<unsigned> heads(2 * 16 * shards);
+            HIPCHK(hipMemcpy(heads.data(), b + o_head, 2 * 64 * shards, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < heads.size(); i += 16) head += heads[i];
+        }
         unsigned long long sum = 0, all = 0, empty = 0, mx = 0;
         for (const uint2& x : sp) {
             if (x.y == 0xffffffffu) ++all;
@@ -1437,6 +1448,7 @@ static int prepare_cells(sdfk_program* p, DevState* d, hipFunction_t cells_fn, c
     out->span = b + o_fspan;
     out->cand = b + o_pool;
     out->enabled = 1u;
+    out->ncells = (unsigned)nf;
     return 0;
 }
 
@@ -1471,13 +1483,23 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
     long long n4 = vec_ok ? (n / 4) * 4 : 0;
     long long tail = n - n4;
 
-    // Very large trees: hiprtc needs ~0.1-0.3 s per primitive and flavour (minutes beyond several hundred
-    // primitives); in AUTO mode they stay on the interpreter kernel, which needs no compilation
-    // (SDFK_SPECIALIZE_LIMIT instructions, default 1200 ~ 400 primitives; MODE_SPECIALIZED always specialises).
+    // Build time bounds (programs that are not chains: those are table-driven and build in under a second whatever their
+    // size). hiprtc's time grows faster than the program — profiles/r04_build_time.txt, left-deep smooth-union chains on
+    // the build container's CPU: row blocks 1 / 4 / 8 / 21 / 102 s at 29 / 89 / 179 / 299 / 449 instructions, line bricks
+    // 0.8 / 3 / 4 / 6 / 12 / 22 / 55 / 105 s at ... 449 / 599 / 899 / 1199, the plain kernel 0.4 ... 9 / 17 / 41 / 76 s —,
+    // so each flavour has a size up to which it is built, for a budget of about 20 s per build:
+    //   row blocks up to SDFK_ROWS_LIMIT instructions (300), line bricks (or, for unaligned arrays, the plain kernel) up to
+    //   SDFK_SPECIALIZE_LIMIT (600); beyond that AUTO stays on the interpreter kernel, which needs no compilation.
+    // MODE_SPECIALIZED / NOCULL always build (the caller asked for the kernel and waits), with the same choice of flavour.
     static const long long spec_limit = [] {
         const char* e = getenv("SDFK_SPECIALIZE_LIMIT");
-        const long long v = e ? atoll(e) : 1200;
-        return v > 0 ? v : 1200;
+        const long long v = e ? atoll(e) : 600;
+        return v > 0 ? v : 600;
+    }();
+    static const long long rows_limit = [] {
+        const char* e = getenv("SDFK_ROWS_LIMIT");
+        const long long v = e ? atoll(e) : 300;
+        return v > 0 ? v : 300;
     }();
     if (mode == SDFK_MODE_AUTO && (long long)(p->code.size() / 2) > spec_limit && p->interp_ok && !p->chain_mode && !d_flags)
         mode = SDFK_MODE_INTERPRET;
@@ -1496,6 +1518,13 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
                                grid->n2 > 1 ? (grid->start / grow) % (long long)grid->n1 : 0, p->chain_mode))   //  knows blocks of 16 rows)
             flavour = grid->n2 > 1 ? SDFK_FL_ROWS_GRID : SDFK_FL_ROWS2D_GRID;
         else if (grid && vec_ok && !p->chain_mode && !d_flags) flavour = SDFK_FL_TILE_GRID;
+        // (too big for a row-block build within the budget: the line-brick kernel where the call allows it, else un-culled)
+        if (!p->chain_mode && (long long)(p->code.size() / 2) > rows_limit &&
+            (flavour == SDFK_FL_ROWS_ARRAY || flavour == SDFK_FL_ROWS2D_ARRAY || flavour == SDFK_FL_ROWS_GRID || flavour == SDFK_FL_ROWS2D_GRID)) {
+            const bool is_arr = arr != nullptr;
+            if (vec_ok && !d_flags && !xy) flavour = is_arr ? SDFK_FL_TILE_ARRAY : SDFK_FL_TILE_GRID;
+            else if (!d_flags) flavour = is_arr ? SDFK_FL_PLAIN_ARRAY : SDFK_FL_PLAIN_GRID;
+        }
     }
     std::shared_ptr<SpecModule> sk;
     if (mode != SDFK_MODE_INTERPRET) {

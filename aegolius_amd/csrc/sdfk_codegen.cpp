@@ -445,9 +445,10 @@ typedef float sdfk_f4u __attribute__((ext_vector_type(4), aligned(4)));
 
 #ifdef SDFK_CELLS
 #ifndef SDFK_ALIST_CAP
-#define SDFK_ALIST_CAP (SDFK_NLEAF < 128 ? SDFK_NLEAF : 128)     // survivors a brick's list holds (more: nalive = ALL)
+#define SDFK_ALIST_CAP (SDFK_NLEAF < 192 ? SDFK_NLEAF : 192)     // survivors a brick's list holds in LDS
 #endif
 #define SDFK_ALL_ALIVE 0xffffffffu
+#define SDFK_LIST_ALIVE 0xfffffffeu
 #endif
 struct sdfk_rowmeta {
     float z[SDFK_RNBRICK][SDFK_RBRICK];         // [row of the brick][point of the window]
@@ -461,7 +462,8 @@ struct sdfk_rowmeta {
 #endif
 #ifdef SDFK_CHAIN
 #ifdef SDFK_CELLS
-    unsigned alist[SDFK_RNBRICK][SDFK_ALIST_CAP];                      // RECORDS of the children that run, in order (more: nalive = ALL)
+    unsigned alist[SDFK_RNBRICK][SDFK_ALIST_CAP];                      // RECORDS of the children that run, in order
+    uint2 aspan[SDFK_RNBRICK];                                         // more survivors than that: the cell's whole list runs (nalive = LIST)
     unsigned inside[SDFK_RNBRICK];                                     // every point of the brick lies in its cell's sphere
 #else
     unsigned short alist[SDFK_RNBRICK][SDFK_NLEAF];                    // the children that run, in order
@@ -505,7 +507,7 @@ struct sdfk_cells {
     const float4* __restrict__ sph;             // per cell: centre, radius (< 0: no such cell)
     const uint2* __restrict__ span;             // per cell: first entry, entries (SDFK_ALL_ALIVE: no list — probe every member)
     const unsigned* __restrict__ cand;          // the lists: one RECORD per member (sdfk_member_record: kind and parameter block)
-    unsigned enabled, pad;
+    unsigned enabled, ncells;
 };
 #endif
 // a / d for wave-uniform a, with inv = floor(2^32 / d) from the host: the estimate is never too large and at most a few
@@ -817,7 +819,8 @@ static __device__ __forceinline__ void sdfk_brick_cell(const sdfk_rowgeom& g, co
     const unsigned cell = ((sx >> cl.lv.lx) * cl.lv.ncy + (blk >> cl.lv.ly)) * cl.lv.ncz + (c >> cl.lv.lz);
     S = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
     span = make_uint2(0u, SDFK_ALL_ALIVE);
-    if (cl.enabled) {
+    // (the launch is padded with bricks beyond the last one: their row block does not exist, and neither does a cell for it)
+    if (cl.enabled && r0 < rend && cell < cl.ncells) {
         const uint2 sp = cl.span[cell];
         span = make_uint2(__builtin_amdgcn_readfirstlane(sp.x), __builtin_amdgcn_readfirstlane(sp.y));
         const float4 t = cl.sph[cell];
@@ -880,7 +883,12 @@ static __device__ __forceinline__ void sdfk_chain_fold_cells(sdfk_rowmeta* meta,
         if (run && pos < SDFK_ALIST_CAP) meta->alist[b][pos] = rec;
         n_out += (unsigned)__builtin_popcountll(bits);
     }
-    if (lane == 0) meta->nalive[b] = n_out <= SDFK_ALIST_CAP ? n_out : SDFK_ALL_ALIVE;
+    // more survivors than the list in LDS holds (dense scenes): the brick runs its cell's whole candidate list straight from
+    // memory — a superset in the chain's order — and every member only where there is no such list
+    if (lane == 0) {
+        meta->nalive[b] = n_out <= SDFK_ALIST_CAP ? n_out : (listed ? SDFK_LIST_ALIVE : SDFK_ALL_ALIVE);
+        meta->aspan[b] = make_uint2(off, cnt);
+    }
 }
 #endif
 
@@ -1148,9 +1156,10 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
 #ifdef SDFK_CELLS
             // (more survivors than the list holds — nalive = ALL —: every member, in order, straight from its index)
             const unsigned nal = __builtin_amdgcn_readfirstlane(meta.nalive[b]);
-            const bool all_alive = nal == SDFK_ALL_ALIVE;
-            const unsigned cnt = all_alive ? (unsigned)SDFK_NLEAF : nal;
-#define SDFK_AREC(i) (all_alive ? sdfk_member_record(i) : meta.alist[b][i])
+            const bool all_alive = nal == SDFK_ALL_ALIVE, list_alive = nal == SDFK_LIST_ALIVE;
+            const unsigned aoff = __builtin_amdgcn_readfirstlane(meta.aspan[b].x);
+            const unsigned cnt = all_alive ? (unsigned)SDFK_NLEAF : (list_alive ? __builtin_amdgcn_readfirstlane(meta.aspan[b].y) : nal);
+#define SDFK_AREC(i) (all_alive ? sdfk_member_record(i) : (list_alive ? cl.cand[aoff + (i)] : meta.alist[b][i]))
 #else
             const unsigned cnt = __builtin_amdgcn_readfirstlane(meta.nalive[b]);
 #define SDFK_AREC(i) sdfk_member_record((unsigned)meta.alist[b][i])
@@ -1258,9 +1267,10 @@ struct sdfk_cellpass {
     uint2* __restrict__ span;                   // ... and list
     const float4* __restrict__ psph;            // the parent level's
     const uint2* __restrict__ pspan;
-    unsigned* __restrict__ cand;                // the pool both levels allocate from (records: sdfk_member_record)
-    unsigned* __restrict__ head;                // its next free entry
-    unsigned cap, ncells;
+    unsigned* __restrict__ cand;                // the pool (records: sdfk_member_record)
+    unsigned* __restrict__ head;                // this level's SDFK_POOL_SHARDS allocation heads, 64 bytes apart
+    unsigned base, shard_cap;                   // shard h owns entries [base + h * shard_cap, base + (h + 1) * shard_cap)
+    unsigned ncells, pad0;
     float inflate, pad;                         // factor on the radius the LIST is computed for (coarse level: > 1, see below)
 };
 // point z of local row `row`
@@ -1359,6 +1369,7 @@ static __device__ __forceinline__ void sdfk_cells_kernel(const float* __restrict
 #ifndef SDFK_CELL_NB
 #define SDFK_CELL_NB 8
 #endif
+#define SDFK_POOL_SHARDS 256u                   // (host: prepare_cells)
     float ev[SDFK_CELL_NB];
     unsigned rv[SDFK_CELL_NB];
     float m = 3.0e38f;
@@ -1397,13 +1408,17 @@ static __device__ __forceinline__ void sdfk_cells_kernel(const float* __restrict
         }
         total += (unsigned)__builtin_popcountll(__ballot(run));
     }
+    // room for the list: a returning atomic add — on ONE word 19,000 cells would queue for 0.2 ms (about 90 such atomics
+    // per microsecond and address), so the pool is cut into SDFK_POOL_SHARDS shards with a head each, dealt by cell index
     unsigned at = 0u;
-    if (lane == 0) at = atomicAdd(cp.head, total);
+    const unsigned shard = cell & (SDFK_POOL_SHARDS - 1u);
+    if (lane == 0) at = atomicAdd(cp.head + 16u * shard, total);
     at = __shfl(at, 0);
-    if (at > cp.cap || total > cp.cap - at) {                   // the pool is full: bricks of this cell probe every member
+    if (at > cp.shard_cap || total > cp.shard_cap - at) {       // the shard is full: bricks of this cell probe every member
         if (lane == 0) cp.span[cell] = make_uint2(0u, SDFK_ALL_ALIVE);
         return;
     }
+    at += cp.base + shard * cp.shard_cap;
     unsigned n_out = 0u;
 #pragma unroll
     for (int bt = 0; bt < SDFK_CELL_NB; ++bt)

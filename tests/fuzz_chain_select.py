@@ -6,8 +6,10 @@ For each seed a random n-ary hard UNION / INTERSECT (9 .. 400 children of random
 random rounding / onion / rotation / position —, in a third of the larger scenes as nested groups with rigid transforms
 of their own, optionally with a value modification on top) on a random grid shape
 (odd / short / long rows, 2-D scenes on flat grids):
-  * the table-driven chain kernel with per-brick survivor lists (row blocks), its un-culled loop (MODE_NOCULL) and — up
-    to 120 children — the interpreter kernel: bit for bit;
+  * the table-driven chain kernel with per-brick survivor lists (row blocks; candidate lists per cell from 65 members
+    on), its un-culled loop (MODE_NOCULL) and — up to 120 children, and for every program that is no chain — the
+    interpreter kernel: bit for bit (programs that are no chain and lie beyond SDFK_SPECIALIZE_LIMIT = 600 instructions
+    are served by the interpreter kernel in the product: that kernel against the oracle);
   * the per-axis table flavour (sdfk_eval_grid_host) against the array flavour: bit for bit;
   * a sample of the field against the float64 oracle (1e-6, magnitude-aware as tests/test_gpu_parity.py);
   * fused selection (flag-writing kernels + compaction) for random thresholds against numpy.flatnonzero(field <= t) of
@@ -126,6 +128,9 @@ def device_eval(engine, prog, co32, mode, row_len=None, flat=False, misalign=0):
         lib.sdfk_free(vp(d_out))
 
 
+SPECIALIZE_LIMIT = int(os.environ.get("SDFK_SPECIALIZE_LIMIT", "600"))     # csrc/sdfk.hip, run(): the same default
+
+
 def main(first=9000, count=40):
     import aegolius_amd.cores as ns
     from aegolius_amd import _engine
@@ -146,18 +151,19 @@ def main(first=9000, count=40):
         chain = prog.chain_members > 0
         chain_seen += chain
         msg = []
-        if not chain and low.code.shape[0] > 600:
-            # a large program that is no chain: its specialised kernels inline every member (minutes of hiprtc per flavour);
-            # AUTO mode serves it from the interpreter kernel — compared with the oracle only
+        if not chain and low.code.shape[0] > SPECIALIZE_LIMIT:
+            # a program that is no chain and lies beyond SDFK_SPECIALIZE_LIMIT (csrc/sdfk.hip: the size up to which a
+            # specialised kernel is built within the build budget): the product serves it from the interpreter kernel,
+            # which is what is checked — against the oracle, every sampled point
             out = device_eval(_engine, prog, co32, _engine.MODE_INTERPRET)
             pick = rng.choice(n, size=min(n, 4000), replace=False)
             with np.errstate(all="ignore"):
                 ref, mag = sdf_oracle.evaluate_with_magnitude(tree, co32[:, pick].astype(np.float64))
             err = np.abs(out[pick].astype(np.float64) - ref) / np.maximum(np.maximum(1.0, np.abs(ref)), mag)
             n_off = int((~(err <= 1e-6)).sum())
-            if n_off > max(1, int(0.005 * pick.size)):
+            if n_off:
                 bad.append((seed, ["%d of %d sampled points off the oracle (interpreter)" % (n_off, pick.size)]))
-            print("seed %d: %d children, NO chain, %d instr: interpreter only, max scaled err %.2e" % (
+            print("seed %d: %d children, NO chain, %d instr (beyond the specialisation limit): interpreter, max scaled err %.2e" % (
                 seed, children, low.code.shape[0], np.nanmax(err)), flush=True)
             continue
         plain = device_eval(_engine, prog, co32, _engine.MODE_NOCULL)
@@ -165,7 +171,7 @@ def main(first=9000, count=40):
             culled = device_eval(_engine, prog, co32, _engine.MODE_SPECIALIZED, row_len=hint, flat=flat and hint is not None, misalign=shift)
             if not np.array_equal(culled, plain, equal_nan=True):
                 msg.append("culled (row_len %r, shift %d) != un-culled at %d points" % (hint, shift, int((culled != plain).sum())))
-        if children <= 120:
+        if children <= 120 or not chain:                        # (every specialised NON-chain program meets the interpreter)
             interp = device_eval(_engine, prog, co32, _engine.MODE_INTERPRET)
             if not np.array_equal(interp, plain, equal_nan=True):
                 msg.append("interpreter != specialised at %d points" % int((interp != plain).sum()))
@@ -177,7 +183,7 @@ def main(first=9000, count=40):
             ref, mag = sdf_oracle.evaluate_with_magnitude(tree, co32[:, pick].astype(np.float64))
         err = np.abs(plain[pick].astype(np.float64) - ref) / np.maximum(np.maximum(1.0, np.abs(ref)), mag)
         n_off = int((~(err <= 1e-6)).sum())
-        if n_off > max(1, int(0.005 * pick.size)):
+        if n_off:
             msg.append("%d of %d sampled points off the oracle (max %.2e)" % (n_off, pick.size, np.nanmax(err)))
         for thr in (0.0, float(np.quantile(plain, rng.uniform(0.01, 0.99))), float(plain.min()), float(plain.max()), -1e30):
             want = np.flatnonzero(plain <= np.float32(thr))

@@ -64,7 +64,7 @@ def _stub_plot_modules():
     return stubs
 
 
-def run_script(relpath, overrides):
+def run_script(relpath, overrides, cwd=None):
     """Execute an example script of the reference (its text stays where it is) -> its namespace."""
     with open(os.path.join(EXAMPLES_DIR, relpath)) as f:
         text = f.read()
@@ -73,9 +73,15 @@ def run_script(relpath, overrides):
         assert n == 1, (relpath, var)
     text = re.sub(r"(?m)^show_3d\s*=.*$", "show_3d = False", text)
     space = {"__name__": "__example__"}
-    with mock.patch.dict(sys.modules, _stub_plot_modules()), contextlib.redirect_stdout(io.StringIO()), \
-            np.errstate(all="ignore"):
-        exec(compile(text, relpath, "exec"), space)             # noqa: S102 (the reference's own example, build container only)
+    here = os.getcwd()
+    try:
+        if cwd:
+            os.chdir(os.path.join(EXAMPLES_DIR, cwd))           # (a script that finds the reference's data files from os.getcwd())
+        with mock.patch.dict(sys.modules, _stub_plot_modules()), contextlib.redirect_stdout(io.StringIO()), \
+                np.errstate(all="ignore"):
+            exec(compile(text, relpath, "exec"), space)         # noqa: S102 (the reference's own example, build container only)
+    finally:
+        os.chdir(here)
     return space
 
 
@@ -85,10 +91,18 @@ def main():
     out, meta = {}, {"numpy": np.__version__, "scipy": scipy.__version__, "reference": "peterropac/Aegolius SPOMSO 1.4.0",
                      "scenes": {}}
     failures = []
+    only = set(sys.argv[1:])                                     # names given: regenerate those, keep the other fixtures as they are
+    if only:
+        old = np.load(os.path.join(HERE, "example_scenes.npz"))
+        out.update({k: old[k] for k in old.files if k not in only})
+        with open(os.path.join(HERE, "example_scenes_meta.json")) as f:
+            meta["scenes"].update({k: v for k, v in json.load(f)["scenes"].items() if k not in only})
     for name, e in example_scenes.EXAMPLES.items():
+        if only and name not in only:
+            continue
         t0 = time.time()
         try:
-            space = run_script(e["script"], e["overrides"])
+            space = run_script(e["script"], e["overrides"], e.get("cwd"))
             script_field = np.asarray(space[e["variable"]], dtype=np.float64)
             co_full, _res = ref.generate_grid(e["size"], e["full_res"])
             with contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):

@@ -1337,7 +1337,7 @@ def test_candidate_lists_are_exact_and_used(members, engine, monkeypatch):
         # axis tables
         np.testing.assert_array_equal(prog.eval_grid_host([a.astype(np.float32) for a in co.grid_axes]), plain)
         # a pool that cannot hold the lists: cells without one, same field
-        monkeypatch.setenv("SDFK_CELLS_POOL", "40")
+        monkeypatch.setenv("SDFK_CELLS_POOL", "4")
         _cells_stats(engine)
         starved = _device_eval(engine, prog, co32, n, n, 0, engine.MODE_SPECIALIZED, row_len=n2, plane_rows=n1)
         np.testing.assert_array_equal(starved, plain)
