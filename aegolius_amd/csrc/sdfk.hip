@@ -32,6 +32,8 @@
 #include <vector>
 #include <dirent.h>
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <signal.h>
 #include <spawn.h>
 #include <sys/wait.h>
 #include <sys/stat.h>
@@ -748,7 +750,7 @@ static void rtc_cache_evict(const std::string& dir) {
     long long total = 0;
     while (dirent* e = readdir(d)) {
         const std::string name = e->d_name;
-        if (name.compare(0, 5, "sdfk-") != 0) continue;
+        if (name.compare(0, 5, "sdfk-") != 0 || name.compare(0, 9, "sdfk-rtc-") == 0) continue;   // (not the hand-over directories of builds in flight)
         struct stat st;
         const std::string path = dir + "/" + name;
         if (stat(path.c_str(), &st) != 0) continue;
@@ -897,17 +899,27 @@ static int rtc_compile_external(const std::string& src, std::vector<char>* out, 
         const char* t = getenv("TMPDIR");
         dir = (t && *t) ? t : "/tmp";
     }
-    char stem[128];
-    snprintf(stem, sizeof stem, "/sdfk-rtc-%ld-%u", (long)getpid(), serial.fetch_add(1));
-    const std::string srcf = dir + stem + ".hip", outf = dir + stem + ".co";
+    // the hand-over files live in a directory of their own that mkdtemp creates (mode 0700, unpredictable name): nobody
+    // can plant a file or a link where the source is written or the code object is read, two processes with the same pid in
+    // different namespaces that share the cache directory cannot meet, and the cache eviction skips the "sdfk-rtc-" prefix
+    (void)serial;
+    std::string priv = dir + "/sdfk-rtc-XXXXXX";
+    if (!mkdtemp(&priv[0])) {
+        *log = "cannot create a private directory under " + dir + ": " + strerror(errno);
+        return -2;
+    }
+    const std::string srcf = priv + "/src.hip", outf = priv + "/out.co";
     auto cleanup = [&] {
         (void)remove(srcf.c_str());
         (void)remove(outf.c_str());
         (void)remove((outf + ".tmp").c_str());
         (void)remove((outf + ".log").c_str());
+        (void)rmdir(priv.c_str());
     };
     {
-        FILE* f = fopen(srcf.c_str(), "wb");
+        const int fd = open(srcf.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_CLOEXEC, 0600);
+        FILE* f = fd >= 0 ? fdopen(fd, "wb") : nullptr;
+        if (!f && fd >= 0) close(fd);
         const bool ok = f && fwrite(src.data(), 1, src.size(), f) == src.size();
         if (!f || fclose(f) != 0 || !ok) {
             cleanup();
@@ -931,11 +943,29 @@ static int rtc_compile_external(const std::string& src, std::vector<char>* out, 
         *log = std::string("posix_spawn of sdfk_rtc_helper: ") + strerror(rc);
         return -2;
     }
+    // a compiler that never returns (wedged inside comgr, a stale network file system) must not hold its worker thread —
+    // and with it sdfk_jit_drain at interpreter exit — for ever: SDFK_RTC_TIMEOUT seconds (default 900), then it is killed
+    static const double limit_s = [] { const char* e = getenv("SDFK_RTC_TIMEOUT"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 900.0; }();
     int status = 0;
-    while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {
+    bool timed_out = false;
+    const auto t_spawn = std::chrono::steady_clock::now();
+    for (;;) {
+        const pid_t w = waitpid(pid, &status, WNOHANG);
+        if (w == pid) break;
+        if (w < 0 && errno != EINTR) { status = -1; break; }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_spawn).count() > limit_s) {
+            timed_out = true;
+            (void)kill(pid, SIGKILL);
+            while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {
+            }
+            break;
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
     }
     int result = -1;
-    if (WIFEXITED(status) && WEXITSTATUS(status) == 0) {
+    if (timed_out) {
+        *log = "sdfk_rtc_helper did not finish within " + std::to_string((long long)limit_s) + " s (SDFK_RTC_TIMEOUT) and was killed";
+    } else if (WIFEXITED(status) && WEXITSTATUS(status) == 0) {
         FILE* f = fopen(outf.c_str(), "rb");
         if (f && fseek(f, 0, SEEK_END) == 0) {
             const long size = ftell(f);
@@ -970,10 +1000,17 @@ static int rtc_compile(const std::string& src, std::vector<char>* out, std::stri
         if (disk_path) *disk_path = path;
         return 0;
     }
-    int rc;
-    if (external) {
-        rc = rtc_compile_external(src, out, log, rwb);         // (a background build: never hiprtc inside this process)
-    } else {
+    // Builds run in the compiler CHILD process whenever it is there — the background ones (never hiprtc inside this process
+    // while the caller is free to dlopen something: profiles/r03_hang_import_during_build.txt) and the ones the caller waits
+    // for alike (ctypes releases the GIL during the wait: another Python thread that imports a HIP library would meet the same
+    // lock inversion). In-process hiprtc is the last resort, and says so once.
+    int rc = -2;
+    if (rtc_helper_available()) rc = rtc_compile_external(src, out, log, rwb);
+    if (rc == -2 && !external) {
+        static std::atomic<bool> told{false};
+        if (!told.exchange(true))
+            fprintf(stderr, "[sdfk] compiler helper unavailable (%s): building inside this process — do not import HIP libraries on "
+                            "other threads meanwhile\n", log->empty() ? "sdfk_rtc_helper not found next to libsdfk.so" : log->c_str());
         std::lock_guard<std::mutex> lk(g_rtc_mu);
         rc = rtc_compile_uncached(src, out, log, rwb);
     }
@@ -1363,7 +1400,9 @@ static int prepare_cells(sdfk_program* p, DevState* d, hipFunction_t cells_fn, c
     // slack (measured lists: a handful to a few dozen entries, a few hundred in scenes where thousands of members overlap).
     const unsigned long long members = (unsigned long long)p->chain_members, shards = 256;
     unsigned long long cshard = ((nc + shards - 1) / shards) * members;
-    unsigned long long fshard = (std::min(nf * members, 256ull * nf + (16ull << 20)) + shards - 1) / shards;
+    // (a fine shard serves ceil(cells / 256) cells: every member for each of them, or the budget — but never less than one
+    //  whole list)
+    unsigned long long fshard = std::max(members, std::min(((nf + shards - 1) / shards) * members, (256ull * nf + (16ull << 20) + shards - 1) / shards));
     if (const char* e = getenv("SDFK_CELLS_POOL")) {             // (tests: a pool too small for the lists)
         const long long v = atoll(e);
         if (v > 0) fshard = std::min<unsigned long long>(fshard, (unsigned long long)v);

@@ -435,9 +435,11 @@ static const char kRowsKernel[] = R"SDFKR(
 #ifndef SDFK_STAGE_MIN
 #define SDFK_STAGE_MIN 2                         // ... when more than this many survive on the brick
 #endif
-#ifndef SDFK_CHAIN_STAGED                        // ... and only for chains of more than 64 children: the staged path costs
-#define SDFK_CHAIN_STAGED (SDFK_NLEAF > 64)      // 16 VGPRs and 6 KB of LDS that the 50-child flat union (1.06 survivors per
-#endif                                           // brick, 4 waves per SIMD instead of 5) pays for and never uses
+#ifndef SDFK_CHAIN_STAGED                        // Round 3 staged the survivors' parameters in LDS for chains of more than 64
+#define SDFK_CHAIN_STAGED 0                      // children (three dependent loads per child: kind, base, parameters). With the
+#endif                                           // survivors kept as RECORDS (round 4) one load is left between the list and the
+                                                 // parameters, and the direct path is faster: 1000 spheres at 513^3 1.08 -> 0.94 ms,
+                                                 // 4096: 2.21 -> 2.11 (SDFK_STAGE_MIN=64 against 2); -DSDFK_CHAIN_STAGED=1 brings it back
 static_assert(SDFK_NP == 2 || SDFK_NP == 4, "2 or 4 packed pairs per lane");
 static_assert(SDFK_RNBRICK <= 64 * SDFK_RWAVES, "one probe lane per brick");
 
@@ -1210,6 +1212,11 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
             }
 #endif
             SDFK_EACH res[q] = sdfk_chain_tail<f2>(acc[q], P[q], PRM, TAB);
+#if defined(SDFK_DEBUG_NALIVE) && defined(SDFK_CELLS)
+            // test aid: instead of the field, how the brick ran — survivors on its list; 100000 + entries when it ran its cell's
+            // whole list (more survivors than SDFK_ALIST_CAP); -1 when it ran every member
+            SDFK_EACH res[q] = sp<f2>(all_alive ? -1.0f : (list_alive ? 100000.0f + (float)cnt : (float)cnt));
+#endif
         }
 #endif
 #ifdef SDFK_FLAGS                                                  // (the flag-writing build) one bit per point instead of the field

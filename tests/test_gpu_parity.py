@@ -1186,6 +1186,45 @@ print("builds", _engine.jit_stats()[0])
 """
 
 
+_IMPORT_DURING_WAITED_BUILD = """
+import os, sys, threading, time
+sys.path.insert(0, {root!r})
+os.environ["SDFK_ASYNC_JIT"] = "0"            # the call WAITS for its kernel (ctypes releases the GIL meanwhile)
+import aegolius_amd.cores as ns
+from aegolius_amd import _engine, workloads
+co, _ = ns.generate_grid((3, 3, 3), (64, 64, 64))
+tree = workloads.cfg5_tree(ns)
+ns.Sphere(0.3).create(co)                      # device context first
+assert "torch" not in sys.modules
+done = []
+def importer():
+    time.sleep(0.3)                            # the build of the 20-primitive tree takes a couple of seconds
+    import torch                               # dlopen of a dozen HIP libraries on ANOTHER thread while the caller waits
+    done.append(torch.__version__)
+t = threading.Thread(target=importer)
+t.start()
+first = tree.create(co)
+t.join()
+import numpy as np
+assert done and np.array_equal(tree.create(co), first)
+print("builds", _engine.jit_stats()[0])
+"""
+
+
+def test_importing_a_hip_library_while_a_call_waits_for_its_build_does_not_deadlock(engine):
+    """The same lock inversion with the build the caller WAITS for (SDFK_ASYNC_JIT=0, MODE_SPECIALIZED): ctypes releases the
+    GIL during the call, so another Python thread can import a HIP library meanwhile. Waited-for builds run in the compiler
+    child process too (in-process hiprtc only when the helper is missing, with a note on stderr)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SDFK_CACHE_DIR="off")
+    res = subprocess.run([sys.executable, "-c", _IMPORT_DURING_WAITED_BUILD.format(root=root)], env=env, capture_output=True,
+                         text=True, timeout=240)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "builds" in res.stdout and "building inside this process" not in res.stderr
+
+
 def test_importing_a_hip_library_during_a_background_build_does_not_deadlock(engine, tmp_path):
     """The round-2 "hang inside ROCm", reproduced 6 times out of 6 in round 3 (profiles/r03_hang_import_during_build.txt):
     hiprtc inside the process holds comgr's global mutex while `import torch` on the main thread runs HIP fat-binary
@@ -1350,6 +1389,45 @@ def test_candidate_lists_are_exact_and_used(members, engine, monkeypatch):
         ref = sdf_oracle.evaluate(tree, co32[:, pick].astype(np.float64))
     err, bad = violations(plain[pick], ref)
     assert not bad.any(), float(np.nanmax(err))
+
+
+def test_survivor_counts_at_the_edges_of_the_brick_list(engine):
+    """How many members survive on a brick decides which path evaluates it: a list of up to SDFK_ALIST_CAP = 192 records in
+    LDS, the cell's whole candidate list beyond that, every member where there is no list. Three clusters of nearly
+    coincident spheres — 10, 192 and 193 members, far apart — make bricks with exactly those survivor counts (read out
+    through the -DSDFK_DEBUG_NALIVE build of the kernel), and a fold over more than 64 candidates (several batches);
+    the field of every path equals the un-culled chain kernel's bit for bit."""
+    rng = np.random.default_rng(44)
+    objs = []
+    for centre, count in (((-0.7, -0.7, -0.6), 10), ((0.7, 0.6, -0.5), 192), ((0.0, -0.5, 0.7), 193)):
+        for k in range(count):
+            o = ns.Sphere(0.2 + 1e-6 * k)
+            o.move(tuple(np.asarray(centre) + rng.uniform(-1e-6, 1e-6, 3)))
+            objs.append(o)
+    tree = ns.CombineGeometry("UNION").combine(*objs)
+    prog = engine.Program.from_lowered(lower_geometry(tree))
+    assert prog.chain_members == 395
+    co, _ = ns.generate_grid((2.4, 2.4, 2.4), (48, 64, 128))
+    co32 = co.astype(np.float32)
+    n0, n1, n2 = [int(a.size) for a in co.grid_axes]
+    n = co32.shape[1]
+    plain = _device_eval(engine, prog, co32, n, n, 0, engine.MODE_NOCULL)
+    rows = _device_eval(engine, prog, co32, n, n, 0, engine.MODE_SPECIALIZED, row_len=n2, plane_rows=n1)
+    np.testing.assert_array_equal(rows, plain)
+    lib = engine.lib()
+    lib.sdfk_debug_set_rtc_defs(b"-DSDFK_DEBUG_NALIVE=1")
+    try:
+        dbg = engine.Program.from_lowered(lower_geometry(tree))
+        how = _device_eval(engine, dbg, co32, n, n, 0, engine.MODE_SPECIALIZED, row_len=n2, plane_rows=n1)
+    finally:
+        lib.sdfk_debug_set_rtc_defs(b"")
+    seen = set(np.unique(how).astype(np.int64).tolist())
+    assert -1 not in seen, "a brick without a list on a regular grid"
+    assert 10 in seen and 192 in seen, sorted(seen)[:20]               # lists in LDS, the second one exactly full
+    over = sorted(v - 100000 for v in seen if v >= 100000)
+    assert over and min(over) >= 193, (over[:5], sorted(seen)[-5:])    # 193 survivors: the cell's whole list runs
+    # bricks far from every cluster keep few members; none keeps zero
+    assert min(v for v in seen if 0 <= v < 100000) >= 1
 
 
 def _clustered_scene(kind="UNION", groups=8, members=25, seed=3, nested=True):
