@@ -35,8 +35,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 BYTES_PER_POINT = 16            # 3 x fp32 coordinate loads + 1 x fp32 store
-PMC_RECORDS = [os.path.join("profiles", "r03_pmc_traffic.json"),   # static: counters cannot be read from inside a run
-               os.path.join("profiles", "r02_pmc_traffic.json")]
+PMC_RECORDS = [os.path.join("profiles", "r04_pmc_traffic.json"),   # static: counters cannot be read from inside a run
+               os.path.join("profiles", "r03_pmc_traffic.json"), os.path.join("profiles", "r02_pmc_traffic.json")]
+VALU_ROOF = os.path.join("profiles", "r04_valu_roof.json")          # calibrated VALU roof (tools/valu_calib.hip, tools/valu_roof.py)
 
 
 def parse():
@@ -461,9 +462,23 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": kernel_ms_max, "kernel_ms_median": median_ms, "kernel_ms_min": min_ms,
-                         "bytes_per_point": BYTES_PER_POINT, "valu_active_frac": valu_busy},
+                         "bytes_per_point": BYTES_PER_POINT},
             "first_kernel_build_s": t_build,
         }
+        # the second roof SURVEY 8(d) asks for beside the HBM one: VALU issue, from per-class instruction counters priced with
+        # measured issue costs (a static record of separate counter runs, like `traffic`; low / mid / high = how the half of the
+        # instructions no class counter covers is priced). The old `valu_active_frac` (SQ_ACTIVE_INST_VALU * 4 / cycles) is not
+        # a fraction — that counter ticks once per instruction, and instructions cost 2.4 to 8.2 cycles — and is gone.
+        try:
+            vr = json.load(open(os.path.join(ROOT, VALU_ROOF)))["workloads"].get(args.workload)
+            if vr and world == 1 and vr.get("points_per_launch") == count:
+                clock_ghz = vr["cycles_per_launch"] / (kernel_ms_max * 1e-3) / 1e9     # (counter runs clock a little lower)
+                line["roofline"]["valu"] = {"bound": "valu issue", "wave_instructions": vr["valu_wave_instructions"],
+                                            "lane_instructions_per_point": vr["lane_instructions_per_point"],
+                                            "busy_frac": vr["valu_busy_frac"], "mean_issue_cycles": vr["mean_issue_cycles_per_instruction"],
+                                            "implied_clock_ghz_at_this_kernel_time": clock_ghz, "source": VALU_ROOF}
+        except Exception:  # noqa: BLE001
+            pass
 
     # Whatever happens in the extras, rank 0 prints the headline line and every rank leaves: a watchdog thread stays armed
     # from here until the line has been printed (N > 1: `--extras-timeout` for the collective extras, re-armed for rank 0's

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main(res=256, m=16384):
+def main(res=256, m=16384, cloud_kind="synthetic"):
     import aegolius_amd.cores as ns
     from aegolius_amd import _engine, _prims
     from aegolius_amd._lower import lower_geometry
@@ -19,11 +19,14 @@ def main(res=256, m=16384):
     # a terrain-like sheet: z = f(x, y) sampled on a jittered lattice
     xy = rng.uniform(-1, 1, (2, m))
     cloud = np.stack([xy[0], xy[1], 0.3 * np.sin(3 * xy[0]) * np.cos(2 * xy[1])])
+    if cloud_kind == "terrain":                                 # the reference's own cloud (tests/golden/terrain_lr_cloud.npz)
+        cloud = np.load(os.path.join(ROOT, "tests", "golden", "terrain_lr_cloud.npz"))["cloud"]
+        m = cloud.shape[1]
     axes = [a.astype(np.float32) for a in grid_axes((2, 2, 2), (res,) * 3)[0]]
     n = axes[0].size * axes[1].size * axes[2].size
     lib = _engine.lib()
     d_out = lib.sdfk_malloc(n * 4)
-    out = {"grid": [int(a.size) for a in axes], "cloud_points": m}
+    out = {"grid": [int(a.size) for a in axes], "cloud_points": int(m), "cloud": cloud_kind}
     fields = {}
     for label, thr in (("box_tree", 256), ("full_scan", 1 << 30)):
         _prims.TREE_THRESHOLD = thr
@@ -64,4 +67,4 @@ def main(res=256, m=16384):
 
 
 if __name__ == "__main__":
-    main(*(int(a) for a in sys.argv[1:]))
+    main(*[int(a) if a.isdigit() else a for a in sys.argv[1:]])

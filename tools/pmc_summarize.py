@@ -36,9 +36,12 @@ def main(root, kernel="sdfk_spec_v4", out=None):
         rec["hbm_bytes_per_launch"] = rec["hbm_read_bytes_per_launch"] + rec["hbm_write_bytes_per_launch"]
     if "TCC_HIT_sum" in avg and "TCC_MISS_sum" in avg:
         rec["l2_hit_rate"] = avg["TCC_HIT_sum"] / max(1.0, avg["TCC_HIT_sum"] + avg["TCC_MISS_sum"])
-    if "SQ_ACTIVE_INST_VALU" in avg and "GRBM_GUI_ACTIVE" in avg:
-        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs; GRBM_GUI_ACTIVE is the sum over the 8 XCDs
-        rec["valu_active_frac"] = avg["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * avg["GRBM_GUI_ACTIVE"] / 8.0)
+    if "SQ_INSTS_VALU" in avg and "GRBM_GUI_ACTIVE" in avg:
+        # (rounds 1-3 derived "valu_active_frac" = SQ_ACTIVE_INST_VALU * 4 / SIMD-cycles from here. That counter ticks once per
+        #  instruction — it reads 1.02 x SQ_INSTS_VALU on every kernel, and 0.96 on a pure v_fma loop that saturates the SIMDs
+        #  (profiles/r04_valu_calib_pmc.json) — while instructions cost 2.4 to 8.2 cycles by class, so the quotient is a
+        #  fraction only for an all-FMA kernel: 1.40 on cfg3. The calibrated roof is tools/valu_roof.py.)
+        rec["valu_instructions_per_simd_cycle"] = avg["SQ_INSTS_VALU"] / (1024.0 * avg["GRBM_GUI_ACTIVE"] / 8.0)
     print(json.dumps(rec, indent=1))
     if out:
         with open(out, "w") as f:
