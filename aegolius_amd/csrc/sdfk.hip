@@ -2181,16 +2181,6 @@ static int eval_host_impl(sdfk_program* p, const void* co, int co_dtype, int64_t
         sl.pending_start = -1;
         return 0;
     };
-    // The caller's result array is usually fresh memory (numpy.empty: an anonymous mapping nothing has touched): ask for
-    // huge pages before the first chunk lands in it — 2 MiB instead of 4 KiB per first-touch fault inside the copy-out, and
-    // 200 instead of 100,000 pages to give back when the array is freed (measured next to a HIP context: freeing a 400 MB
-    // result costs 18 ms, more than half of the call that produced it; tools/host_path_ab.py). Refused or unavailable: no harm.
-    if (!out_on_device && n >= ((int64_t)1 << 20)) {
-        const uintptr_t lo = reinterpret_cast<uintptr_t>(out), hi = lo + (uintptr_t)n * sizeof(float), huge = (uintptr_t)1 << 21;
-        const uintptr_t hlo = (lo + huge - 1) & ~(huge - 1), hhi = hi & ~(huge - 1);
-        static const bool thp = [] { const char* e = getenv("SDFK_HOST_THP"); return !(e && e[0] == '0'); }();
-        if (thp && hhi > hlo) (void)madvise(reinterpret_cast<void*>(hlo), hhi - hlo, MADV_HUGEPAGE);
-    }
     int k = 0;
     for (int64_t s = 0; s < n && rc == 0; s += chunk, ++k) {
         HostSlot& sl = st->slot[k & 1];
