@@ -759,7 +759,7 @@ def main():
                                               "bytes": fused_bytes, "evaluate_then_select_ms": kernel_ms_max + sel_ms,
                                               "frac_of_hbm_peak": fused_bytes / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                               "note": "sdfk_eval_device_select: 12 B/point in, flag bits + 8 B per selected "
-                                                      "point out; includes the zeroing of the flags and two stream syncs"},
+                                                      "point out; evaluation kernel + count + scan + scatter, one stream sync"},
                 "interior_selection": {"ms": sel_ms, "selected": selected.value, "bytes": sel_bytes,
                                        "frac_of_hbm_peak": sel_bytes / (sel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
                 "gradient_direction": {"ms": grad_ms, "bytes": (12.0 if flat else 16.0) * count,
