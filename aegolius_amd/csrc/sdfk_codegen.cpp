@@ -442,23 +442,6 @@ static const char kRowsKernel[] = R"SDFKR(
                                                  // 4096: 2.21 -> 2.11 (SDFK_STAGE_MIN=64 against 2); -DSDFK_CHAIN_STAGED=1 brings it back
 static_assert(SDFK_NP == 2 || SDFK_NP == 4, "2 or 4 packed pairs per lane");
 static_assert(SDFK_RNBRICK <= 64 * SDFK_RWAVES, "one probe lane per brick");
-// Two-stage probe (mask kernels with sub-brick centres): every brick is first probed at ONE centre, its whole sphere, and
-// only a workgroup in which some brick of whole row segments is left with more than SDFK_REFINE_MIN undecided sites goes on
-// to the SDFK_NSUB sub-brick centres. Where the grid is fine against the scene the coarse probe already decides nearly
-// everything and eight times the leaf evaluations buy nothing (the 20-primitive tree at 1025^3: 3.29 ms with sub-brick
-// centres everywhere, 3.20 with the one-centre probe of round 2, and the reverse at 513^3: 0.50 against 0.61 —
-// profiles/r04_cfg5_probe_variants.txt); this way each workgroup pays for the finer probe only where it can cull more.
-#ifndef SDFK_TWOSTAGE
-#if defined(SDFK_SIMT) && !defined(SDFK_CHAIN) && SDFK_NSUB > 1 && (SDFK_NCEN & (SDFK_NCEN - 1)) == 0 && (SDFK_RNBRICK & (SDFK_RNBRICK - 1)) == 0
-#define SDFK_TWOSTAGE 1
-#else
-#define SDFK_TWOSTAGE 0
-#endif
-#endif
-#ifndef SDFK_REFINE_MIN
-#define SDFK_REFINE_MIN 0
-#endif
-#define SDFK_LOG2U(x) (31 - __builtin_clz((unsigned)(x)))
 
 typedef float sdfk_f4u __attribute__((ext_vector_type(4), aligned(4)));
 
@@ -478,10 +461,6 @@ struct sdfk_rowmeta {
 #if defined(SDFK_SIMT) && !defined(SDFK_CELLS)
     float4 cen[SDFK_NCEN];                      // probe centres (x, y, z, radius): SDFK_NSUB per brick
     float leafval[SDFK_NLEAF * SDFK_NCEN];      // [leaf][centre]: every leaf of the tree at every centre
-#if SDFK_TWOSTAGE
-    unsigned refine[SDFK_RNBRICK];              // the brick asked for the sub-brick probe
-    unsigned any_refine;
-#endif
 #endif
 #ifdef SDFK_CHAIN
 #ifdef SDFK_CELLS
@@ -546,9 +525,7 @@ static __device__ __forceinline__ unsigned sdfk_udiv(unsigned a, unsigned d, uns
 //  block's index within it)
 static __device__ __forceinline__ void sdfk_block_rows(const sdfk_rowgeom& g, unsigned rb, long long& r0, long long& rend,
                                                        unsigned* slot = nullptr, unsigned* blk = nullptr) {
-    // ONE plane (no plane hint, flat grids, plane blocks not asked for): blocks of 16 consecutive rows, nothing to divide.
-    // (Round 3 sent every brick through the plane arithmetic below, twice: 2 % of the 20-primitive tree at 1025^3 —
-    //  profiles/r04_bisect_cfg5.txt, commit bf2936c against round 2.)
+    // ONE plane (no plane hint, flat grids, plane blocks not asked for): blocks of 16 consecutive rows, nothing to divide
     if (g.nb0 == 0u && (long long)g.prow >= g.R) {
         r0 = (long long)rb * SDFK_RROWS;
         rend = g.R;
@@ -688,10 +665,9 @@ static __device__ __forceinline__ void sdfk_rows_bounds(const sdfk_rowregs& r, i
         if (head) meta->xy[b][8 * t + (lane >> 3)] = make_float2(r.X[t].x, r.Y[t].x);
     }
     const bool uniform = __ballot(uni) == ~0ull;
-#if defined(SDFK_SIMT) && SDFK_NSUB > 1 && !SDFK_TWOSTAGE
+#if defined(SDFK_SIMT) && SDFK_NSUB > 1
     // bricks of whole row segments are bounded per SUB-brick by the probe lanes (sdfk_sub_centre, from the staged
-    // coordinates): the sphere around the whole brick is only needed for the others (and for the first stage of the
-    // two-stage probe)
+    // coordinates): the sphere around the whole brick is only needed for the others
     if (uniform) {
         if (lane == 0) {
             meta->uniform[b] = 1u;
@@ -1028,55 +1004,6 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
     __syncthreads();
     return;
 #endif
-#if SDFK_TWOSTAGE && !defined(SDFK_ABLATE_PROBE)
-    {
-        // stage 1: the brick's whole sphere
-        if (sdfk_tx() < SDFK_RNBRICK) meta->cen[sdfk_tx()] = meta->bound[sdfk_tx()];
-        if (sdfk_tx() == 0) meta->any_refine = 0u;
-        __syncthreads();
-        sdfk_probe_leaves(meta->cen, meta->leafval, PRM, TAB, SDFK_LOG2U(SDFK_RNBRICK), nullptr);
-        __syncthreads();
-        if (sdfk_tx() < SDFK_RNBRICK) {
-            unsigned long long m0 = 0ull, m1 = 0ull;
-            unsigned want = 0u;
-            if (tile * SDFK_RNBRICK + sdfk_tx() < g.nbricks) {
-                const float4 cc = meta->cen[sdfk_tx()];
-                V3T<float> ctr = {cc.x, cc.y, cc.z};
-                sdfk_probe_fold(meta->leafval, sdfk_tx(), ctr, cc.w, PRM, m0, m1);
-                // sites at which neither operand is skipped: what a finer probe could still decide
-                const unsigned decided = (unsigned)__builtin_popcountll((m0 | (m0 >> 1)) & 0x5555555555555555ull) +
-                                         (unsigned)__builtin_popcountll((m1 | (m1 >> 1)) & 0x5555555555555555ull);
-                want = (meta->uniform[sdfk_tx()] != 0u && SDFK_NSITES - decided > SDFK_REFINE_MIN) ? 1u : 0u;
-            }
-            meta->mask0[sdfk_tx()] = want ? ~0ull : m0;          // (a brick that refines starts again from "skip everything")
-            meta->mask1[sdfk_tx()] = want ? ~0ull : m1;
-            meta->refine[sdfk_tx()] = want;
-            if (want) meta->any_refine = 1u;
-        }
-        __syncthreads();
-        if (meta->any_refine == 0u) return;
-        // stage 2: the sub-brick centres of the bricks that asked for them
-        if (sdfk_tx() < SDFK_NCEN) {
-            const unsigned b = sdfk_tx() / SDFK_NSUB, sb = sdfk_tx() % SDFK_NSUB;
-            float4 cc = meta->bound[b];
-            if (meta->refine[b]) cc = sdfk_sub_centre(meta, b, sb);
-            meta->cen[sdfk_tx()] = cc;
-        }
-        __syncthreads();
-        sdfk_probe_leaves(meta->cen, meta->leafval, PRM, TAB, SDFK_LOG2U(SDFK_NCEN), meta->refine);
-        __syncthreads();
-        if (sdfk_tx() < SDFK_NCEN && meta->refine[sdfk_tx() / SDFK_NSUB]) {
-            const float4 cc = meta->cen[sdfk_tx()];
-            V3T<float> ctr = {cc.x, cc.y, cc.z};
-            unsigned long long m0, m1;
-            sdfk_probe_fold(meta->leafval, sdfk_tx(), ctr, cc.w, PRM, m0, m1);
-            __hip_atomic_fetch_and(&meta->mask0[sdfk_tx() / SDFK_NSUB], m0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_and(&meta->mask1[sdfk_tx() / SDFK_NSUB], m1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        __syncthreads();
-        return;
-    }
-#endif
 #if defined(SDFK_SIMT) && !defined(SDFK_CELLS)
     // lane-parallel probe: probe centres -> every leaf at every centre (all lanes) -> one fold lane per centre ANDs its
     // skip decisions into the brick's mask (a subtree is skipped only if every sub-brick allows it)
@@ -1092,7 +1019,7 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
     }
     __syncthreads();
 #ifndef SDFK_ABLATE_PROBE
-    sdfk_probe_leaves(meta->cen, meta->leafval, PRM, TAB, SDFK_LOG2U(SDFK_NCEN), nullptr);
+    sdfk_probe_leaves(meta->cen, meta->leafval, PRM, TAB);
     __syncthreads();
 #ifdef SDFK_CHAIN
 #pragma unroll 1
@@ -1971,7 +1898,7 @@ struct Gen {
             // chain mode (one centre per brick, few bricks per workgroup): a lane takes a LEAF and walks the centres, so the
             // leaf's parameters — two dependent memory round trips, the offsets and then the values — are fetched once
             s += "\nstatic __device__ __forceinline__ void sdfk_probe_leaves(const float4* __restrict__ cen, float* __restrict__ leafval, "
-                 "const float* __restrict__ PRM, const float* __restrict__ TAB, unsigned, const unsigned*) {\n";
+                 "const float* __restrict__ PRM, const float* __restrict__ TAB) {\n";
             for (size_t g = 0; g < groups.size(); ++g) {
                 snprintf(buf, sizeof buf,
                          "    _Pragma(\"unroll 2\") for (unsigned m = sdfk_tx(); m < %zuu; m += 64u * SDFK_RWAVES) {\n"
@@ -1991,22 +1918,19 @@ struct Gen {
         // (several rounds of a big group in flight at once: each round is two dependent memory round trips — the offsets,
         //  then the parameters — and nothing else hides them)
         s += "\n#ifndef SDFK_LEAF_UNROLL\n#define SDFK_LEAF_UNROLL _Pragma(\"unroll 1\")\n#endif\n";
-        // (lcen: log2 of the centres in use — all SDFK_NCEN, or one per brick in the first stage of the two-stage probe; the
-        //  table keeps its stride of SDFK_NCEN. only: per-brick flags, centres of other bricks are left out)
         s += "static __device__ __forceinline__ void sdfk_probe_leaves(const float4* __restrict__ cen, float* __restrict__ leafval, "
-             "const float* __restrict__ PRM, const float* __restrict__ TAB, unsigned lcen, const unsigned* only) {\n";
+             "const float* __restrict__ PRM, const float* __restrict__ TAB) {\n";
         for (size_t g = 0; g < groups.size(); ++g) {
             snprintf(buf, sizeof buf,
-                     "    SDFK_LEAF_UNROLL for (unsigned item = sdfk_tx(); item < ((SDFK_NCEN & (SDFK_NCEN - 1)) ? %zuu * SDFK_NCEN : (%zuu << lcen)); item += 64u * SDFK_RWAVES) {\n"
-                     "        unsigned m = (SDFK_NCEN & (SDFK_NCEN - 1)) ? item / SDFK_NCEN : item >> lcen;\n"
-                     "        if ((1u << lcen) %% 64u == 0u) m = __builtin_amdgcn_readfirstlane(m);   // one member per wave: scalar parameter loads\n"
-                     "        const unsigned c = (SDFK_NCEN & (SDFK_NCEN - 1)) ? item - m * SDFK_NCEN : item & ((1u << lcen) - 1u);\n"
-                     "        if (only && !only[c / SDFK_NSUB]) continue;\n"
+                     "    SDFK_LEAF_UNROLL for (unsigned item = sdfk_tx(); item < %zuu * SDFK_NCEN; item += 64u * SDFK_RWAVES) {\n"
+                     "        unsigned m = item / SDFK_NCEN;\n"
+                     "        if (SDFK_NCEN %% 64 == 0) m = __builtin_amdgcn_readfirstlane(m);   // one member per wave: scalar parameter loads\n"
+                     "        const unsigned c = item - m * SDFK_NCEN;\n"
                      "        const float4 cc = cen[c];\n"
                      "        const V3T<float> p = {cc.x, cc.y, cc.z};\n"
                      "        leafval[sdfk_grp%zu_leaf[m] * SDFK_NCEN + c] = sdfk_grp%zu<float>(p, %s, TAB);\n"
                      "    }\n",
-                     groups[g].members.size(), groups[g].members.size(), g, g,
+                     groups[g].members.size(), g, g,
                      rel ? ("PRM + sdfk_leaf_base[sdfk_grp" + std::to_string(g) + "_leaf[m]]").c_str()
                          : ("sdfk_grp" + std::to_string(g) + "_off[m], PRM").c_str());
             s += buf;
@@ -2630,8 +2554,7 @@ std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32
             // sub-bricks per brick (every one gets a probe centre of its own): as many as the lanes of the workgroup
             // pay for — the leaf evaluations are the cost: (leaves x centres) / lanes rounds of one leaf each
             char def[160];
-            snprintf(def, sizeof def, "\n#ifndef SDFK_NOSIMT\n#define SDFK_SIMT 1\n#endif\n#define SDFK_NLEAF %zu\n#define SDFK_NSITES %zuu\n", g.leaves.size(),
-                     sites.size());
+            snprintf(def, sizeof def, "\n#ifndef SDFK_NOSIMT\n#define SDFK_SIMT 1\n#endif\n#define SDFK_NLEAF %zu\n", g.leaves.size());
             g.s += def;
             g.s += kSimtGeometry;
             g.emit_groups();
