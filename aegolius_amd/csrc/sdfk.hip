@@ -589,12 +589,15 @@ static int tile_wbricks() {
 static int tile_points() { return tile_waves() * tile_wbricks() * 128; }
 // bricks per wave of the row-block kernel: 2 — except for big trees (> 150 instructions, e.g. the 50-primitive 2-D
 // union), whose whole-tree probe is better shared by 16 bricks per workgroup than by 8 (measured -11 %)
-// waves per workgroup of the row-block kernel: 2 — many small workgroups interleave their memory and VALU phases
-// best (north-star tree -0.5 %, 50-primitive flat union -10 % against 4 waves)
+// waves per workgroup of the row-block kernel: 4. (Round 2 measured 2 best, when ONE lane per brick probed the whole tree and
+// a bigger workgroup only made more waves wait for it. Since the probe runs on all lanes — round 3 — the workgroup's serial
+// steps, centres and fold on the first wave, are shared by more bricks: round 4, one box, 2 -> 4 waves: north-star tree
+// 2.944 -> 2.913 ms, 20-primitive tree 3.356 -> 3.186 at 1025^3 and 25.4 -> 24.9 at 2049^3, 50-member flat union 0.847 ->
+// 0.833, 513^3 1-2 %; 3, 6 and 8 waves are slower everywhere: profiles/r04_rwaves_sweep.txt.)
 static std::atomic<int> g_rwaves_override{0};
 static int rows_waves(const sdfk_program*) {
     if (const int o = g_rwaves_override.load()) return o;
-    return 2;
+    return 4;
 }
 static int rows_wbricks(const sdfk_program* p);
 static int rows_geo(const sdfk_program* p) { return rows_wbricks(p) | (rows_waves(p) << 4); }
@@ -805,7 +808,7 @@ extern "C" void sdfk_debug_set_rtc_defs(const char* defs) {
 }
 // geo: bricks per wave | waves per workgroup << 4 of the row-block kernel (rows_geo)
 static std::vector<std::string> rtc_options(int geo) {
-    const int rwb = geo & 15, rwaves = (geo >> 4) ? (geo >> 4) : 2;
+    const int rwb = geo & 15, rwaves = (geo >> 4) ? (geo >> 4) : 4;
     std::vector<std::string> o = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17",
                                   // -fno-honor-nans: v_min/v_max without the canonicalising pre-op. -mno-amdgpu-ieee (same
                                   // flags as the hipcc build of the interpreter kernel: both flavours stay bit-identical)

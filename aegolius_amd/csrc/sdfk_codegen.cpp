@@ -391,7 +391,7 @@ static const char kSimtGeometry[] = R"SDFKR(
 #define SDFK_RWBRICKS 2
 #endif
 #ifndef SDFK_RWAVES
-#define SDFK_RWAVES 2
+#define SDFK_RWAVES 4
 #endif
 #ifndef SDFK_NSUB                        // sub-bricks (probe centres) per brick: 16 = 4 rows x 8 points, 8 = 8 rows x 8, 4 = 16 rows x 8
 // measured (north-star tree, 20-primitive tree; 513^3 and 1025^3): 8 centres beat 16 — half the leaf evaluations, nearly
@@ -421,7 +421,7 @@ static const char kRowsKernel[] = R"SDFKR(
 #define SDFK_RWBRICKS 2
 #endif
 #ifndef SDFK_RWAVES
-#define SDFK_RWAVES 2                           // waves per workgroup (host launch code must agree: sdfk.hip)
+#define SDFK_RWAVES 4                           // waves per workgroup (host launch code must agree: sdfk.hip)
 #endif
 #define SDFK_RZ 32
 #define SDFK_RLPR (SDFK_RZ / (2 * SDFK_NP))     // lanes per row in phase C
