@@ -1071,7 +1071,11 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
 #define SDFK_RTILES 1
 #endif
 #ifndef SDFK_XGROUP
+#ifdef SDFK_FLAT                         // flat grids (rows of 16385 points: 513 windows): short runs — the 50-member union at
+#define SDFK_XGROUP 4                    // 16385^2 0.833 -> 0.805 ms against runs of 8, 0.840 with 16 (profiles/r04_w4_cfg4.txt)
+#else
 #define SDFK_XGROUP (SDFK_RNBRICK <= 4 ? 16 : (SDFK_RNBRICK <= 8 ? 8 : 4))    // runs of about 64 bricks: two row blocks at 1025
+#endif
 #endif
 #pragma unroll 1
   for (unsigned tt = 0; tt < SDFK_RTILES; ++tt) {
