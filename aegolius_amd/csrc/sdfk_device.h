@@ -104,12 +104,23 @@ SDFK_DEV V3P sd_join(V3 a, V3 b) { V3P r = {{a.x, b.x}, {a.y, b.y}, {a.z, b.z}};
 //  pair form of op_infrep — packed add / mul / fma, fix-ups as additions of d, -d or 0 — is bit-identical and exactly as
 //  fast as the pair wrapper around this scalar function, 3.45 vs 3.45 ms in alternation: the compiler pairs the two
 //  scalar calls by itself.)
+// all ones where the sign bit of x is set. Inline asm on purpose: written as a shift the optimiser turns it back into
+// compare + select, and the select's constants into moves (16 VALU instructions per sd_mod in round 3's listing, 11 now).
+SDFK_DEV int sd_signmask(float x) {
+    int m;
+    asm("v_ashrrev_i32_e32 %0, 31, %1" : "=v"(m) : "v"(x));
+    return m;
+}
 SDFK_DEV float sd_mod(float a, float d, float inv_d) {
     float q = __builtin_floorf(a * inv_d);
     float r = sd_fma(-q, d, a);
     if (d > 0.0f) {            // wave-uniform: d is a parameter
-        r = (r < 0.0f) ? r + d : r;
-        r = (r >= d) ? r - d : r;
+        // r < 0 ? r + d : r   (r is never -0 here: an exact cancellation gives +0)
+        r += __builtin_bit_cast(float, sd_signmask(r) & __builtin_bit_cast(int, d));
+        // r >= d ? r - d : r   (t = r - d carries the exact sign of the comparison)
+        const float t = r - d;
+        const int m = sd_signmask(t);
+        r = __builtin_bit_cast(float, (m & __builtin_bit_cast(int, r)) | (~m & __builtin_bit_cast(int, t)));
     } else {
         r = (r > 0.0f) ? r + d : r;
         r = (r <= d) ? r - d : r;
@@ -229,8 +240,10 @@ SDFK_DEV void sd_sincos(float x, float* s, float* c) {
                             sd_fma(z, -0.5f, 1.0f));
     const int q = (int)k;
     const float ss = (q & 1) ? pc : ps, cc = (q & 1) ? ps : pc;
-    *s = (q & 2) ? -ss : ss;
-    *c = ((q + 1) & 2) ? -cc : cc;
+    // sign flips as bit 1 of q (sine) and of q + 1 (cosine) moved onto the sign bit: three two-operand instructions each
+    // instead of and + compare + select
+    *s = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, ss) ^ (((unsigned)q << 30) & 0x80000000u));
+    *c = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, cc) ^ (((unsigned)(q + 1) << 30) & 0x80000000u));
 }
 
 // atan2 with numpy's conventions for finite arguments (atan2(0, 0) = 0, signed zeros of y kept): one division
