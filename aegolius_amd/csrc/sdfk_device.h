@@ -287,9 +287,8 @@ SDFK_DEV V3 op_bend(V3 p, const float* __restrict__ P, const float* __restrict__
         float sg = sd_sign(p.x);
         float wx = p.x - P[4] * sg;
         float wy = p.y - P[5];
-        float rx, ry;
-        if (p.x >= 0.0f) { rx = sd_fma(c, wx, s * wy);  ry = sd_fma(-s, wx, c * wy); }
-        else             { rx = sd_fma(c, wx, -s * wy); ry = sd_fma(s, wx, c * wy); }
+        const float ss = (p.x >= 0.0f) ? s : -s;           // one select on the sine instead of one per output: same bits
+        const float rx = sd_fma(c, wx, ss * wy), ry = sd_fma(-ss, wx, c * wy);
         qx = rx + P[3] * sg;
         qy = ry;
     }

@@ -25,7 +25,10 @@ def prims(rng, count):
         angle = float(rng.uniform(0, np.pi)); axis = rng.normal(0, 1, 3)
         o.rotate(angle, axis); o.move(rng.uniform(-0.7, 0.7, 3)); out.append(o)
     return out
-if workload == "cfg2":
+if workload in ("cfg1", "cfg3"):
+    from aegolius_amd import workloads
+    tree, size = workloads.build(workload, ns)[:2]
+elif workload == "cfg2":
     p = prims(np.random.default_rng(1234), 10); tree = p[0]
     for q in p[1:]: tree = ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(tree, q, parameters=0.1)
     size = (2, 2, 2)
@@ -49,7 +52,7 @@ ts = []
 for _ in range(30):
     e0, e1 = _engine.Event(), _engine.Event(); e0.record(st); step(); e1.record(st); ts.append(e0.elapsed_ms(e1))
 ts.sort()
-print(json.dumps({"median_ms": ts[len(ts) // 2], "min_ms": ts[0], "checksum": float(out[:n].double().sum())}))
+print(json.dumps({"median_ms": ts[len(ts) // 2], "min_ms": ts[0], "checksum": float(out[:n].double().sum()), "bits": int(out[:n].view(torch.int32).to(torch.int64).sum())}))
 '''
 
 
@@ -69,7 +72,7 @@ def main():
                 continue
             d = json.loads(line[-1])
             res[t].append(d)
-            print("round %d %-4s median %.3f min %.3f ms  checksum %.6e" % (r, t, d["median_ms"], d["min_ms"], d["checksum"]), flush=True)
+            print("round %d %-9s median %.3f min %.3f ms  checksum %.9e  bit sum %d" % (r, t, d["median_ms"], d["min_ms"], d["checksum"], d.get("bits", 0)), flush=True)
     n = 1076890625
     for t in tags:
         if res[t]:
