@@ -57,26 +57,26 @@ class _Anything:
 def _stub_plot_modules():
     stubs = {}
     for name in ("matplotlib", "matplotlib.pyplot", "matplotlib.cm", "matplotlib.colors", "plotly", "plotly.graph_objects",
-                 "plotly.subplots", "plotly.express"):
+                 "plotly.subplots", "plotly.express", "mpl_toolkits", "mpl_toolkits.axes_grid1"):
         m = types.ModuleType(name)
         m.__getattr__ = lambda _attr: _Anything()
         stubs[name] = m
     return stubs
 
 
-def run_script(relpath, overrides, cwd=None):
+def run_script(relpath, overrides, cwd=None, base=EXAMPLES_DIR, hide=("show_3d",)):
     """Execute an example script of the reference (its text stays where it is) -> its namespace."""
-    with open(os.path.join(EXAMPLES_DIR, relpath)) as f:
+    with open(os.path.join(base, relpath)) as f:
         text = f.read()
     for var, value in overrides.items():                        # variant constants: `name = <literal>` at module level
         text, n = re.subn(r"(?m)^%s\s*=.*$" % re.escape(var), "%s = %r" % (var, value), text, count=1)
         assert n == 1, (relpath, var)
-    text = re.sub(r"(?m)^show_3d\s*=.*$", "show_3d = False", text)
+    text = re.sub(r"(?m)^(%s)\s*=.*$" % "|".join(hide), r"\1 = False", text)
     space = {"__name__": "__example__"}
     here = os.getcwd()
     try:
         if cwd:
-            os.chdir(os.path.join(EXAMPLES_DIR, cwd))           # (a script that finds the reference's data files from os.getcwd())
+            os.chdir(os.path.join(base, cwd))           # (a script that finds the reference's data files from os.getcwd())
         with mock.patch.dict(sys.modules, _stub_plot_modules()), contextlib.redirect_stdout(io.StringIO()), \
                 np.errstate(all="ignore"):
             exec(compile(text, relpath, "exec"), space)         # noqa: S102 (the reference's own example, build container only)
