@@ -506,3 +506,42 @@ def pointcloud_terrain_3d(ns):
     final.onion(0.01)
     return final
 
+
+
+# Point clouds the reference's image examples extract from its own test images (Files/test_images/*.png through
+# `Points.from_image`; `Points` itself is outside SURVEY §8): kept as DATA in tests/golden/image_clouds.npz by
+# tests/golden/generate_image_clouds.py — 64,691 points of hand-drawn lines, the 332,281 + 1,735,884 pixels outside / inside
+# a logo, 201,874 points of four shapes. Nearest-point leaves three to one hundred times the size of the terrain cloud
+# (SURVEY §8(f).2): all through the two-level box tree. Proven equal to what the scripts extract by the generator's
+# script == builder check.
+def image_cloud(name):
+    import os
+    xy = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "image_clouds.npz"))[name]
+    return np.vstack([xy, np.zeros((1, xy.shape[1]))])
+
+
+def _cloud2d(ns, name):
+    import importlib
+    return importlib.import_module(ns.__name__ + ".geom_2d").PointCloud2D(image_cloud(name))
+
+
+@example("pointcloud_image_2D", (4, 4), (400, 400), (40, 40), "2D/pointcloud_image_2D.py", "final_pattern", cwd="2D")
+def pointcloud_image_2d(ns):
+    final = _cloud2d(ns, "lines")
+    final.onion(0.01)
+    return final
+
+
+def _owl(rounding):
+    def build(ns):
+        final = ns.CombineGeometry("DIFFERENCE").combine(_cloud2d(ns, "owl_exterior"), _cloud2d(ns, "owl_interior"))
+        if rounding:
+            final.rounding(rounding)
+        return final
+    return build
+
+
+for _name, _morph, _r in (("sdf_from_mask_2D", "NOTHING", 0.0), ("sdf_from_mask_2D_dilate", "DILATE", 0.5),
+                          ("sdf_from_mask_2D_erode", "ERODE", -0.5)):
+    example(_name, (8, 6), (800, 600), (24, 18), "2D/sdf_from_mask_2D.py", "final_pattern",
+            overrides={"morphology": _morph}, cwd="2D")(_owl(_r))
