@@ -80,6 +80,7 @@ SIGNATURES = {
     "sdfk_set_default_mode": (None, [_int]),
     "sdfk_debug_brick_masks": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "sdfk_linspace_f32": (_int, [_c.c_double, _c.c_double, _i64, _vp]),
+    "sdfk_point_tree_build": (_i64, [_vp, _i64, _int, _vp, _i64, _vp, _vp, _vp]),
     "sdfk_grid_fill": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp]),
     "sdfk_set_device": (_int, [_int]),
     "sdfk_malloc": (_vp, [_sz]),
@@ -585,6 +586,26 @@ def linspace_f32(lo, hi, n):
     out = np.empty(int(n), dtype=np.float32)
     check(lib().sdfk_linspace_f32(float(lo), float(hi), int(n), _ptr(out)), "sdfk_linspace_f32")
     return out
+
+
+def point_tree(points32, leaf, with_order=False):
+    """sdfk_point_tree_build: (m, 3) fp32 points -> (table, n_top, point_base, order or None). Host only."""
+    pts = np.ascontiguousarray(points32, dtype=np.float32)
+    if pts.ndim != 2 or pts.shape[1] != 3 or pts.shape[0] < 1:
+        raise ValueError("points must have shape (M, 3), M >= 1; got %r" % (pts.shape,))
+    m = int(pts.shape[0])
+    half = max(1, int(leaf) // 2)
+    cap = 3 * m + 8 * (m // half + 2) + 8 * (m // half // int(leaf) + 2)
+    table = np.empty(cap, dtype=np.float32)
+    order = np.empty(m, dtype=np.int64) if with_order else None
+    n_top, point_base = _c.c_int64(0), _c.c_int64(0)
+    used = lib().sdfk_point_tree_build(_ptr(pts), m, int(leaf), _ptr(table), cap, _ptr(order) if with_order else None,
+                                       _c.byref(n_top), _c.byref(point_base))
+    if used == -2:
+        raise ValueError(last_error())
+    if used < 0:
+        raise SdfkError("sdfk_point_tree_build: " + last_error())
+    return table[:used].copy(), int(n_top.value), int(point_base.value), order
 
 
 def grid_fill(d_co, row_stride, axes, start, count, stream=None):

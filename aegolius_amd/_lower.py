@@ -75,7 +75,8 @@ class Lowerer:
     def __init__(self):
         self.code = []
         self.params = []
-        self.tables = []
+        self.tables = []            # chunks (float64 arrays), concatenated by finish(); offsets count floats
+        self._table_len = 0
         self._c_used = {0}
         self._v_used = set()
         self.n_creg = 1
@@ -252,16 +253,18 @@ class Lowerer:
             self.lip_v[a] = fn(la, lb) if fn and np.isfinite(la) and np.isfinite(lb) else _lip.INF
 
     def add_table(self, values):
-        off = len(self.tables)
-        self.tables.extend(float(x) for x in np.asarray(values, dtype=np.float64).ravel())
-        if len(self.tables) >= (1 << 24):
+        off = self._table_len
+        chunk = np.array(values, dtype=np.float64).ravel()       # (a copy: the caller's array may change afterwards)
+        self.tables.append(chunk)
+        self._table_len += chunk.size
+        if self._table_len >= (1 << 24):
             raise LoweringError("tables exceed 2^24 floats (offsets are carried as fp32)")
         return off
 
     def finish(self, vreg):
         with np.errstate(over="ignore"):
             params = np.asarray(self.params, dtype=np.float64).astype(np.float32)
-            tables = np.asarray(self.tables, dtype=np.float64).astype(np.float32)
+            tables = (np.concatenate(self.tables) if self.tables else np.zeros(0)).astype(np.float32)
         # the largest subtrees first if there are more sites than mask bits
         sites = sorted(self.cull, key=lambda r: -((r[2] - r[1]) + (r[4] - r[3])))[:_lip.MAX_SITES]
         sites.sort(key=lambda r: r[0])

@@ -2322,3 +2322,4 @@ extern "C" int sdfk_stream_probe(const float* d_co, int64_t n, int64_t row_strid
 #include "sdfk_gridops.inc"
 #include "sdfk_fieldops.inc"
 #include "sdfk_vector.inc"
+#include "sdfk_hosttree.inc"

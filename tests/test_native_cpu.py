@@ -154,6 +154,20 @@ def test_point_tree_layout_and_validation(built):
     seen = np.concatenate(seen)
     assert seen.shape == pts.shape
     np.testing.assert_array_equal(np.sort(seen.view("f4,f4,f4").ravel()), np.sort(pts.view("f4,f4,f4").ravel()))
+    # the leaf order of the points (what CURVEINSTT maps back to instance rows) is a permutation that reproduces the table
+    table2, n_top2, point_base, order = _prims.build_point_tree(pts, with_order=True)
+    np.testing.assert_array_equal(table2, table)
+    assert n_top2 == n_top and np.array_equal(np.sort(order), np.arange(pts.shape[0]))
+    np.testing.assert_array_equal(table[point_base:].reshape(-1, 3), pts[order])
+    # degenerate inputs: one point; all points equal (every split is a tie); the argument checks of the C entry point
+    one, n1 = _prims.build_point_tree(pts[:1])
+    assert n1 == 1 and one.size == 8 + 8 + 3 and one[7] == 1 and one[15] == 1
+    same, ns_ = _prims.build_point_tree(np.repeat(pts[:1], 1000, axis=0))
+    assert same.size == 3 * 1000 + 8 * ns_ + 8 * int(sum(same[8 * t + 7] for t in range(ns_)))
+    with pytest.raises(ValueError):
+        built.point_tree(np.zeros((0, 3), dtype=np.float32), 32)
+    with pytest.raises(built.SdfkError):
+        built.point_tree(pts, 1)
     # through the public classes: large clouds lower to the tree, small ones to the scan
     names = lambda obj: [_ops.OPS[w & 255].name for w in lower_geometry(obj).code[:, 0]]      # noqa: E731
     assert "P_NEARTREE" in names(ns.geom_3d.PointCloud3D(pts.T.astype(np.float64)))
