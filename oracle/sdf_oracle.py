@@ -924,26 +924,28 @@ def _post(fn):
     return wrapped
 
 
-MODS["sigmoid_falloff"] = _post(lambda u, a: a["amplitude"] * (1 / (1 + np.exp(4 * u / a["width"]))))
-MODS["positive_sigmoid_falloff"] = _post(
-    lambda u, a: a["amplitude"] * (1 / (1 + np.exp(4 * (u - a["width"]) / a["width"]))))
-MODS["capped_exponential"] = _post(lambda u, a: a["amplitude"] * np.minimum(np.exp(-4 * u / a["width"]), 1))
-MODS["hard_binarization"] = _post(lambda u, a: (u <= a["threshold"]).astype(float))
-MODS["linear_falloff"] = _post(lambda u, a: np.clip(1 - u / a["width"], 0, 1) * a["amplitude"])
-MODS["relu"] = _post(lambda u, a: np.maximum(u / a["width"], 0))
-MODS["smooth_relu"] = _post(
-    lambda u, a: (u / a["width"] + np.sqrt((u / a["width"]) ** 2
-                                           + (a["smooth_width"] + a["threshold"]) * 4 * a["threshold"])) / 2)
-
-
+# u = the field, a = the keyword arguments of the function (the array-level functions of C/post_processing.py and the
+# modification methods of the same names share these formulas)
 def _slowstart(u, a):
     b = (2 * a["smooth_width"] + a["threshold"]) * a["threshold"]
     return np.sqrt(np.maximum(u / a["width"], 0) ** 2 + b / a["width"]) - np.sqrt(b / a["width"]) * a["ground"]
 
 
-MODS["slowstart"] = _post(_slowstart)
-MODS["gaussian_boundary"] = _post(lambda u, a: a["amplitude"] * np.exp(-4 * (u / a["width"]) ** 2))
-MODS["gaussian_falloff"] = _post(lambda u, a: a["amplitude"] * np.exp(-4 * (np.maximum(u, 0) / a["width"]) ** 2))
+POST_FUNCTIONS = {
+    "sigmoid_falloff": lambda u, a: a["amplitude"] * (1 / (1 + np.exp(4 * u / a["width"]))),
+    "positive_sigmoid_falloff": lambda u, a: a["amplitude"] * (1 / (1 + np.exp(4 * (u - a["width"]) / a["width"]))),
+    "capped_exponential": lambda u, a: a["amplitude"] * np.minimum(np.exp(-4 * u / a["width"]), 1),
+    "hard_binarization": lambda u, a: (u <= a["threshold"]).astype(float),
+    "linear_falloff": lambda u, a: np.clip(1 - u / a["width"], 0, 1) * a["amplitude"],
+    "relu": lambda u, a: np.maximum(u / a["width"], 0),
+    "smooth_relu": lambda u, a: (u / a["width"] + np.sqrt((u / a["width"]) ** 2
+                                                          + (a["smooth_width"] + a["threshold"]) * 4 * a["threshold"])) / 2,
+    "slowstart": _slowstart,
+    "gaussian_boundary": lambda u, a: a["amplitude"] * np.exp(-4 * (u / a["width"]) ** 2),
+    "gaussian_falloff": lambda u, a: a["amplitude"] * np.exp(-4 * (np.maximum(u, 0) / a["width"]) ** 2),
+}
+for _name, _fn in POST_FUNCTIONS.items():
+    MODS[_name] = _post(_fn)
 
 
 @_m("custom_modification")   # C/modifications.py:1353-1356

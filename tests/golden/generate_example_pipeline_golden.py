@@ -1,16 +1,16 @@
 """Fixture generator for the reference's own VECTOR example scripts — runs ONLY in the build container (the reference is
 mounted read-only at /root/reference; it never travels).
 
-For every entry of tests/example_vector_scenes.py:
+For every entry of tests/example_pipelines.py:
   1. the example SCRIPT itself is executed against the real reference (plots stubbed, its variant constant set as the entry
      says); `final_field` and the six read-outs are taken from its namespace;
   2. the entry's workflow is walked by the real reference at the script's own resolution with a pass-through hook: all
      seven arrays must equal the script's bit for bit — the workflow IS the script's pipeline;
   3. the workflow is walked by the real reference on the entry's reduced grid with a RECORDING hook: every array is stored
      as computed (float64) and the walk continues from its fp32 rounding (the "identical grids" rule applied to every
-     stage: `example_vector_scenes.continue_from`). tests/test_example_vector_scenes.py replays the stages against the oracle and the GPU path.
+     stage: `example_pipelines.continue_from`). tests/test_example_pipelines.py replays the stages against the oracle and the GPU path.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/generate_example_vector_golden.py
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/generate_example_pipeline_golden.py
 """
 import contextlib
 import io
@@ -28,10 +28,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, HERE)
 sys.path.insert(0, "/root/reference/Code/spomso")
 sys.dont_write_bytecode = True
-VECTOR_DIR = "/root/reference/Code/examples/vector"
+EXAMPLES_DIR = "/root/reference/Code/examples"
 
 import spomso.cores as ref  # noqa: E402  (the real reference)
-import example_vector_scenes as evs  # noqa: E402
+import example_pipelines as evs  # noqa: E402
 from generate_example_golden import run_script  # noqa: E402
 
 
@@ -45,7 +45,7 @@ def main():
         t0 = time.time()
         if e["raises"] is not None:
             got = []
-            for walk in (lambda: run_script(e["script"], e["overrides"], base=VECTOR_DIR),
+            for walk in (lambda: run_script(e["script"], e["overrides"], e["cwd"], base=EXAMPLES_DIR),
                          lambda: e["run"](ref, ev, lambda _stage, value: value, e["size"], e["res"], **e["variant"])):
                 try:
                     walk()
@@ -60,15 +60,16 @@ def main():
                 failures.append((name, "expected %s, got %r" % (e["raises"].__name__, got)))
             continue
         try:
-            space = run_script(e["script"], e["overrides"], base=VECTOR_DIR,
+            space = run_script(e["script"], e["overrides"], e["cwd"], base=EXAMPLES_DIR,
                                hide=("show_3d", "show_field_3d", "show_field", "show_midplane"))
             with contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):
                 full = e["run"](ref, ev, lambda _stage, value: value, e["size"], e["full_res"], **e["variant"])
             same = True
-            for r in evs.READ_OUTS:
-                theirs = np.asarray(space[evs.SCRIPT_VARIABLES[r]], dtype=np.float64)
+            assert set(full) == set(e["outputs"]), (set(full), set(e["outputs"]))
+            for r, (variable, reshaped) in e["outputs"].items():
+                theirs = np.asarray(space[variable], dtype=np.float64)
                 mine = np.asarray(full[r], dtype=np.float64)
-                if r != "create":
+                if reshaped:
                     mine = np.asarray(reshape(mine, e["full_res"]), dtype=np.float64)   # the scripts keep these as grids
                 same = same and theirs.shape == mine.shape and np.array_equal(theirs, mine, equal_nan=True)
             stages = {}
@@ -92,11 +93,11 @@ def main():
                                 "workflow_equals_script_bit_for_bit": bool(same),
                                 "nan": int(sum(np.isnan(v).sum() for v in stages.values()))}
         print("%-40s script == workflow: %-5s  %d stages, %d points  (%.1f s)"
-              % (name, same, len(stages), stages["out/x"].size, time.time() - t0), flush=True)
+              % (name, same, len(stages), stages["coor"].shape[1], time.time() - t0), flush=True)
         if not same:
             failures.append((name, "workflow differs from the script"))
-    np.savez_compressed(os.path.join(HERE, "example_vector_golden.npz"), **out)
-    with open(os.path.join(HERE, "example_vector_golden_meta.json"), "w") as f:
+    np.savez_compressed(os.path.join(HERE, "example_pipelines.npz"), **out)
+    with open(os.path.join(HERE, "example_pipelines_meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     for name, err in failures:
         print("  FAILED %-36s %s" % (name, err[:300]))

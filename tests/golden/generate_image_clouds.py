@@ -1,7 +1,7 @@
 """Fixture generator (build container only): the point clouds the reference's image examples extract from its own test
 images (Files/test_images/*.png through `Points.from_image`, C/geom.py), kept as DATA in tests/golden/image_clouds.npz —
 x and y of every point, float64, bit for bit (pixel lattices: they compress to tens of kilobytes). The example builders of
-tests/example_scenes.py / example_vector_scenes.py read them; `generate_example_golden.py` then proves each builder equal
+tests/example_scenes.py / example_pipelines.py read them; `generate_example_golden.py` then proves each builder equal
 to its script, which pins these arrays to what the script itself extracts.
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/generate_image_clouds.py
