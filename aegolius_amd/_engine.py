@@ -589,23 +589,23 @@ def linspace_f32(lo, hi, n):
 
 
 def point_tree(points32, leaf, with_order=False):
-    """sdfk_point_tree_build: (m, 3) fp32 points -> (table, n_top, point_base, order or None). Host only."""
+    """sdfk_point_tree_build: (m, 3) fp32 points -> (table, n_root, point_base, order or None). Host only."""
     pts = np.ascontiguousarray(points32, dtype=np.float32)
     if pts.ndim != 2 or pts.shape[1] != 3 or pts.shape[0] < 1:
         raise ValueError("points must have shape (M, 3), M >= 1; got %r" % (pts.shape,))
     m = int(pts.shape[0])
     half = max(1, int(leaf) // 2)
-    cap = 3 * m + 8 * (m // half + 2) + 8 * (m // half // int(leaf) + 2)
+    cap = 3 * m + 24 * (m // half + 4)
     table = np.empty(cap, dtype=np.float32)
     order = np.empty(m, dtype=np.int64) if with_order else None
-    n_top, point_base = _c.c_int64(0), _c.c_int64(0)
+    n_root, point_base = _c.c_int64(0), _c.c_int64(0)
     used = lib().sdfk_point_tree_build(_ptr(pts), m, int(leaf), _ptr(table), cap, _ptr(order) if with_order else None,
-                                       _c.byref(n_top), _c.byref(point_base))
+                                       _c.byref(n_root), _c.byref(point_base))
     if used == -2:
         raise ValueError(last_error())
     if used < 0:
         raise SdfkError("sdfk_point_tree_build: " + last_error())
-    return table[:used].copy(), int(n_top.value), int(point_base.value), order
+    return table[:used].copy(), int(n_root.value), int(point_base.value), order
 
 
 def grid_fill(d_co, row_stride, axes, start, count, stream=None):

@@ -295,12 +295,12 @@ def _curve_instancing(L, e, creg, mode, params):
     centres = np.ascontiguousarray(rows[:, :3], dtype=np.float32)
     if n > TREE_THRESHOLD and np.all(np.isfinite(centres)):
         # many instances: nearest centre through the box tree of the point clouds
-        tree, n_top, point_base, order = build_point_tree(centres, with_order=True)
+        tree, n_root, point_base, order = build_point_tree(centres, with_order=True)
         tree_off = L.add_table(tree)
         rows_off = L.add_table(rows)
         order_off = L.add_table(order)                         # original index of the tree's points, leaf order
         return _coord_mod(L, e, creg, mode, params,
-                          [("CURVEINSTT", 0, [n_top, tree_off, 1.0 if frames else 0.0, rows_off, point_base, order_off])])
+                          [("CURVEINSTT", 0, [n_root, tree_off, 1.0 if frames else 0.0, rows_off, point_base, order_off])])
     off = L.add_table(rows)
     return _coord_mod(L, e, creg, mode, params, [("CURVEINST", 0, [n, off, 1.0 if frames else 0.0])])
 

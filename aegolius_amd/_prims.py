@@ -252,21 +252,22 @@ def emit_segline2(L, v, c, points, extra=(), closed_loop=False):
 
 
 TREE_THRESHOLD = 256     # tables up to this many points are scanned (P_NEAREST*), larger ones go through a box tree
-TREE_LEAF = 32           # points per leaf box, leaf boxes per top box
+TREE_LEAF = 32           # points per leaf box = children per box on the two levels above
 
 
 def build_point_tree(points32, with_order=False):
-    """(M, 3) float32 points -> flat float32 table for P_NEARTREE and the number of top boxes
+    """(M, 3) float32 points -> flat float32 table for P_NEARTREE and the number of root boxes
     (with_order: also the index of the tree's first point and the original indices of the points in leaf order).
     k-d median splits along the longest axis down to leaves of <= TREE_LEAF points; consecutive leaves (spatially
-    coherent in k-d order) are grouped TREE_LEAF at a time under one top box. Boxes are the exact float32 bounds
-    of their points. Built by the library on the host (sdfk_point_tree_build: compiled code, as the reference's scipy
-    KDTree is; 1.7 M points in a fraction of a second) — no GPU involved."""
+    coherent in k-d order) are grouped TREE_LEAF at a time under one middle box, middle boxes TREE_LEAF at a time under
+    one root box. Boxes are the exact float32 bounds of their points. Built by the library on the host
+    (sdfk_point_tree_build: compiled code, as the reference's scipy KDTree is; 1.7 M points in a fraction of a second)
+    — no GPU involved."""
     from . import _engine
-    table, n_top, point_base, order = _engine.point_tree(points32, TREE_LEAF, with_order)
+    table, n_root, point_base, order = _engine.point_tree(points32, TREE_LEAF, with_order)
     if with_order:
-        return table, n_top, point_base, order
-    return table, n_top
+        return table, n_root, point_base, order
+    return table, n_root
 
 
 def emit_nearest(L, v, c, samples, dim):
@@ -280,9 +281,9 @@ def emit_nearest(L, v, c, samples, dim):
             p32 = np.zeros((s.shape[1], 3), dtype=np.float32)
             p32[:, :dim] = s.T.astype(np.float32)
         if np.all(np.isfinite(p32)):
-            table, n_top = build_point_tree(p32)
+            table, n_root = build_point_tree(p32)
             off = L.add_table(table)
-            L.emit("P_NEARTREE", v, c, params=[n_top, off, dim])
+            L.emit("P_NEARTREE", v, c, params=[n_root, off, dim])
             return
     off = L.add_table(s.T)
     L.emit("P_NEAREST3" if dim == 3 else "P_NEAREST2", v, c, params=[s.shape[1], off])

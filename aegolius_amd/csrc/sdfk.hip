@@ -282,35 +282,41 @@ static int table_rows_ok(const sdfk_program* p, int op, const float* P, std::str
         case SDFK_OP_CURVEINST: row = (P[2] != 0.0f) ? 12 : 3; break;
         case SDFK_OP_CURVEINSTT:
         case SDFK_OP_P_NEARTREE: {
-            // every index the kernel will follow stays inside the table; leaves are non-empty
-            if (cnt < 1) return bad("point tree without top boxes");
+            // every index the kernel will follow stays inside the table; no box is empty (root -> middle -> leaf -> points)
+            if (cnt < 1) return bad("point tree without root boxes");
             if (op == SDFK_OP_P_NEARTREE && P[2] != 2.0f && P[2] != 3.0f) return bad("point tree dimension must be 2 or 3");
-            if (off + 8 * cnt > nt) return bad("point tree: top boxes out of range");
+            if (off + 8 * cnt > nt) return bad("point tree: root boxes out of range");
             const float* t = p->tables.data() + off;
             const long long room = nt - off;
-            for (long long i = 0; i < cnt; ++i) {
-                const float fl = t[8 * i + 6], fn = t[8 * i + 7];
-                const long long first = (long long)fl, nl = (long long)fn;
-                if (!(fl >= 0.0f) || !(fn >= 1.0f) || (float)first != fl || (float)nl != fn || first + 8 * nl > room)
-                    return bad("point tree: leaf boxes out of range");
-                for (long long l = 0; l < nl; ++l) {
-                    const float pf = t[first + 8 * l + 6], pn = t[first + 8 * l + 7];
-                    const long long pfirst = (long long)pf, pcount = (long long)pn;
-                    if (!(pf >= 0.0f) || !(pn >= 1.0f) || (float)pfirst != pf || (float)pcount != pn || pfirst + 3 * pcount > room)
-                        return bad("point tree: points out of range");
-                    if (op == SDFK_OP_CURVEINSTT) {
-                        // the original index of every point the kernel can pick is readable and names a row inside the table
-                        const long long base = (long long)P[4], rows = (long long)P[3], ids = (long long)P[5];
-                        const long long stride = (P[2] != 0.0f) ? 12 : 3;
-                        if (!(P[3] >= 0.0f) || !(P[4] >= 0.0f) || !(P[5] >= 0.0f) || (float)base != P[4] || (float)rows != P[3] ||
-                            (float)ids != P[5] || pfirst < base || (pfirst - base) % 3 != 0 ||
-                            ids + (pfirst - base) / 3 + pcount > nt)
-                            return bad("instancing tree: original indices out of range");
-                        for (long long q = 0; q < pcount; ++q) {
-                            const float of = p->tables[(size_t)(ids + (pfirst - base) / 3 + q)];
-                            const long long o = (long long)of;
-                            if (!(of >= 0.0f) || (float)o != of || rows + (o + 1) * stride > nt)
-                                return bad("instancing tree: instance row out of range");
+            auto kids = [&](const float* box, long long width, long long* first, long long* n) {
+                const float ff = box[6], fn = box[7];
+                *first = (long long)ff;
+                *n = (long long)fn;
+                return ff >= 0.0f && fn >= 1.0f && (float)*first == ff && (float)*n == fn && *first + width * *n <= room;
+            };
+            for (long long r = 0; r < cnt; ++r) {
+                long long mfirst, nm;
+                if (!kids(t + 8 * r, 8, &mfirst, &nm)) return bad("point tree: middle boxes out of range");
+                for (long long i = 0; i < nm; ++i) {
+                    long long first, nl;
+                    if (!kids(t + mfirst + 8 * i, 8, &first, &nl)) return bad("point tree: leaf boxes out of range");
+                    for (long long l = 0; l < nl; ++l) {
+                        long long pfirst, pcount;
+                        if (!kids(t + first + 8 * l, 3, &pfirst, &pcount)) return bad("point tree: points out of range");
+                        if (op == SDFK_OP_CURVEINSTT) {
+                            // the original index of every point the kernel can pick is readable and names a row inside the table
+                            const long long base = (long long)P[4], rows = (long long)P[3], ids = (long long)P[5];
+                            const long long stride = (P[2] != 0.0f) ? 12 : 3;
+                            if (!(P[3] >= 0.0f) || !(P[4] >= 0.0f) || !(P[5] >= 0.0f) || (float)base != P[4] || (float)rows != P[3] ||
+                                (float)ids != P[5] || pfirst < base || (pfirst - base) % 3 != 0 ||
+                                ids + (pfirst - base) / 3 + pcount > nt)
+                                return bad("instancing tree: original indices out of range");
+                            for (long long q = 0; q < pcount; ++q) {
+                                const float of = p->tables[(size_t)(ids + (pfirst - base) / 3 + q)];
+                                const long long o = (long long)of;
+                                if (!(of >= 0.0f) || (float)o != of || rows + (o + 1) * stride > nt)
+                                    return bad("instancing tree: instance row out of range");
+                            }
                         }
                     }
                 }

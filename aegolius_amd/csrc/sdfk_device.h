@@ -549,8 +549,11 @@ SDFK_DEV float prim_nearest3(V3 p, const float* __restrict__ P, const float* __r
 }
 
 // The same distance for large tables: points sorted into leaves of <= 32 (k-d median splits, built on
-// the host: _prims.build_point_tree), leaves grouped into <= 32 per top box. Table at T + P[1]:
-//   top boxes  P[0] x 8 floats : lo(3), hi(3), index of the first leaf box, leaf boxes
+// the host: sdfk_point_tree_build), <= 32 consecutive leaves under one middle box, <= 32 consecutive middle boxes under
+// one root box (round 4: the third level — a cloud of 1.7 M points has 1,696 middle boxes, and a walk that looked at each
+// of them twice per query was a serial chain of milliseconds). Table at T + P[1]:
+//   root boxes   P[0] x 8 floats : lo(3), hi(3), index of the first middle box, middle boxes
+//   middle boxes        8 floats : lo(3), hi(3), index of the first leaf box, leaf boxes
 //   leaf boxes          8 floats : lo(3), hi(3), index of the first point, points      (indices relative to the table)
 //   points              3 floats (2-D tables carry z = 0 and the query's z is ignored)
 // A box is skipped only if a slightly deflated lower bound of its distance exceeds the best squared distance found
@@ -570,35 +573,48 @@ SDFK_DEV float sd_scan_leaf(V3 p, const float* __restrict__ tab, const float* __
     }
     return best;
 }
+// index of the child of `box` (8-float rows at tab + box[6], box[7] of them) nearest to p
+SDFK_DEV int sd_nearest_child(V3 p, const float* __restrict__ tab, const float* __restrict__ box) {
+    const float* __restrict__ kids = tab + (int)box[6];
+    const int n = (int)box[7];
+    int b = 0;
+    float bd = 3.0e38f;
+    for (int k = 0; k < n; ++k) {
+        const float d = sd_boxdist2(p, kids + 8 * k);
+        if (d < bd) { bd = d; b = k; }
+    }
+    return b;
+}
 SDFK_DEV float prim_neartree(V3 p, const float* __restrict__ P, const float* __restrict__ T) {
-    const int n_top = (int)P[0];
+    const int n_root = (int)P[0];
     const float* __restrict__ tab = T + (int)P[1];
     if (P[2] == 2.0f) p.z = 0.0f;
-    // a first bound: the nearest top box, its nearest leaf
-    int bt = 0;
+    // a first bound: the nearest root box, its nearest middle box, its nearest leaf
+    int br = 0;
     float bd = 3.0e38f;
-    for (int t = 0; t < n_top; ++t) {
-        const float d = sd_boxdist2(p, tab + 8 * t);
-        if (d < bd) { bd = d; bt = t; }
+    for (int r = 0; r < n_root; ++r) {
+        const float d = sd_boxdist2(p, tab + 8 * r);
+        if (d < bd) { bd = d; br = r; }
     }
-    const float* __restrict__ leaves0 = tab + (int)tab[8 * bt + 6];
-    int bl = 0;
-    bd = 3.0e38f;
-    for (int l = 0; l < (int)tab[8 * bt + 7]; ++l) {
-        const float d = sd_boxdist2(p, leaves0 + 8 * l);
-        if (d < bd) { bd = d; bl = l; }
-    }
-    float best = sd_scan_leaf(p, tab, leaves0 + 8 * bl, 3.0e38f);
+    const float* __restrict__ mid0 = tab + (int)tab[8 * br + 6] + 8 * sd_nearest_child(p, tab, tab + 8 * br);
+    const float* __restrict__ leaf0 = tab + (int)mid0[6] + 8 * sd_nearest_child(p, tab, mid0);
+    float best = sd_scan_leaf(p, tab, leaf0, 3.0e38f);
     // pruned sweep over everything else
-    for (int t = 0; t < n_top; ++t) {
-        const float* __restrict__ tb = tab + 8 * t;
-        if (sd_boxdist2(p, tb) > best) continue;
-        const float* __restrict__ leaves = tab + (int)tb[6];
-        const int nl = (int)tb[7];
-        for (int l = 0; l < nl; ++l) {
-            const float* __restrict__ lf = leaves + 8 * l;
-            if ((t == bt && l == bl) || sd_boxdist2(p, lf) > best) continue;
-            best = sd_scan_leaf(p, tab, lf, best);
+    for (int r = 0; r < n_root; ++r) {
+        const float* __restrict__ rb = tab + 8 * r;
+        if (sd_boxdist2(p, rb) > best) continue;
+        const float* __restrict__ mids = tab + (int)rb[6];
+        const int nm = (int)rb[7];
+        for (int m = 0; m < nm; ++m) {
+            const float* __restrict__ mb = mids + 8 * m;
+            if (sd_boxdist2(p, mb) > best) continue;
+            const float* __restrict__ leaves = tab + (int)mb[6];
+            const int nl = (int)mb[7];
+            for (int l = 0; l < nl; ++l) {
+                const float* __restrict__ lf = leaves + 8 * l;
+                if (lf == leaf0 || sd_boxdist2(p, lf) > best) continue;
+                best = sd_scan_leaf(p, tab, lf, best);
+            }
         }
     }
     return sd_sqrt(best);
@@ -627,35 +643,36 @@ SDFK_DEV void sd_scan_leaf_idx(V3 p, const float* __restrict__ tab, const float*
     }
 }
 SDFK_DEV V3 op_curveinstt(V3 p, const float* __restrict__ P, const float* __restrict__ T, int) {
-    const int n_top = (int)P[0];
+    const int n_root = (int)P[0];
     const float* __restrict__ tab = T + (int)P[1];
     const float* __restrict__ orig = T + (int)P[5];
     const int point_base = (int)P[4];
-    int bt = 0;
+    int br = 0;
     float bd = 3.0e38f;
-    for (int t = 0; t < n_top; ++t) {
-        const float d = sd_boxdist2(p, tab + 8 * t);
-        if (d < bd) { bd = d; bt = t; }
+    for (int r = 0; r < n_root; ++r) {
+        const float d = sd_boxdist2(p, tab + 8 * r);
+        if (d < bd) { bd = d; br = r; }
     }
-    const float* __restrict__ leaves0 = tab + (int)tab[8 * bt + 6];
-    int bl = 0;
-    bd = 3.0e38f;
-    for (int l = 0; l < (int)tab[8 * bt + 7]; ++l) {
-        const float d = sd_boxdist2(p, leaves0 + 8 * l);
-        if (d < bd) { bd = d; bl = l; }
-    }
+    const float* __restrict__ mid0 = tab + (int)tab[8 * br + 6] + 8 * sd_nearest_child(p, tab, tab + 8 * br);
+    const float* __restrict__ leaf0 = tab + (int)mid0[6] + 8 * sd_nearest_child(p, tab, mid0);
     float best = 3.0e38f;
     int who = 0x7fffffff;
-    sd_scan_leaf_idx(p, tab, leaves0 + 8 * bl, orig, point_base, &best, &who);
-    for (int t = 0; t < n_top; ++t) {
-        const float* __restrict__ tb = tab + 8 * t;
-        if (sd_boxdist2(p, tb) > best) continue;              // a box AT the best distance is still visited (ties)
-        const float* __restrict__ leaves = tab + (int)tb[6];
-        const int nl = (int)tb[7];
-        for (int l = 0; l < nl; ++l) {
-            const float* __restrict__ lf = leaves + 8 * l;
-            if ((t == bt && l == bl) || sd_boxdist2(p, lf) > best) continue;
-            sd_scan_leaf_idx(p, tab, lf, orig, point_base, &best, &who);
+    sd_scan_leaf_idx(p, tab, leaf0, orig, point_base, &best, &who);
+    for (int r = 0; r < n_root; ++r) {
+        const float* __restrict__ rb = tab + 8 * r;
+        if (sd_boxdist2(p, rb) > best) continue;              // a box AT the best distance is still visited (ties)
+        const float* __restrict__ mids = tab + (int)rb[6];
+        const int nm = (int)rb[7];
+        for (int m = 0; m < nm; ++m) {
+            const float* __restrict__ mb = mids + 8 * m;
+            if (sd_boxdist2(p, mb) > best) continue;
+            const float* __restrict__ leaves = tab + (int)mb[6];
+            const int nl = (int)mb[7];
+            for (int l = 0; l < nl; ++l) {
+                const float* __restrict__ lf = leaves + 8 * l;
+                if (lf == leaf0 || sd_boxdist2(p, lf) > best) continue;
+                sd_scan_leaf_idx(p, tab, lf, orig, point_base, &best, &who);
+            }
         }
     }
     const int stride = (P[2] != 0.0f) ? 12 : 3;

@@ -336,12 +336,13 @@ int sdfk_linspace_f32(double lo, double hi, int64_t n, float* out);
  * Box tree over a point table for the nearest-point leaves (point clouds, resampled / parametric curves, curve
  * instancing: C/sdf_2D.py:221-224, C/sdf_3D.py:283-286 build a scipy KDTree per evaluation; here the tree is part of the
  * program's tables, built once per lowering). Host only, no GPU. pts: (m, 3) fp32, row-major; leaf: points per leaf box
- * = leaf boxes per top box (the lowering uses 32); table: out, capacity table_cap floats (3 m + 8 (m / (leaf / 2) + 2) +
- * 8 (m / (leaf / 2) / leaf + 2) always suffices); order: out or NULL, the original index of every point in leaf order;
- * n_top / point_base: out, the number of top boxes and the offset of the first point. Returns the number of floats
- * written, < 0 on error (-2: more than 2^24 words — table indices are carried as fp32). */
+ * = children per box on every level above (the lowering uses 32); table: out — root boxes, middle boxes, leaf boxes (8
+ * floats each: lo, hi, first child, children), then the points in leaf order —, capacity table_cap floats (3 m + 24 (m /
+ * (leaf / 2) + 4) always suffices); order: out or NULL, the original index of every point in leaf order; n_root /
+ * point_base: out, the number of root boxes and the offset of the first point. Returns the number of floats written,
+ * < 0 on error (-2: more than 2^24 words — table indices are carried as fp32). */
 int64_t sdfk_point_tree_build(const float* pts, int64_t m, int leaf, float* table, int64_t table_cap, int64_t* order,
-                              int64_t* n_top, int64_t* point_base);
+                              int64_t* n_root, int64_t* point_base);
 
 /* Fill a device (3, count) coordinate slab for flat indices [start, start+count) of the grid. */
 int sdfk_grid_fill(float* d_co, int64_t row_stride, const float* ax0, int64_t n0, const float* ax1, int64_t n1,

@@ -492,7 +492,7 @@ def custom_post_processing_2d(ns):
 # surface, kept as DATA in tests/golden/terrain_lr_cloud.npz (float64, bit for bit). The script evaluates it on 151 x 151 x
 # 101 points (nine minutes in the reference); the generator runs the script itself with co_resolution = (50, 50, 34) — the
 # same scene, seconds — and the fixture is the reference's field on a 31 x 31 x 21 grid. Here the cloud goes through the
-# two-level box tree (P_NEARTREE: more than 256 points).
+# three-level box tree (P_NEARTREE: more than 256 points).
 def terrain_cloud():
     import os
     return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "terrain_lr_cloud.npz"))["cloud"]
@@ -512,7 +512,7 @@ def pointcloud_terrain_3d(ns):
 # `Points.from_image`; `Points` itself is outside SURVEY §8): kept as DATA in tests/golden/image_clouds.npz by
 # tests/golden/generate_image_clouds.py — 64,691 points of hand-drawn lines, the 332,281 + 1,735,884 pixels outside / inside
 # a logo, 201,874 points of four shapes. Nearest-point leaves three to one hundred times the size of the terrain cloud
-# (SURVEY §8(f).2): all through the two-level box tree. Proven equal to what the scripts extract by the generator's
+# (SURVEY §8(f).2): all through the three-level box tree. Proven equal to what the scripts extract by the generator's
 # script == builder check.
 def image_cloud(name):
     import os

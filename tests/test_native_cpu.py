@@ -132,38 +132,50 @@ def test_cull_sites_are_validated(built):
 
 
 def test_point_tree_layout_and_validation(built):
-    """P_NEARTREE: every point sits in exactly one leaf, boxes are the exact bounds, indices stay inside the table;
+    """P_NEARTREE: every point sits in exactly one leaf of the three-level tree, boxes are the exact bounds, indices stay
+    inside the table;
     the library refuses a tree whose indices leave it."""
     from aegolius_amd import _prims
     rng = np.random.default_rng(4)
     pts = rng.normal(0, 1, (5000, 3)).astype(np.float32)
-    table, n_top = _prims.build_point_tree(pts)
+    table, n_root = _prims.build_point_tree(pts)
     seen = []
-    for t in range(n_top):
-        lo, hi, first, nl = table[8 * t:8 * t + 3], table[8 * t + 3:8 * t + 6], int(table[8 * t + 6]), int(table[8 * t + 7])
-        assert 1 <= nl <= _prims.TREE_LEAF
-        for l in range(nl):
-            row = table[first + 8 * l: first + 8 * l + 8]
-            pf, pn = int(row[6]), int(row[7])
-            assert 1 <= pn <= _prims.TREE_LEAF
-            p = table[pf:pf + 3 * pn].reshape(-1, 3)
-            np.testing.assert_array_equal(p.min(axis=0), row[0:3])
-            np.testing.assert_array_equal(p.max(axis=0), row[3:6])
-            assert np.all(row[0:3] >= lo) and np.all(row[3:6] <= hi)
-            seen.append(p)
+    assert n_root == 1                                          # 5000 points: 157 .. 313 leaves, <= 10 middle boxes
+    for r in range(n_root):
+        rlo, rhi, mfirst, nm = table[8 * r:8 * r + 3], table[8 * r + 3:8 * r + 6], int(table[8 * r + 6]), int(table[8 * r + 7])
+        assert 1 <= nm <= _prims.TREE_LEAF
+        for m in range(nm):
+            mid = table[mfirst + 8 * m: mfirst + 8 * m + 8]
+            lo, hi, first, nl = mid[0:3], mid[3:6], int(mid[6]), int(mid[7])
+            assert 1 <= nl <= _prims.TREE_LEAF and np.all(lo >= rlo) and np.all(hi <= rhi)
+            for l in range(nl):
+                row = table[first + 8 * l: first + 8 * l + 8]
+                pf, pn = int(row[6]), int(row[7])
+                assert 1 <= pn <= _prims.TREE_LEAF
+                p = table[pf:pf + 3 * pn].reshape(-1, 3)
+                np.testing.assert_array_equal(p.min(axis=0), row[0:3])
+                np.testing.assert_array_equal(p.max(axis=0), row[3:6])
+                assert np.all(row[0:3] >= lo) and np.all(row[3:6] <= hi)
+                seen.append(p)
     seen = np.concatenate(seen)
     assert seen.shape == pts.shape
     np.testing.assert_array_equal(np.sort(seen.view("f4,f4,f4").ravel()), np.sort(pts.view("f4,f4,f4").ravel()))
     # the leaf order of the points (what CURVEINSTT maps back to instance rows) is a permutation that reproduces the table
-    table2, n_top2, point_base, order = _prims.build_point_tree(pts, with_order=True)
+    table2, n_root2, point_base, order = _prims.build_point_tree(pts, with_order=True)
     np.testing.assert_array_equal(table2, table)
-    assert n_top2 == n_top and np.array_equal(np.sort(order), np.arange(pts.shape[0]))
+    assert n_root2 == n_root and np.array_equal(np.sort(order), np.arange(pts.shape[0]))
     np.testing.assert_array_equal(table[point_base:].reshape(-1, 3), pts[order])
     # degenerate inputs: one point; all points equal (every split is a tie); the argument checks of the C entry point
     one, n1 = _prims.build_point_tree(pts[:1])
-    assert n1 == 1 and one.size == 8 + 8 + 3 and one[7] == 1 and one[15] == 1
+    assert n1 == 1 and one.size == 8 + 8 + 8 + 3 and one[7] == 1 and one[15] == 1 and one[23] == 1
     same, ns_ = _prims.build_point_tree(np.repeat(pts[:1], 1000, axis=0))
-    assert same.size == 3 * 1000 + 8 * ns_ + 8 * int(sum(same[8 * t + 7] for t in range(ns_)))
+    assert ns_ == 1 and same[8 * ns_ + 7] >= 1
+    big, nb = _prims.build_point_tree(rng.normal(0, 1, (70000, 3)).astype(np.float32))
+    assert 3 <= nb <= 5                                         # 2188 .. 4375 leaves -> 69 .. 137 middle boxes -> 3 .. 5 roots
+    n_mid = int(sum(big[8 * r + 7] for r in range(nb)))
+    n_leaf = int(sum(big[8 * nb + 8 * m + 7] for m in range(n_mid)))
+    assert big.size == 8 * (nb + n_mid + n_leaf) + 3 * 70000
+    assert int(sum(big[8 * (nb + n_mid) + 8 * l + 7] for l in range(n_leaf))) == 70000
     with pytest.raises(ValueError):
         built.point_tree(np.zeros((0, 3), dtype=np.float32), 32)
     with pytest.raises(built.SdfkError):
@@ -176,7 +188,7 @@ def test_point_tree_layout_and_validation(built):
     low = lower_geometry(ns.geom_3d.PointCloud3D(pts.T.astype(np.float64)))
     assert built.Program(low.code, low.params, low.tables, low.result_reg).handle
     bad = low.tables.copy()
-    bad[int(low.params[1]) + 6] = 1e7                       # first leaf index of top box 0 far outside
+    bad[int(low.params[1]) + 6] = 1e7                       # first middle box of root box 0 far outside
     with pytest.raises(built.SdfkError):
         built.Program(low.code, low.params, bad, low.result_reg)
 
