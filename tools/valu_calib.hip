@@ -17,6 +17,8 @@ __global__ __launch_bounds__(256) void calib(float* out, const float* __restrict
     f2 p0 = {x0, x1}, p1 = {x2, x3}, p2 = {x4, x5}, p3 = {x6, x7}, p4 = {x1, x0}, p5 = {x3, x2}, p6 = {x5, x4}, p7 = {x7, x6};
     const float a = prm[0], b = prm[1];
     f2 av = {x0 * 0 + a, x0 * 0 + a};
+    const float sa = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a)));
+    const unsigned long long spair = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a)) | (1ull << 62);
     for (int i = 0; i < trips; ++i) {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
@@ -66,7 +68,57 @@ __global__ __launch_bounds__(256) void calib(float* out, const float* __restrict
 #define I_CMP(k) "v_cmp_gt_f32_e32 vcc, %8, %" #k "\n"
 #define I_MAX(k) "v_max_f32_e32 %" #k ", %8, %" #k "\n"
 #define I_XOR(k) "v_xor_b32_e32 %" #k ", %8, %" #k "\n"
-                if (KIND == 8) A8(I_ADD);
+#define P8(INS) asm volatile(INS(0) INS(1) INS(2) INS(3) INS(4) INS(5) INS(6) INS(7) \
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "s"(spair), "v"(av))
+#define I_PKS(k) "v_pk_fma_f32 %" #k ", %" #k ", %8, %" #k " op_sel_hi:[1,0,1]\n"      /* constant: low half of an SGPR pair */
+#define I_PKV(k) "v_pk_fma_f32 %" #k ", %" #k ", %9, %" #k "\n"                         /* constant: a VGPR pair */
+#define I_FMAAK(k) "v_fmaak_f32 %" #k ", %8, %" #k ", 0x3c08839e\n"                     /* VOP2 with a 32-bit literal */
+#define I_FMA3(k) "v_fma_f32 %" #k ", %" #k ", %8, %9\n"                                 /* VOP3, all VGPRs */
+#define I_FMAMK(k) "v_fmamk_f32 %" #k ", %" #k ", 0x3c08839e, %8\n"                     /* VOP2, literal multiplier */
+#define I_FMAS(k) "v_fma_f32 %" #k ", %" #k ", %10, %8\n"                                /* VOP3, one SGPR operand */
+#define I_FMAI(k) "v_fma_f32 %" #k ", %" #k ", %8, 1.0\n"                                /* VOP3, inline constant addend */
+#define I_SUB(k) "v_sub_f32_e32 %" #k ", %8, %" #k "\n"
+#define I_MIN(k) "v_min_f32_e32 %" #k ", %8, %" #k "\n"
+#define I_MAX3(k) "v_max3_f32 %" #k ", %" #k ", %8, %9\n"
+#define I_BFI(k) "v_bfi_b32 %" #k ", %8, %" #k ", %9\n"
+#define I_BITOP(k) "v_bitop3_b32 %" #k ", %" #k ", %8, %9 bitop3:0x6c\n"
+#define I_LSHL(k) "v_lshlrev_b32_e32 %" #k ", 3, %" #k "\n"
+#define I_ASHR(k) "v_ashrrev_i32_e32 %" #k ", 1, %" #k "\n"
+#define I_ADDU(k) "v_add_u32_e32 %" #k ", %8, %" #k "\n"
+#define I_CVT(k) "v_cvt_i32_f32_e32 %" #k ", %" #k "\n"
+#define I_RND(k) "v_rndne_f32_e32 %" #k ", %" #k "\n"
+#define I_FLOOR(k) "v_floor_f32_e32 %" #k ", %" #k "\n"
+#define I_PKMUL(k) "v_pk_mul_f32 %" #k ", %" #k ", %9\n"
+#define I_PKADD(k) "v_pk_add_f32 %" #k ", %" #k ", %9\n"
+#define I_CNDS(k) "v_cndmask_b32_e64 %" #k ", %" #k ", %8, s[10:11]\n"                   /* select on an SGPR mask: no vcc dependency */
+#define I_MULS(k) "v_mul_f32_e32 %" #k ", %10, %" #k "\n"                                /* SGPR multiplier */
+#define I_ABSMAX(k) "v_max_f32_e64 %" #k ", |%" #k "|, %8\n"
+#define A8S(INS) asm volatile(INS(0) INS(1) INS(2) INS(3) INS(4) INS(5) INS(6) INS(7) \
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(av.x), "v"(av.y), "s"(sa) : "s10", "s11")
+                if (KIND == 21) A8(I_FMAMK);
+                else if (KIND == 22) A8S(I_FMAS);
+                else if (KIND == 23) A8(I_FMAI);
+                else if (KIND == 24) A8(I_SUB);
+                else if (KIND == 25) A8(I_MIN);
+                else if (KIND == 26) A8(I_MAX3);
+                else if (KIND == 27) A8(I_BFI);
+                else if (KIND == 28) A8(I_BITOP);
+                else if (KIND == 29) A8(I_LSHL);
+                else if (KIND == 30) A8(I_ASHR);
+                else if (KIND == 31) A8(I_ADDU);
+                else if (KIND == 32) A8(I_CVT);
+                else if (KIND == 33) A8(I_RND);
+                else if (KIND == 34) A8(I_FLOOR);
+                else if (KIND == 35) P8(I_PKMUL);
+                else if (KIND == 36) P8(I_PKADD);
+                else if (KIND == 37) A8S(I_CNDS);
+                else if (KIND == 38) A8S(I_MULS);
+                else if (KIND == 39) A8(I_ABSMAX);
+                else if (KIND == 17) P8(I_PKS);
+                else if (KIND == 18) P8(I_PKV);
+                else if (KIND == 19) A8(I_FMAAK);
+                else if (KIND == 20) A8(I_FMA3);
+                else if (KIND == 8) A8(I_ADD);
                 else if (KIND == 9) A8(I_MUL);
                 else if (KIND == 10) A8(I_MOV);
                 else if (KIND == 11) A8(I_AND);
@@ -121,5 +173,13 @@ int main(int argc, char** argv) {
     sweep<8>("v_add_f32_e32", trips); sweep<9>("v_mul_f32_e32", trips); sweep<10>("v_mov_b32_e32", trips); sweep<11>("v_and_b32_e32", trips);
     sweep<12>("v_cndmask_b32_e32", trips); sweep<13>("v_fmac_f32_e32", trips); sweep<14>("v_cmp_gt_f32_e32", trips); sweep<15>("v_max_f32_e32", trips);
     sweep<16>("v_xor_b32_e32", trips);
+    sweep<17>("v_pk_fma_f32 sgpr-pair constant", trips); sweep<18>("v_pk_fma_f32 vgpr-pair constant", trips);
+    sweep<19>("v_fmaak_f32 literal", trips); sweep<20>("v_fma_f32 vop3 vgprs", trips);
+    sweep<21>("v_fmamk_f32 literal", trips); sweep<22>("v_fma_f32 vop3 one sgpr", trips); sweep<23>("v_fma_f32 vop3 inline constant", trips);
+    sweep<24>("v_sub_f32_e32", trips); sweep<25>("v_min_f32_e32", trips); sweep<26>("v_max3_f32", trips); sweep<27>("v_bfi_b32", trips);
+    sweep<28>("v_bitop3_b32", trips); sweep<29>("v_lshlrev_b32_e32", trips); sweep<30>("v_ashrrev_i32_e32", trips);
+    sweep<31>("v_add_u32_e32", trips); sweep<32>("v_cvt_i32_f32_e32", trips); sweep<33>("v_rndne_f32_e32", trips);
+    sweep<34>("v_floor_f32_e32", trips); sweep<35>("v_pk_mul_f32", trips); sweep<36>("v_pk_add_f32", trips);
+    sweep<37>("v_cndmask_b32_e64 sgpr mask", trips); sweep<38>("v_mul_f32_e32 sgpr operand", trips); sweep<39>("v_max_f32_e64 abs modifier", trips);
     return 0;
 }
