@@ -1,6 +1,6 @@
 #!/bin/bash
 # Developer tool (GPU box): the evidence set of round 4. Writes gpurun_out/r04e_*; copy what is to be judged to profiles/.
-#   collect_profiles_r04.sh [a|b|c|all]   a: the driver's command + counters of cfg2 and the 513^3 grid;  b: counters and bench
+#   collect_profiles_r04.sh [a|b|c|cfg3|all]   a: the driver's command + counters of cfg2 and the 513^3 grid;  b: counters and bench
 #   lines of cfg3 / cfg5 / cfg4 / cfg1;  c: unions (kernel trace + list statistics), consumers, fused selection
 set -u
 tag=r04e
@@ -41,6 +41,10 @@ for w in cfg1 cfg3 cfg5; do python3 bench.py --workload $w $B > "$O/${tag}_${w}_
 python3 bench.py --workload cfg4 --grid 16384 --steps 100 --warmup 30 --no-extras --cpu-seconds 0 > "$O/${tag}_cfg4_bench.json" 2>/dev/null
 python3 bench.py --mode nocull --steps 10 --warmup 3 --no-extras --cpu-seconds 0 > "$O/${tag}_cfg2_bench_nocull.json" 2>/dev/null
 python3 bench.py --mode interpret --steps 5 --warmup 2 --no-extras --cpu-seconds 0 > "$O/${tag}_cfg2_bench_interpreter.json" 2>/dev/null
+fi
+if [ "$part" = cfg3 ]; then                                   # after the instruction diet of cfg 3: its own set again
+pmc_set cfg3 sdfk_spec_v4 python3 $R/bench.py --workload cfg3 $B
+python3 bench.py --workload cfg3 $B > "$O/${tag}_cfg3_bench.json" 2>/dev/null
 fi
 if [ "$part" = c ] || [ "$part" = all ]; then
 for n in 200 1000 4096 16384; do
