@@ -606,7 +606,20 @@ static int rows_waves(const sdfk_program*) {
     return 4;
 }
 static int rows_wbricks(const sdfk_program* p);
-static int rows_geo(const sdfk_program* p) { return rows_wbricks(p) | (rows_waves(p) << 4); }
+// Programs that are not chains and hold more than SDFK_BIG_PROGRAM instructions (300) are built with two LLVM passes off
+// (big_build_options): bit 16 of the geometry word, which selects the compiler options of a build and is part of its key
+static long long big_program_limit() {
+    static const long long v = [] {
+        const char* e = getenv("SDFK_BIG_PROGRAM");
+        const long long t = e ? atoll(e) : 300;
+        return t > 0 ? t : 300;
+    }();
+    return v;
+}
+static int rows_geo(const sdfk_program* p) {
+    const bool big = p && !p->chain_mode && (long long)(p->code.size() / 2) > big_program_limit();
+    return rows_wbricks(p) | (rows_waves(p) << 4) | (big ? 1 << 16 : 0);
+}
 static int rows_wbricks(const sdfk_program* p) {
     static int forced = [] { const char* e = getenv("SDFK_RWBRICKS"); int t = e ? atoi(e) : 0; return (t >= 1 && t <= 16) ? t : 0; }();
     if (const int o = g_rwbricks_override.load()) return o;
@@ -814,8 +827,10 @@ extern "C" void sdfk_debug_set_rtc_defs(const char* defs) {
 }
 // geo: bricks per wave | waves per workgroup << 4 of the row-block kernel (rows_geo)
 static std::vector<std::string> rtc_options(int geo) {
-    const int rwb = geo & 15, rwaves = (geo >> 4) ? (geo >> 4) : 4;
-    std::vector<std::string> o = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17",
+    const int rwb = geo & 15, rwaves = ((geo >> 4) & 0xff) ? ((geo >> 4) & 0xff) : 4;
+    const bool big = (geo >> 16) & 1;
+    const char* opt = getenv("SDFK_RTC_OPT");                 // experiments: "-O1" ... (the cache key carries the options)
+    std::vector<std::string> o = {"--offload-arch=gfx950", (opt && opt[0] == '-') ? opt : "-O3", "-ffp-contract=off", "-std=c++17",
                                   // -fno-honor-nans: v_min/v_max without the canonicalising pre-op. -mno-amdgpu-ieee (same
                                   // flags as the hipcc build of the interpreter kernel: both flavours stay bit-identical)
                                   // keeps the device library's sincos / atan2 / pow out of line — the inliner refuses
@@ -824,6 +839,28 @@ static std::vector<std::string> rtc_options(int geo) {
                                   "-fno-honor-nans", "-mno-amdgpu-ieee",
                                   "-DSDFK_TWAVES=" + std::to_string(tile_waves()), "-DSDFK_WBRICKS=" + std::to_string(tile_wbricks()),
                                   "-DSDFK_RWBRICKS=" + std::to_string(rwb), "-DSDFK_RWAVES=" + std::to_string(rwaves)};
+    if (big) {
+        // Big programs (round 4): hiprtc's time grows with the square of a straight-line program, and -ftime-report on a
+        // 599-instruction tree names the pass: CodeGenPrepare, 458 of 630 s (then VectorCombine, 31 of the remaining 151).
+        // Without the two a row-block build takes 30 s instead of 250 at 599 instructions, line bricks 33 s at 1199
+        // instead of 105 (profiles/r04_build_time.txt). CodeGenPrepare is worth 2 % on the north-star tree and 12 % on the
+        // 20-primitive one (profiles/r04_nocgp.txt) — so small programs keep it — but a culled kernel without it is still
+        // several times the interpreter kernel, which is what served these programs before. Same FP semantics: same bits.
+        o.push_back("-mllvm");
+        o.push_back("-disable-cgp");
+        o.push_back("-mllvm");
+        o.push_back("-disable-vector-combine");
+    }
+    if (const char* extra = getenv("SDFK_RTC_EXTRA")) {       // experiments: raw compiler options, space-separated
+        std::string e = extra;
+        size_t q = 0;
+        while (q < e.size()) {
+            size_t sp = e.find(' ', q);
+            if (sp == std::string::npos) sp = e.size();
+            if (sp > q) o.push_back(e.substr(q, sp - q));
+            q = sp + 1;
+        }
+    }
     std::string all;
     {
         std::lock_guard<std::mutex> lk(g_defs_mu);
@@ -1534,21 +1571,22 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
 
     // Build time bounds (programs that are not chains: those are table-driven and build in under a second whatever their
     // size). hiprtc's time grows faster than the program — profiles/r04_build_time.txt, left-deep smooth-union chains on
-    // the build container's CPU: row blocks 1 / 4 / 8 / 21 / 102 s at 29 / 89 / 179 / 299 / 449 instructions, line bricks
-    // 0.8 / 3 / 4 / 6 / 12 / 22 / 55 / 105 s at ... 449 / 599 / 899 / 1199, the plain kernel 0.4 ... 9 / 17 / 41 / 76 s —,
-    // so each flavour has a size up to which it is built, for a budget of about 20 s per build:
-    //   row blocks up to SDFK_ROWS_LIMIT instructions (300), line bricks (or, for unaligned arrays, the plain kernel) up to
-    //   SDFK_SPECIALIZE_LIMIT (600); beyond that AUTO stays on the interpreter kernel, which needs no compilation.
+    // the build container's CPU: row blocks 1 / 4 / 8 / 21 / 102 s at 29 / 89 / 179 / 299 / 449 instructions with the full
+    // pipeline; beyond SDFK_BIG_PROGRAM (300) instructions builds run without CodeGenPrepare and VectorCombine
+    // (rtc_options): row blocks 21 / 30 / 49 / 85 s at 449 / 599 / 899 / 1199, line bricks 8 / 11 / 22 / 33 s, the plain
+    // kernel 4 / 6 / 12 / 25 s. For a budget of about 30 s per (background) build:
+    //   row blocks up to SDFK_ROWS_LIMIT instructions (600), line bricks (or, for unaligned arrays, the plain kernel) up to
+    //   SDFK_SPECIALIZE_LIMIT (1200); beyond that AUTO stays on the interpreter kernel, which needs no compilation.
     // MODE_SPECIALIZED / NOCULL always build (the caller asked for the kernel and waits), with the same choice of flavour.
     static const long long spec_limit = [] {
         const char* e = getenv("SDFK_SPECIALIZE_LIMIT");
-        const long long v = e ? atoll(e) : 600;
-        return v > 0 ? v : 600;
+        const long long v = e ? atoll(e) : 1200;
+        return v > 0 ? v : 1200;
     }();
     static const long long rows_limit = [] {
         const char* e = getenv("SDFK_ROWS_LIMIT");
-        const long long v = e ? atoll(e) : 300;
-        return v > 0 ? v : 300;
+        const long long v = e ? atoll(e) : 600;
+        return v > 0 ? v : 600;
     }();
     if (mode == SDFK_MODE_AUTO && (long long)(p->code.size() / 2) > spec_limit && p->interp_ok && !p->chain_mode && !d_flags)
         mode = SDFK_MODE_INTERPRET;

@@ -31,9 +31,13 @@ extern "C" {
                                    are served by the interpreter kernel (bit-identical results; SDFK_ASYNC_JIT=0: wait
                                    instead). The background build runs in a CHILD PROCESS (aegolius_amd/sdfk_rtc_helper:
                                    hiprtc inside the caller deadlocks against a dlopen of any HIP library on another
-                                   thread); without the helper the first call waits. Programs beyond
-                                   SDFK_SPECIALIZE_LIMIT (env, default 1200) instructions stay on the interpreter kernel
-                                   unless they run in chain mode (sdfk_program_set_cull) */
+                                   thread); without the helper the first call waits. Build time is bounded by program
+                                   size (programs that run in chain mode — sdfk_program_set_cull — build in under a
+                                   second whatever their size): row-block kernels up to SDFK_ROWS_LIMIT (env, default
+                                   600) instructions, line bricks / plain up to SDFK_SPECIALIZE_LIMIT (1200), beyond that
+                                   the interpreter kernel serves the program; from SDFK_BIG_PROGRAM (300) instructions on
+                                   a build runs without LLVM's CodeGenPrepare and VectorCombine passes (quadratic in a
+                                   straight-line program; same FP semantics, same bits) */
 #define SDFK_MODE_INTERPRET 1   /* generic register-machine interpreter kernel */
 #define SDFK_MODE_SPECIALIZED 2 /* wait for the specialised kernel; fail instead of falling back if hiprtc fails */
 #define SDFK_MODE_NOCULL 3      /* specialised kernel with brick culling switched off (A/B runs, tests) */

@@ -8,7 +8,7 @@ of their own, optionally with a value modification on top) on a random grid shap
 (odd / short / long rows, 2-D scenes on flat grids):
   * the table-driven chain kernel with per-brick survivor lists (row blocks; candidate lists per cell from 65 members
     on), its un-culled loop (MODE_NOCULL) and — up to 120 children, and for every program that is no chain — the
-    interpreter kernel: bit for bit (programs that are no chain and lie beyond SDFK_SPECIALIZE_LIMIT = 600 instructions
+    interpreter kernel: bit for bit (programs that are no chain and lie beyond SDFK_SPECIALIZE_LIMIT = 1200 instructions
     are served by the interpreter kernel in the product: that kernel against the oracle);
   * the per-axis table flavour (sdfk_eval_grid_host) against the array flavour: bit for bit;
   * a sample of the field against the float64 oracle (1e-6, magnitude-aware as tests/test_gpu_parity.py);
@@ -128,7 +128,7 @@ def device_eval(engine, prog, co32, mode, row_len=None, flat=False, misalign=0):
         lib.sdfk_free(vp(d_out))
 
 
-SPECIALIZE_LIMIT = int(os.environ.get("SDFK_SPECIALIZE_LIMIT", "600"))     # csrc/sdfk.hip, run(): the same default
+SPECIALIZE_LIMIT = int(os.environ.get("SDFK_SPECIALIZE_LIMIT", "1200"))     # csrc/sdfk.hip, run(): the same default
 
 
 def main(first=9000, count=40):

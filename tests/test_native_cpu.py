@@ -420,3 +420,38 @@ def test_nested_hard_unions_flatten_only_at_chain_size(built, monkeypatch):
     d = cluster("UNION", 10, 2.0)
     d.rescale(-1.0)                                             # a negative scale turns min into max: not flattened
     assert members(ns.CombineGeometry("UNION2").combine(a, d)) == 0
+
+
+_BIG_SCRIPT = """
+import json, sys
+sys.path.insert(0, {root!r})
+import aegolius_amd.cores as ns
+from aegolius_amd import _engine, workloads
+from aegolius_amd._lower import lower_geometry
+low = lower_geometry(workloads.cfg2_tree(ns, seed=7, count={count}))
+prog = _engine.Program.from_lowered(low)
+size, seconds = prog.compile_flavour(_engine.FLAVOUR_PLAIN_ARRAY)
+print(json.dumps(dict(instructions=int(low.code.shape[0]), size=size, builds=_engine.jit_stats()[0])))
+"""
+
+
+def test_big_programs_are_built_with_their_own_compiler_options(built, tmp_path):
+    """From SDFK_BIG_PROGRAM instructions on (300) a program that is no chain is built without the two LLVM passes whose
+    time grows with the square of the program (csrc/sdfk.hip rtc_options): the options reach hiprtc through the compiler
+    child process, and they are part of the cache key — the same program under another threshold is another file."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(threshold):
+        env = dict(os.environ, SDFK_CACHE_DIR=str(tmp_path), SDFK_BIG_PROGRAM=str(threshold))
+        res = subprocess.run([sys.executable, "-c", _BIG_SCRIPT.format(root=root, count=101)], env=env, capture_output=True,
+                             text=True, check=True)
+        return json.loads(res.stdout.strip().splitlines()[-1])
+    big = run(300)
+    assert big["instructions"] == 302 and big["builds"] == 1 and big["size"] > 50000
+    assert len(list(tmp_path.iterdir())) == 1
+    again = run(300)
+    assert again["builds"] == 0 and again["size"] == big["size"]                # same options: the cached file
+    full = run(100000)
+    assert full["builds"] == 1 and len(list(tmp_path.iterdir())) == 2         # full pipeline: another key, another file

@@ -3,7 +3,7 @@
     python tools/rows_ab.py [--workload cfg2] [--grid 1024] [--reps 10] VARIANT [VARIANT ...]
 
 A VARIANT is a string of -D switches for the generated source ("" = the shipped kernel), optionally prefixed by
-`mode=nocull:` / `mode=interpret:` / `norows:` / `noplanes:`; every variant is built as its own code object
+`mode=nocull:` / `mode=interpret:` / `norows:` / `noplanes:` / `extra=-mllvm,-disable-cgp:` (raw compiler options); every variant is built as its own code object
 (sdfk_debug_set_rtc_defs), timed with HIP events on the launch stream, and — unless it contains ABLATE — compared
 bit for bit with the un-culled kernel's field."""
 import argparse
@@ -54,12 +54,15 @@ def main():
     results = []
     for var in args.variants:
         mode, rows, planes, defs = _engine.MODE_SPECIALIZED, True, True, var
+        os.environ.pop("SDFK_RTC_EXTRA", None)
         while ":" in defs:
             head, defs = defs.split(":", 1)
             if head == "norows":
                 rows = False
             elif head == "noplanes":
                 planes = False
+            elif head.startswith("extra="):                     # raw compiler options for this variant, "," for " "
+                os.environ["SDFK_RTC_EXTRA"] = head[6:].replace(",", " ")
             elif head.startswith("mode="):
                 mode = {"nocull": _engine.MODE_NOCULL, "interpret": _engine.MODE_INTERPRET}[head[5:]]
         defs = " ".join("-DSDFK_" + t for t in defs.split("+") if t and t != "base")
