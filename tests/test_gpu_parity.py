@@ -911,6 +911,29 @@ def test_chains_of_thousands_of_members(engine):
     assert not bad.any(), float(np.nanmax(err))
 
 
+def test_big_trees_that_are_no_chains_run_on_specialised_kernels(engine):
+    """A left-deep smooth union of 120 primitives (359 instructions: beyond SDFK_BIG_PROGRAM, so built without the two
+    quadratic LLVM passes; within SDFK_ROWS_LIMIT, so a row-block kernel) and one of 210 (629: line bricks) — the culled
+    kernels, the un-culled one and the interpreter kernel agree bit for bit, and with the oracle on a sample."""
+    from aegolius_amd import workloads
+    co, _ = ns.generate_grid((2, 2, 2), (24, 24, 64))
+    co32 = co.astype(np.float32)
+    n = co32.shape[1]
+    row_len = int(np.flatnonzero(co32[1] != co32[1][0])[0])
+    for count, instructions in ((120, 359), (210, 629)):
+        tree = workloads.cfg2_tree(ns, seed=40 + count, count=count)
+        low = lower_geometry(tree)
+        assert low.code.shape[0] == instructions and len(low.cull_sites) == count - 1
+        prog = engine.Program.from_lowered(low)
+        assert prog.chain_members == 0
+        interp = _device_eval(engine, prog, co32, n, n, 0, engine.MODE_INTERPRET)
+        np.testing.assert_array_equal(_device_eval(engine, prog, co32, n, n, 0, engine.MODE_SPECIALIZED, row_len=row_len), interp)
+        np.testing.assert_array_equal(_device_eval(engine, prog, co32, n, n, 0, engine.MODE_SPECIALIZED), interp)   # no row length
+        pick = np.random.default_rng(count).choice(n, 800, replace=False)
+        err, bad = violations(interp[pick], sdf_oracle.evaluate(tree, co32[:, pick].astype(np.float64)))
+        assert not bad.any(), float(np.nanmax(err))
+
+
 def test_sharded_evaluation_of_trees_with_conv_operators(engine):
     """Slabs of whole planes with a recomputed halo (evaluate_slab_staged): conv_averaging (iterated, even and odd
     kernels, nested under other modifications) and conv_edge_detection give, slab by slab, exactly the whole-grid
