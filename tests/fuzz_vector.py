@@ -72,7 +72,19 @@ def fp32_noise_model(vo, field, p, out, want, trials=6, eps=1.2e-7):
         a = np.asarray(a, dtype=np.float64)
         scale = np.sqrt((a * a).sum(axis=0)) if a.ndim == 2 else np.abs(a)
         return a + eps * scale * rng.uniform(-1, 1, size=a.shape)
-    for _ in range(trials):
+
+    def snap(a):
+        # the other way a float64 chain is fragile: a component that is round-off (cos(pi/2) = 6e-17 in NumPy) where an
+        # exact evaluation has 0 — the GPU's revolutions take cos / sin of atan2 without the angle and get the 0 —, and
+        # a planar normalisation (rotate_theta) blows that round-off up to a unit direction (seed 96336: an axial vector
+        # revolved by pi/2 twice; the reference's length 1 against |cos(angle)| for the exactly axial vector)
+        a = np.array(a, dtype=np.float64)
+        scale = np.sqrt((a * a).sum(axis=0)) if a.ndim == 2 else np.abs(a)
+        a[np.abs(a) < 1e-12 * scale] = 0.0
+        return a
+    for trial in range(trials + 1):
+        if trial == trials:
+            jitter = snap                                      # noqa: F811  (the last trial: exact zeros instead of noise)
         with np.errstate(all="ignore"):
             v = jitter(vo.leaf(_leaf_name(inner), jitter(p), field._vf_parameters))
             for name, args in mods:
