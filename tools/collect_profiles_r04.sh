@@ -1,6 +1,6 @@
 #!/bin/bash
 # Developer tool (GPU box): the evidence set of round 4. Writes gpurun_out/r04e_*; copy what is to be judged to profiles/.
-#   collect_profiles_r04.sh [a|b|c|cfg3|all]   a: the driver's command + counters of cfg2 and the 513^3 grid;  b: counters and bench
+#   collect_profiles_r04.sh [a|b|c|cfg3|consumers|all]   a: the driver's command + counters of cfg2 and the 513^3 grid;  b: counters and bench
 #   lines of cfg3 / cfg5 / cfg4 / cfg1;  c: unions (kernel trace + list statistics), consumers, fused selection
 set -u
 tag=r04e
@@ -45,6 +45,12 @@ fi
 if [ "$part" = cfg3 ]; then                                   # after the instruction diet of cfg 3: its own set again
 pmc_set cfg3 sdfk_spec_v4 python3 $R/bench.py --workload cfg3 $B
 python3 bench.py --workload cfg3 $B > "$O/${tag}_cfg3_bench.json" 2>/dev/null
+fi
+if [ "$part" = consumers ]; then                              # after the gradient kernel's new run length
+python3 tools/consumers_bench.py 1024 > "$O/${tag}_consumers_1025.json" 2>/dev/null
+( cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${tag}_prof_consumers" -- python3 $R/tools/consumers_bench.py 1024 > /dev/null 2> "$O/${tag}_prof_consumers.log" )
+cp "$O/${tag}_prof_consumers"/*/*kernel_stats.csv "$O/${tag}_consumers_kernel_stats.csv" 2>/dev/null
 fi
 if [ "$part" = c ] || [ "$part" = all ]; then
 for n in 200 1000 4096 16384; do
