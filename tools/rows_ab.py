@@ -3,7 +3,7 @@
     python tools/rows_ab.py [--workload cfg2] [--grid 1024] [--reps 10] VARIANT [VARIANT ...]
 
 A VARIANT is a string of -D switches for the generated source ("" = the shipped kernel), optionally prefixed by
-`mode=nocull:` / `mode=interpret:` / `norows:` / `noplanes:` / `extra=-mllvm,-disable-cgp:` (raw compiler options); every variant is built as its own code object
+`mode=nocull:` / `mode=interpret:` / `norows:` / `noplanes:` / `grid:` (sdfk_eval_grid) / `extra=-mllvm,-disable-cgp:` (raw compiler options); every variant is built as its own code object
 (sdfk_debug_set_rtc_defs), timed with HIP events on the launch stream, and — unless it contains ABLATE — compared
 bit for bit with the un-culled kernel's field."""
 import argparse
@@ -54,6 +54,7 @@ def main():
     results = []
     for var in args.variants:
         mode, rows, planes, defs = _engine.MODE_SPECIALIZED, True, True, var
+        gridpath = False
         os.environ.pop("SDFK_RTC_EXTRA", None)
         while ":" in defs:
             head, defs = defs.split(":", 1)
@@ -61,6 +62,8 @@ def main():
                 rows = False
             elif head == "noplanes":
                 planes = False
+            elif head == "grid":                                # the 4 B/point path: coordinates from the axis tables
+                gridpath = True
             elif head.startswith("extra="):                     # raw compiler options for this variant, "," for " "
                 os.environ["SDFK_RTC_EXTRA"] = head[6:].replace(",", " ")
             elif head.startswith("mode="):
@@ -70,6 +73,8 @@ def main():
         p = _engine.Program.from_lowered(low)
 
         def step():
+            if gridpath:
+                return p.eval_grid(axes, 0, n, out.data_ptr(), stream=stream, mode=mode)
             p.eval_device(co.data_ptr(), n, stride, out.data_ptr(), stream=stream, mode=mode, row_len=row_len if rows else None,
                           flat=axes[2].size == 1, plane_rows=int(axes[1].size) if planes and axes[2].size > 1 else None)
         out.zero_()
