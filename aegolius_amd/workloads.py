@@ -123,5 +123,8 @@ BASELINE = {
 
 def build(name, ns):
     """-> (tree, grid size, description) of a BASELINE config."""
+    if name.startswith("tree") and name[4:].isdigit():          # developer workloads: the cfg2 recipe with n primitives
+        count = int(name[4:])
+        return cfg2_tree(ns, seed=100 + count, count=count), (2, 2, 2), "left-deep SMOOTH_UNION2 chain of %d primitives" % count
     builder, size, desc, _request = BASELINE[name]
     return builder(ns), size, desc
