@@ -41,6 +41,7 @@ SIGNATURES = {
     "sdfk_debug_compile_external": (_int, [_vp, _int, _c.POINTER(_sz)]),
     "sdfk_debug_jit_stats": (None, [_c.POINTER(_i64), _c.POINTER(_c.c_double)]),
     "sdfk_jit_drain": (None, []),
+    "sdfk_jit_cancel": (None, []),
     "sdfk_debug_set_rtc_defs": (None, [_c.c_char_p]),
     "sdfk_eval_device": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _int]),
     "sdfk_eval_device_rows": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int]),
@@ -146,8 +147,9 @@ def lib():
                     fn.restype, fn.argtypes = res, args
                 if handle.sdfk_abi_version() != 1:
                     raise SdfkError("libsdfk.so ABI version mismatch")
-                # background kernel builds finish before the interpreter (and with it torch's HIP runtime) shuts down
-                atexit.register(handle.sdfk_jit_drain)
+                # no background kernel build survives the interpreter (and with it torch's HIP runtime): queued ones are
+                # dropped, running compiler processes killed — a big tree's build takes up to a minute
+                atexit.register(handle.sdfk_jit_cancel)
                 _lib = handle
     return _lib
 

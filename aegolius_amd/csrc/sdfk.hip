@@ -235,7 +235,7 @@ struct sdfk_program {
     unsigned long long params_version = 1;
     std::string key;
     std::string source;
-    std::vector<sdfk_cullsite> sites;  // brick-culling sites the mask kernels use: the 64 widest (sdfk_program_set_cull)
+    std::vector<sdfk_cullsite> sites;  // brick-culling sites the mask kernels use: the SDFK_MASK_SITES widest (sdfk_program_set_cull)
     std::vector<sdfk_cullsite> sites_all;  // every site that was passed in
     bool chain_mode = false;           // long n-ary min / max chain: table-driven kernels (sdfk_codegen.cpp)
     int chain_members = 0;             // its members (the program may hold more sites: combiners above the chain)
@@ -259,6 +259,7 @@ extern "C" int sdfk_device_count(void) {
 }
 
 extern "C" const char* sdfk_last_error(void) { return g_err.c_str(); }
+#define SDFK_MASK_SITES 256   // sites a row-block kernel carries skip bits for (8 words of 64 bits per brick at most)
 extern "C" void sdfk_set_default_mode(int mode) { g_default_mode = mode; }
 
 // ---- validation -------------------------------------------------------------------------------
@@ -541,15 +542,17 @@ extern "C" int sdfk_program_set_cull(sdfk_program* p, const uint32_t* rows, size
         t.skip_b_ok = range_skippable(p, t.b0, t.b1, t.comb, c) ? 1 : 0;
         sites.push_back(t);
     }
-    // the kernels that carry two mask bits per site in two 64-bit words take the 64 widest sites, in program order
+    // the row-block kernels carry two mask bits per site, 32 sites per 64-bit word and brick (SDFK_NMASK words; rounds 1-3:
+    // two words, 64 sites — a left-deep union of 200 primitives then evaluated 135 of them at every point): up to
+    // SDFK_MASK_SITES = 256 sites, the widest ones, in program order (the line-brick kernel picks its 31 among them)
     p->sites_all = sites;
-    if (sites.size() > 64) {
+    if (sites.size() > SDFK_MASK_SITES) {
         std::vector<size_t> order(sites.size());
         for (size_t i = 0; i < order.size(); ++i) order[i] = i;
         std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) {
             return (sites[x].a1 - sites[x].a0) + (sites[x].b1 - sites[x].b0) > (sites[y].a1 - sites[y].a0) + (sites[y].b1 - sites[y].b0);
         });
-        order.resize(64);
+        order.resize(SDFK_MASK_SITES);
         std::sort(order.begin(), order.end());
         std::vector<sdfk_cullsite> widest;
         for (size_t i : order) widest.push_back(sites[i]);
@@ -628,7 +631,10 @@ static int rows_wbricks(const sdfk_program* p) {
     // evaluation pass one after the other, and the leaf values take 6 bytes of LDS per child and brick — few bricks per
     // wave win: 1000 spheres 21.9 / 11.4 / 5.5 ms with 4 / 2 / 1, the flat union 1.08 / 0.99 / 1.03 ms
     if (p && p->chain_mode) return p->chain_members <= 64 ? 2 : 1;
-    return (p && p->code.size() / 2 > 150) ? 4 : 2;
+    // (rounds 2-3 gave programs beyond 150 instructions 4 bricks per wave; with skip bits for every site — SDFK_MASK_SITES —
+    //  2 win at every size: 70 / 100 / 150 / 200 primitives at 513^3 1.40 / 1.87 / 2.79 / 3.51 ms against 1.55 / 2.34 / 3.18 /
+    //  4.00, profiles/r04_bigtree_wbricks.txt)
+    return 2;
 }
 struct RowGeom {           // mirrors sdfk_rowgeom of the generated source
     unsigned L, nchunk, nbricks;
@@ -934,6 +940,7 @@ static std::string rtc_library_path() {                        // the hiprtc THI
     return info.dli_fname;
 }
 static bool rtc_helper_available() { return !rtc_helper_path().empty() && !rtc_library_path().empty(); }
+static std::atomic<bool> g_cancel_builds{false};              // set by sdfk_jit_cancel: running compiler children are killed, queued builds dropped
 static int rtc_compile_external(const std::string& src, std::vector<char>* out, std::string* log, int rwb) {
     static std::atomic<unsigned> serial{0};
     const std::string helper = rtc_helper_path(), lib = rtc_library_path();
@@ -994,12 +1001,19 @@ static int rtc_compile_external(const std::string& src, std::vector<char>* out, 
     // and with it sdfk_jit_drain at interpreter exit — for ever: SDFK_RTC_TIMEOUT seconds (default 900), then it is killed
     static const double limit_s = [] { const char* e = getenv("SDFK_RTC_TIMEOUT"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 900.0; }();
     int status = 0;
-    bool timed_out = false;
+    bool timed_out = false, cancelled = false;
     const auto t_spawn = std::chrono::steady_clock::now();
     for (;;) {
         const pid_t w = waitpid(pid, &status, WNOHANG);
         if (w == pid) break;
         if (w < 0 && errno != EINTR) { status = -1; break; }
+        if (g_cancel_builds.load(std::memory_order_relaxed)) {  // the process is leaving (sdfk_jit_cancel): nobody will use the kernel
+            cancelled = true;
+            (void)kill(pid, SIGKILL);
+            while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {
+            }
+            break;
+        }
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_spawn).count() > limit_s) {
             timed_out = true;
             (void)kill(pid, SIGKILL);
@@ -1010,7 +1024,9 @@ static int rtc_compile_external(const std::string& src, std::vector<char>* out, 
         std::this_thread::sleep_for(std::chrono::milliseconds(5));
     }
     int result = -1;
-    if (timed_out) {
+    if (cancelled) {
+        *log = "build cancelled: the process is shutting down";
+    } else if (timed_out) {
         *log = "sdfk_rtc_helper did not finish within " + std::to_string((long long)limit_s) + " s (SDFK_RTC_TIMEOUT) and was killed";
     } else if (WIFEXITED(status) && WEXITSTATUS(status) == 0) {
         FILE* f = fopen(outf.c_str(), "rb");
@@ -1108,6 +1124,11 @@ struct BuildWorker {
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [this] { return jobs.empty() && busy == 0; });
     }
+    void drop_queued() {
+        std::lock_guard<std::mutex> lk(mu);
+        jobs.clear();
+        cv.notify_all();
+    }
     ~BuildWorker() {
         {
             std::lock_guard<std::mutex> lk(mu);
@@ -1120,6 +1141,13 @@ struct BuildWorker {
 };
 static BuildWorker g_builds;
 extern "C" void sdfk_jit_drain(void) { g_builds.drain(); }
+// At interpreter exit: a background build nobody will use any more (a big tree evaluated once: up to a minute of hiprtc)
+// must not hold the process. Queued builds are dropped, running compiler children killed, then the workers are idle.
+extern "C" void sdfk_jit_cancel(void) {
+    g_cancel_builds.store(true);
+    g_builds.drop_queued();
+    g_builds.drain();
+}
 static std::atomic<long long> g_compile_count{0};             // hiprtc builds this process has actually run
 static std::atomic<long long> g_compile_micros{0};
 extern "C" void sdfk_debug_jit_stats(int64_t* builds, double* seconds) {
@@ -1574,9 +1602,11 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
     // the build container's CPU: row blocks 1 / 4 / 8 / 21 / 102 s at 29 / 89 / 179 / 299 / 449 instructions with the full
     // pipeline; beyond SDFK_BIG_PROGRAM (300) instructions builds run without CodeGenPrepare and VectorCombine
     // (rtc_options): row blocks 21 / 30 / 49 / 85 s at 449 / 599 / 899 / 1199, line bricks 8 / 11 / 22 / 33 s, the plain
-    // kernel 4 / 6 / 12 / 25 s. For a budget of about 30 s per (background) build:
-    //   row blocks up to SDFK_ROWS_LIMIT instructions (600), line bricks (or, for unaligned arrays, the plain kernel) up to
+    // kernel 4 / 6 / 12 / 25 s (on the GPU boxes' CPUs less than half of that). With skip bits for 256 sites a row-block
+    // kernel is 2-3 x a line-brick one on these programs, so both limits are the same now:
+    //   row blocks up to SDFK_ROWS_LIMIT instructions (1200), line bricks (or, for unaligned arrays, the plain kernel) up to
     //   SDFK_SPECIALIZE_LIMIT (1200); beyond that AUTO stays on the interpreter kernel, which needs no compilation.
+    // A background build that is still running when the process leaves is killed (sdfk_jit_cancel).
     // MODE_SPECIALIZED / NOCULL always build (the caller asked for the kernel and waits), with the same choice of flavour.
     static const long long spec_limit = [] {
         const char* e = getenv("SDFK_SPECIALIZE_LIMIT");
@@ -1585,8 +1615,8 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
     }();
     static const long long rows_limit = [] {
         const char* e = getenv("SDFK_ROWS_LIMIT");
-        const long long v = e ? atoll(e) : 600;
-        return v > 0 ? v : 600;
+        const long long v = e ? atoll(e) : 1200;
+        return v > 0 ? v : 1200;
     }();
     if (mode == SDFK_MODE_AUTO && (long long)(p->code.size() / 2) > spec_limit && p->interp_ok && !p->chain_mode && !d_flags)
         mode = SDFK_MODE_INTERPRET;

@@ -456,7 +456,7 @@ struct sdfk_rowmeta {
     float z[SDFK_RNBRICK][SDFK_RBRICK];         // [row of the brick][point of the window]
     float2 xy[SDFK_RNBRICK][SDFK_RROWS];
     float4 bound[SDFK_RNBRICK];
-    unsigned long long mask0[SDFK_RNBRICK], mask1[SDFK_RNBRICK];
+    unsigned long long mask[SDFK_NMASK][SDFK_RNBRICK];   // two bits per site: SDFK_NMASK x 32 sites (2 words up to 64 sites)
     unsigned uniform[SDFK_RNBRICK];
 #if defined(SDFK_SIMT) && !defined(SDFK_CELLS)
     float4 cen[SDFK_NCEN];                      // probe centres (x, y, z, radius): SDFK_NSUB per brick
@@ -671,8 +671,8 @@ static __device__ __forceinline__ void sdfk_rows_bounds(const sdfk_rowregs& r, i
     if (uniform) {
         if (lane == 0) {
             meta->uniform[b] = 1u;
-            meta->mask0[b] = ~0ull;
-            meta->mask1[b] = ~0ull;
+#pragma unroll
+            for (int w = 0; w < SDFK_NMASK; ++w) meta->mask[w][b] = ~0ull;
         }
         return;
     }
@@ -727,8 +727,8 @@ static __device__ __forceinline__ void sdfk_rows_bounds(const sdfk_rowregs& r, i
 #endif
         meta->uniform[b] = uniform ? 1u : 0u;
 #ifdef SDFK_SIMT
-        meta->mask0[b] = ~0ull;                                   // the fold lanes AND their decisions into these
-        meta->mask1[b] = ~0ull;
+#pragma unroll
+        for (int w = 0; w < SDFK_NMASK; ++w) meta->mask[w][b] = ~0ull;   // the fold lanes AND their decisions into these
 #endif
     }
 }
@@ -1031,14 +1031,18 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
     if (sdfk_tx() < SDFK_NCEN && tile * SDFK_RNBRICK + sdfk_tx() / SDFK_NSUB < g.nbricks) {
         const float4 cc = meta->cen[sdfk_tx()];
         V3T<float> ctr = {cc.x, cc.y, cc.z};
-        unsigned long long m0, m1;
-        sdfk_probe_fold(meta->leafval, sdfk_tx(), ctr, cc.w, PRM, m0, m1);
-        __hip_atomic_fetch_and(&meta->mask0[sdfk_tx() / SDFK_NSUB], m0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_and(&meta->mask1[sdfk_tx() / SDFK_NSUB], m1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        unsigned long long mk[SDFK_NMASK];
+        sdfk_probe_fold(meta->leafval, sdfk_tx(), ctr, cc.w, PRM, mk);
+#pragma unroll
+        for (int w = 0; w < SDFK_NMASK; ++w)
+            __hip_atomic_fetch_and(&meta->mask[w][sdfk_tx() / SDFK_NSUB], mk[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 #endif
 #else
-    if (sdfk_tx() < SDFK_RNBRICK) { meta->mask0[sdfk_tx()] = 0ull; meta->mask1[sdfk_tx()] = 0ull; }
+    if (sdfk_tx() < SDFK_RNBRICK) {
+#pragma unroll
+        for (int w = 0; w < SDFK_NMASK; ++w) meta->mask[w][sdfk_tx()] = 0ull;
+    }
 #endif
     __syncthreads();
     return;
@@ -1046,12 +1050,14 @@ static __device__ __forceinline__ void sdfk_rows_prepare(const float* __restrict
     if (sdfk_tx() < SDFK_RNBRICK && tile * SDFK_RNBRICK + sdfk_tx() < g.nbricks) {
         const float4 bb = meta->bound[sdfk_tx()];
         V3T<float> ctr = {bb.x, bb.y, bb.z};
-        unsigned long long m0 = 0ull, m1 = 0ull;
+        unsigned long long mk[SDFK_NMASK];
+#pragma unroll
+        for (int w = 0; w < SDFK_NMASK; ++w) mk[w] = 0ull;
 #if !defined(SDFK_ABLATE_PROBE) && !defined(SDFK_CHAIN)
-        sdfk_probe_r(ctr, bb.w, PRM, TAB, m0, m1);
+        sdfk_probe_r(ctr, bb.w, PRM, TAB, mk);
 #endif
-        meta->mask0[sdfk_tx()] = m0;
-        meta->mask1[sdfk_tx()] = m1;
+#pragma unroll
+        for (int w = 0; w < SDFK_NMASK; ++w) meta->mask[w][sdfk_tx()] = mk[w];
     }
     __syncthreads();
 }
@@ -1101,9 +1107,13 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
         sdfk_block_rows(g, rb, r0, rend);
         if (++c == g.nchunk) { c = 0; ++rb; }
         if (r0 >= rend) continue;
-        const unsigned long long m0 = meta.mask0[b], m1 = meta.mask1[b];
-        const unsigned w0 = __builtin_amdgcn_readfirstlane((unsigned)m0), w1 = __builtin_amdgcn_readfirstlane((unsigned)(m0 >> 32));
-        const unsigned w2 = __builtin_amdgcn_readfirstlane((unsigned)m1), w3 = __builtin_amdgcn_readfirstlane((unsigned)(m1 >> 32));
+        unsigned mw[2 * SDFK_NMASK];                             // the brick's skip bits as scalar words
+#pragma unroll
+        for (int w = 0; w < SDFK_NMASK; ++w) {
+            const unsigned long long m = meta.mask[w][b];
+            mw[2 * w] = __builtin_amdgcn_readfirstlane((unsigned)m);
+            mw[2 * w + 1] = __builtin_amdgcn_readfirstlane((unsigned)(m >> 32));
+        }
         const bool uniform = __builtin_amdgcn_readfirstlane(meta.uniform[b]) != 0u;
         const bool interior = sdfk_interior(g.L, k);
 #ifdef SDFK_ABLATE_EDGE
@@ -1125,9 +1135,9 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
 #ifdef SDFK_ABLATE_EVAL
         if (true) {
 #ifdef SDFK_FLAT
-            SDFK_EACH res[q] = P[q].y + __builtin_bit_cast(float, w0 ^ w1 ^ w2 ^ w3);
+            SDFK_EACH res[q] = P[q].y + __builtin_bit_cast(float, mw[0] ^ mw[1] ^ mw[2] ^ mw[3]);
 #else
-            SDFK_EACH res[q] = P[q].z + __builtin_bit_cast(float, w0 ^ w1 ^ w2 ^ w3);
+            SDFK_EACH res[q] = P[q].z + __builtin_bit_cast(float, mw[0] ^ mw[1] ^ mw[2] ^ mw[3]);
 #endif
         } else
 #endif
@@ -1139,7 +1149,7 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
             SDFK_EACH { P[q].x = sp<f2>(xy.x); P[q].y = sp<f2>(xy.y); }
 #endif
 #ifndef SDFK_CHAIN
-            sdfk_rows_culled<true>(xy.x, xy.y, P, w0, w1, w2, w3, PRM, TAB, res);
+            sdfk_rows_culled<true>(xy.x, xy.y, P, mw, PRM, TAB, res);
 #endif
         } else {                                                  // the other coordinates of every point again (L2-resident)
 #pragma unroll
@@ -1157,7 +1167,7 @@ static __device__ __forceinline__ void sdfk_rows_kernel(const float* __restrict_
 #endif
             }
 #ifndef SDFK_CHAIN
-            sdfk_rows_culled<false>(0.0f, 0.0f, P, w0, w1, w2, w3, PRM, TAB, res);
+            sdfk_rows_culled<false>(0.0f, 0.0f, P, mw, PRM, TAB, res);
 #endif
         }
 #ifdef SDFK_CHAIN
@@ -1509,8 +1519,8 @@ extern "C" __global__ __launch_bounds__(64 * SDFK_RWAVES) void sdfk_spec_rmask(
     sdfk_rows_prepare(PRM, TAB, s, g, &meta, sdfk_bx(), rb, c);
     const unsigned q = sdfk_bx() * SDFK_RNBRICK + sdfk_tx();
     if (sdfk_tx() < SDFK_RNBRICK && q < g.nbricks) {
-        masks[3ull * q] = meta.mask0[sdfk_tx()];
-        masks[3ull * q + 1] = meta.mask1[sdfk_tx()];
+        masks[3ull * q] = meta.mask[0][sdfk_tx()];
+        masks[3ull * q + 1] = meta.mask[1][sdfk_tx()];
         masks[3ull * q + 2] = meta.uniform[sdfk_tx()];
     }
 }
@@ -1946,7 +1956,7 @@ struct Gen {
     // with the skip decision of every site exactly as in the sequential probe below
     void emit_probe_fold() {
         s += "\nstatic __device__ __forceinline__ void sdfk_probe_fold(const float* __restrict__ leafval, unsigned cen, V3T<float> C_0, "
-             "float rho, const float* __restrict__ PRM, unsigned long long& mask, unsigned long long& mask1) {\n";
+             "float rho, const float* __restrict__ PRM, unsigned long long (&mask)[SDFK_NMASK]) {\n";
         std::set<unsigned> vregs;
         for (size_t i = 0; i < n_instr; ++i)
             if (leaf_at[i] < 0) vregs.insert((code[2 * i] >> 8) & 255u);
@@ -1956,7 +1966,7 @@ struct Gen {
             snprintf(buf, sizeof buf, "    float V_%u;\n", v);
             s += buf;
         }
-        s += "    mask = 0ull; mask1 = 0ull;\n";
+        s += "    _Pragma(\"unroll\") for (int w_ = 0; w_ < SDFK_NMASK; ++w_) mask[w_] = 0ull;\n";
         s += "    const float cmag = 1e-6f * (fabsf(C_0.x) + fabsf(C_0.y) + fabsf(C_0.z) + rho);\n";
         for (size_t i = 0; i < n_instr; ++i) {
             if (leaf_at[i] >= 0) {
@@ -1973,7 +1983,9 @@ struct Gen {
                 site_ops(t, gB, gA, wx, &neg, sizeof gB);
                 const uint32_t w = code[2 * i];
                 const unsigned b = (w >> 16) & 255u, c = w >> 24;
-                const char* mv = k < 32 ? "mask" : "mask1";
+                char mv[24];
+                if (rows) snprintf(mv, sizeof mv, "mask[%zu]", k / 32);
+                else snprintf(mv, sizeof mv, "mask");
                 const unsigned sh = 2 * (unsigned)(k & 31);
                 snprintf(buf, sizeof buf,
                          "    { const float thr = %s + %.9ef * rho + %.9ef * cmag + 1e-6f * (1.0f + fabsf(V_%u) + fabsf(V_%u));\n"
@@ -2165,13 +2177,12 @@ struct Gen {
     void emit_probe() {
         if (rows)
             s += "\nstatic __device__ __forceinline__ void sdfk_probe_r(V3T<float> C_0, float rho, "
-                 "const float* __restrict__ PRM, const float* __restrict__ TAB, unsigned long long& mask, "
-                 "unsigned long long& mask1) {\n";
+                 "const float* __restrict__ PRM, const float* __restrict__ TAB, unsigned long long (&mask)[SDFK_NMASK]) {\n";
         else
             s += "\nstatic __device__ __forceinline__ unsigned long long sdfk_probe(V3T<float> C_0, float rho, float* bases, "
                  "const float* __restrict__ PRM, const float* __restrict__ TAB) {\n";
         declare("V3", "float", false);
-        s += rows ? "    mask = 0ull; mask1 = 0ull;\n" : "    unsigned long long mask = 0ull;\n";
+        s += rows ? "    _Pragma(\"unroll\") for (int w_ = 0; w_ < SDFK_NMASK; ++w_) mask[w_] = 0ull;\n" : "    unsigned long long mask = 0ull;\n";
         // fp32 rounding of an operand grows with the magnitude of the coordinates it is computed from (about
         // 6e-8 |p| per rounding step of a transform), not with its value: a scene far from the origin needs a margin
         // in |c| + rho, scaled by the Lipschitz sum of the site, on top of the margin in the operand values
@@ -2185,7 +2196,9 @@ struct Gen {
                 site_ops(t, gB, gA, wx, &neg, sizeof gB);
                 const uint32_t w = code[2 * i];
                 const unsigned b = (w >> 16) & 255u, c = w >> 24;
-                const char* mv = k < 32 ? "mask" : "mask1";
+                char mv[24];
+                if (rows) snprintf(mv, sizeof mv, "mask[%zu]", k / 32);
+                else snprintf(mv, sizeof mv, "mask");
                 const unsigned sh = 2 * (unsigned)(k & 31);
                 snprintf(buf, sizeof buf,
                          "    { const float thr = %s + %.9ef * rho + %.9ef * cmag + 1e-6f * (1.0f + fabsf(V_%u) + fabsf(V_%u));\n"
@@ -2201,10 +2214,10 @@ struct Gen {
     }
 
     // ---- culled evaluation ----
-    // mask bit `bit` (0..63) as a test on one of the two 32-bit scalar halves
+    // mask bit `bit` as a test on one of the 32-bit scalar words (row blocks: 2 * SDFK_NMASK of them; line bricks: 2)
     std::string bit_test(unsigned bit) const {
         char b[48];
-        if (rows) snprintf(b, sizeof b, "(mw%u & %uu)", bit >> 5, 1u << (bit & 31));
+        if (rows) snprintf(b, sizeof b, "(mw[%u] & %uu)", bit >> 5, 1u << (bit & 31));
         else snprintf(b, sizeof b, "(%s & %uu)", bit < 32 ? "mlo" : "mhi", 1u << (bit & 31));
         return b;
     }
@@ -2286,7 +2299,7 @@ struct Gen {
             // CombineGeometry produces), the levels that must run are a BITSET computed with a dozen scalar operations
             // — st = highest level whose first operand is irrelevant, alive = levels >= st whose second operand is
             // not skipped — and a loop visits exactly those: ctz, clear the bit, jump to the level's code.
-            bool loopable = rows && m >= 4 && m <= 64;
+            bool loopable = rows && m >= 4 && m <= 64 && chain[m - 1] + (int)m <= 64;   // (the loop's bitset: sites 0..63)
             for (size_t idx = 1; idx <= m && loopable; ++idx) {
                 const sdfk_cullsite& t = (*sites)[chain[m - idx]];
                 const uint32_t w = code[2 * t.comb];
@@ -2331,8 +2344,8 @@ struct Gen {
         const int k0 = chain[m - 1];                              // site of level 1; level idx = site k0 + idx - 1
         const sdfk_cullsite& first = (*sites)[k0];
         char buf[512];
-        s += ind + "{ const unsigned long long cm0 = (unsigned long long)mw0 | ((unsigned long long)mw1 << 32), "
-                   "cm1 = (unsigned long long)mw2 | ((unsigned long long)mw3 << 32);\n";
+        s += ind + "{ const unsigned long long cm0 = (unsigned long long)mw[0] | ((unsigned long long)mw[1] << 32), "
+                   "cm1 = (unsigned long long)mw[2] | ((unsigned long long)mw[3] << 32);\n";
         // bit k of sa / sb = "skip the first / the second operand" of site k (sites 0..63)
         s += ind + "  unsigned long long sa = sdfk_even_bits(cm0) | (sdfk_even_bits(cm1) << 32), "
                    "sb = sdfk_even_bits(cm0 >> 1) | (sdfk_even_bits(cm1 >> 1) << 32);\n";
@@ -2374,7 +2387,7 @@ struct Gen {
 
     void emit_rows_culled(int result_reg) {
         s += "\ntemplate <bool ZRUN> static __device__ __forceinline__ void sdfk_rows_culled(float X, float Y, "
-             "const V3P (&P0)[SDFK_NP], unsigned mw0, unsigned mw1, unsigned mw2, unsigned mw3, "
+             "const V3P (&P0)[SDFK_NP], const unsigned (&mw)[2 * SDFK_NMASK], "
              "const float* __restrict__ PRM, const float* __restrict__ TAB, f2 (&R)[SDFK_NP]) {\n"
              "    typedef f2 T;\n    V3P C_0[SDFK_NP];\n    SDFK_EACH C_0[q] = P0[q];\n";
         declare("V3P", "f2", true, true);
@@ -2481,6 +2494,7 @@ std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32
             g.s += kWaveHelpers;
             if (flat2) g.s += "\n#define SDFK_FLAT 1\n";
             g.s += "\n#define SDFK_NP 4\n#define SDFK_EACH _Pragma(\"unroll\") for (int q = 0; q < SDFK_NP; ++q)\n"
+                   "#define SDFK_NMASK 2\n"
                    "#define SDFK_SIMT 1\n#define SDFK_NSUB 1\n"
                    // candidate lists per cell (sdfk_spec_cells) for chains of more than 64 members; up to 64 the probe of every
                    // member by the whole workgroup stays (measured on the 50-child flat union at 16385^2: 0.88 ms against 1.04
@@ -2543,6 +2557,11 @@ std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32
         g.find_roots();
         if (flat) g.s += "\n#define SDFK_FLAT 1\n";
         g.s += "\n#define SDFK_NP 4\n#define SDFK_EACH _Pragma(\"unroll\") for (int q = 0; q < SDFK_NP; ++q)\n";
+        {   // skip bits of the sites: two per site, 32 sites per 64-bit word, at least the two words of rounds 1-3
+            char nm[64];
+            snprintf(nm, sizeof nm, "#define SDFK_NMASK %zu\n", std::max<size_t>(2, (sites.size() + 31) / 32));
+            g.s += nm;
+        }
         g.s += "#ifndef SDFK_CHAIN_LOOP_MIN\n#define SDFK_CHAIN_LOOP_MIN 12   // chains of at least this many sites run as a loop over the levels that survive\n#endif\n"
                "// the even bits of x, packed into the low 32 bits (wave-uniform: scalar unit)\n"
                "static __device__ __forceinline__ unsigned long long sdfk_even_bits(unsigned long long x) {\n"

@@ -34,7 +34,7 @@ extern "C" {
                                    thread); without the helper the first call waits. Build time is bounded by program
                                    size (programs that run in chain mode — sdfk_program_set_cull — build in under a
                                    second whatever their size): row-block kernels up to SDFK_ROWS_LIMIT (env, default
-                                   600) instructions, line bricks / plain up to SDFK_SPECIALIZE_LIMIT (1200), beyond that
+                                   1200) instructions, line bricks / plain up to SDFK_SPECIALIZE_LIMIT (1200), beyond that
                                    the interpreter kernel serves the program; from SDFK_BIG_PROGRAM (300) instructions on
                                    a build runs without LLVM's CodeGenPrepare and VectorCombine passes (quadratic in a
                                    straight-line program; same FP semantics, same bits) */
@@ -118,9 +118,11 @@ void sdfk_debug_cells_stats(int enable, long long* out8);
  * process-wide lock of its compiler library for the whole build, against which a dlopen of any HIP library on another
  * thread deadlocks. Without the helper next to the library there are no background builds: the first call waits. */
 int sdfk_debug_compile_external(sdfk_program* prog, int flavour, size_t* code_size);
-/* Wait until no background kernel build is queued or running (call before the process tears hiprtc down: the Python
- * layer registers it with atexit). */
+/* Wait until no background kernel build is queued or running. */
 void sdfk_jit_drain(void);
+/* The same for a process that is leaving: queued builds are dropped, running compiler child processes killed (a build of a
+ * big tree takes up to a minute; nobody would use its kernel). What the Python layer registers with atexit. */
+void sdfk_jit_cancel(void);
 /* hiprtc builds this process has actually run (cache hits excluded) and the seconds they took. */
 void sdfk_debug_jit_stats(int64_t* builds, double* seconds);
 /* Extra -D switches handed to hiprtc for kernels built from now on (experiments; also env SDFK_RTC_DEFS). */

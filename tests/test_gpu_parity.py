@@ -913,8 +913,9 @@ def test_chains_of_thousands_of_members(engine):
 
 def test_big_trees_that_are_no_chains_run_on_specialised_kernels(engine):
     """A left-deep smooth union of 120 primitives (359 instructions: beyond SDFK_BIG_PROGRAM, so built without the two
-    quadratic LLVM passes; within SDFK_ROWS_LIMIT, so a row-block kernel) and one of 210 (629: line bricks) — the culled
-    kernels, the un-culled one and the interpreter kernel agree bit for bit, and with the oracle on a sample."""
+    quadratic LLVM passes; 119 sites: four mask words per brick) and one of 210 (629 instructions, 209 sites: seven words)
+    — row blocks with the row length, line bricks without it, and the interpreter kernel agree bit for bit, and with the
+    oracle on a sample."""
     from aegolius_amd import workloads
     co, _ = ns.generate_grid((2, 2, 2), (24, 24, 64))
     co32 = co.astype(np.float32)

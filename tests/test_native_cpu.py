@@ -455,3 +455,37 @@ def test_big_programs_are_built_with_their_own_compiler_options(built, tmp_path)
     assert again["builds"] == 0 and again["size"] == big["size"]                # same options: the cached file
     full = run(100000)
     assert full["builds"] == 1 and len(list(tmp_path.iterdir())) == 2         # full pipeline: another key, another file
+
+
+_CANCEL_SCRIPT = """
+import sys, threading, time
+sys.path.insert(0, {root!r})
+import aegolius_amd.cores as ns
+from aegolius_amd import _engine, workloads
+from aegolius_amd._lower import lower_geometry
+prog = _engine.Program.from_lowered(lower_geometry(workloads.cfg2_tree(ns, seed=9, count=150)))
+def build():
+    try:
+        prog.compile_flavour(_engine.FLAVOUR_ROWS_ARRAY)          # 20 s and more of hiprtc, in the compiler child process
+        print("BUILT", flush=True)
+    except Exception as exc:
+        print("STOPPED", str(exc)[:120], flush=True)
+threading.Thread(target=build, daemon=True).start()
+time.sleep(2.0)
+print("LEAVING", flush=True)
+"""
+
+
+def test_a_process_that_leaves_does_not_wait_for_a_running_build(built, tmp_path):
+    """atexit -> sdfk_jit_cancel: the compiler child process of a build that is still running is killed and the
+    interpreter exits at once — with the build tiers of round 4 a background build may take a minute."""
+    import subprocess
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SDFK_CACHE_DIR="off")
+    t0 = time.time()
+    res = subprocess.run([sys.executable, "-c", _CANCEL_SCRIPT.format(root=root)], env=env, capture_output=True, text=True,
+                         timeout=120)
+    took = time.time() - t0
+    assert "LEAVING" in res.stdout and "BUILT" not in res.stdout, res.stdout + res.stderr[-300:]
+    assert took < 12.0, took                                       # (import + 2 s of sleep + the kill; the build alone: > 20 s)
