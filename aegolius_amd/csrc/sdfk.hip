@@ -259,7 +259,7 @@ extern "C" int sdfk_device_count(void) {
 }
 
 extern "C" const char* sdfk_last_error(void) { return g_err.c_str(); }
-#define SDFK_MASK_SITES 256   // sites a row-block kernel carries skip bits for (8 words of 64 bits per brick at most)
+#define SDFK_MASK_SITES 512   // sites a row-block kernel carries skip bits for (16 words of 64 bits per brick at most)
 extern "C" void sdfk_set_default_mode(int mode) { g_default_mode = mode; }
 
 // ---- validation -------------------------------------------------------------------------------
@@ -544,7 +544,7 @@ extern "C" int sdfk_program_set_cull(sdfk_program* p, const uint32_t* rows, size
     }
     // the row-block kernels carry two mask bits per site, 32 sites per 64-bit word and brick (SDFK_NMASK words; rounds 1-3:
     // two words, 64 sites — a left-deep union of 200 primitives then evaluated 135 of them at every point): up to
-    // SDFK_MASK_SITES = 256 sites, the widest ones, in program order (the line-brick kernel picks its 31 among them)
+    // SDFK_MASK_SITES = 512 sites, the widest ones, in program order (the line-brick kernel picks its 31 among them)
     p->sites_all = sites;
     if (sites.size() > SDFK_MASK_SITES) {
         std::vector<size_t> order(sites.size());
@@ -1602,7 +1602,7 @@ static int run(sdfk_program* p, const SrcArray* arr, const SrcGrid* grid, long l
     // the build container's CPU: row blocks 1 / 4 / 8 / 21 / 102 s at 29 / 89 / 179 / 299 / 449 instructions with the full
     // pipeline; beyond SDFK_BIG_PROGRAM (300) instructions builds run without CodeGenPrepare and VectorCombine
     // (rtc_options): row blocks 21 / 30 / 49 / 85 s at 449 / 599 / 899 / 1199, line bricks 8 / 11 / 22 / 33 s, the plain
-    // kernel 4 / 6 / 12 / 25 s (on the GPU boxes' CPUs less than half of that). With skip bits for 256 sites a row-block
+    // kernel 4 / 6 / 12 / 25 s (on the GPU boxes' CPUs less than half of that). With skip bits for 512 sites a row-block
     // kernel is 2-3 x a line-brick one on these programs, so both limits are the same now:
     //   row blocks up to SDFK_ROWS_LIMIT instructions (1200), line bricks (or, for unaligned arrays, the plain kernel) up to
     //   SDFK_SPECIALIZE_LIMIT (1200); beyond that AUTO stays on the interpreter kernel, which needs no compilation.
