@@ -396,8 +396,9 @@ static const char kSimtGeometry[] = R"SDFKR(
 #ifndef SDFK_NSUB                        // sub-bricks (probe centres) per brick: 16 = 4 rows x 8 points, 8 = 8 rows x 8, 4 = 16 rows x 8
 // measured (north-star tree, 20-primitive tree; 513^3 and 1025^3): 8 centres beat 16 — half the leaf evaluations, nearly
 // the same radius — and beat 4 for 20 leaves too (513^3: 0.56 -> 0.49 ms, 1025^3: 1 %); beyond 32 leaves the probe itself
-// is the cost: one centre
-#define SDFK_NSUB ((SDFK_NLEAF <= 32 && 8 * SDFK_RWBRICKS <= 64) ? 8 : ((SDFK_NLEAF <= 32 && 4 * SDFK_RWBRICKS <= 64) ? 4 : 1))
+// becomes the cost: 4 centres up to 96 leaves (round 4, smooth unions of n primitives at 513^3, 1 -> 4 centres: n = 40
+// 1.06 -> 0.95 ms, 60: 1.44 -> 1.30, 80: 1.58 -> 1.52, 100: 1.86 -> 1.85, 130: 2.48 -> 2.61), one centre beyond
+#define SDFK_NSUB ((SDFK_NLEAF <= 32 && 8 * SDFK_RWBRICKS <= 64) ? 8 : ((SDFK_NLEAF <= 96 && 4 * SDFK_RWBRICKS <= 64) ? 4 : 1))
 #endif
 #define SDFK_NCEN (SDFK_RWAVES * SDFK_RWBRICKS * SDFK_NSUB)
 static_assert(SDFK_NSUB == 1 || SDFK_NSUB == 4 || SDFK_NSUB == 8 || SDFK_NSUB == 16, "1, 4, 8 or 16 probe centres per brick");
