@@ -2563,7 +2563,10 @@ std::string sdfk_generate_source(const sdfk_opinfo* ops, int n_ops, const uint32
             snprintf(nm, sizeof nm, "#define SDFK_NMASK %zu\n", std::max<size_t>(2, (sites.size() + 31) / 32));
             g.s += nm;
         }
-        g.s += "#ifndef SDFK_CHAIN_LOOP_MIN\n#define SDFK_CHAIN_LOOP_MIN 12   // chains of at least this many sites run as a loop over the levels that survive\n#endif\n"
+        // (the loop over surviving levels — a bitset walked with ctz — paid for the 49-level union of cfg 4 in round 2, before
+        //  chain mode took the long hard chains; on what is left for it, smooth chains of 13 .. 64 primitives and hard ones of
+        //  13 .. 16, the plain level-after-level form is 7-11 % faster at every size tried: profiles/r04_chain_loop.txt. Off.)
+        g.s += "#ifndef SDFK_CHAIN_LOOP_MIN\n#define SDFK_CHAIN_LOOP_MIN 100000   // chains of at least this many sites run as a loop over the levels that survive\n#endif\n"
                "// the even bits of x, packed into the low 32 bits (wave-uniform: scalar unit)\n"
                "static __device__ __forceinline__ unsigned long long sdfk_even_bits(unsigned long long x) {\n"
                "    x &= 0x5555555555555555ull;\n"

@@ -123,6 +123,13 @@ BASELINE = {
 
 def build(name, ns):
     """-> (tree, grid size, description) of a BASELINE config."""
+    if name.startswith("hard") and name[4:].isdigit():          # developer workloads: the same primitives under pairwise hard unions
+        count = int(name[4:])
+        prims = _cfg2_prims(ns, np.random.default_rng(100 + count), count)
+        acc = prims[0]
+        for p in prims[1:]:
+            acc = ns.CombineGeometry("UNION2").combine(acc, p)
+        return acc, (2, 2, 2), "left-deep UNION2 chain of %d primitives" % count
     if name.startswith("tree") and name[4:].isdigit():          # developer workloads: the cfg2 recipe with n primitives
         count = int(name[4:])
         return cfg2_tree(ns, seed=100 + count, count=count), (2, 2, 2), "left-deep SMOOTH_UNION2 chain of %d primitives" % count

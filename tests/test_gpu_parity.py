@@ -911,6 +911,30 @@ def test_chains_of_thousands_of_members(engine):
     assert not bad.any(), float(np.nanmax(err))
 
 
+def test_level_loop_build_of_a_left_deep_chain(engine):
+    """The loop over surviving levels (a bitset walked with ctz: -DSDFK_CHAIN_LOOP_MIN=n) is off by default since round 4 —
+    the level-after-level form is faster on every chain that reaches it — but stays a build switch: both forms of a 20-level
+    smooth chain agree with the interpreter kernel bit for bit."""
+    from aegolius_amd import workloads
+    co, _ = ns.generate_grid((2, 2, 2), (20, 24, 64))
+    co32 = co.astype(np.float32)
+    n = co32.shape[1]
+    row_len = int(np.flatnonzero(co32[1] != co32[1][0])[0])
+    low = lower_geometry(workloads.cfg2_tree(ns, seed=21, count=21))
+    lib = engine.lib()
+    fields = []
+    try:
+        for defs in (b"", b"-DSDFK_CHAIN_LOOP_MIN=12"):
+            lib.sdfk_debug_set_rtc_defs(defs)
+            prog = engine.Program.from_lowered(low)
+            fields.append(_device_eval(engine, prog, co32, n, n, 0, engine.MODE_SPECIALIZED, row_len=row_len))
+    finally:
+        lib.sdfk_debug_set_rtc_defs(b"")
+    interp = _device_eval(engine, engine.Program.from_lowered(low), co32, n, n, 0, engine.MODE_INTERPRET)
+    np.testing.assert_array_equal(fields[0], interp)
+    np.testing.assert_array_equal(fields[1], interp)
+
+
 def test_big_trees_that_are_no_chains_run_on_specialised_kernels(engine):
     """A left-deep smooth union of 120 primitives (359 instructions: beyond SDFK_BIG_PROGRAM, so built without the two
     quadratic LLVM passes; 119 sites: four mask words per brick) and one of 210 (629 instructions, 209 sites: seven words)
