@@ -971,6 +971,38 @@ def test_big_trees_that_are_no_chains_run_on_specialised_kernels(engine):
             np.testing.assert_array_equal(cloud[:2], np.asarray(co)[:2, interp <= 0])
 
 
+def test_flat_big_tree_with_three_mask_words(engine):
+    """The flat (2-D) builds of the row-block kernel with more than 64 sites: a left-deep smooth union of 90 circles and
+    rectangles (89 sites: three mask words per brick) on a 601 x 501 grid — the grid flavour behind create(generate_grid(...))
+    and the array flavour with the row-length hint against the interpreter kernel, bit for bit."""
+    import torch
+    rng = np.random.default_rng(3)
+    acc = None
+    for k in range(90):
+        o = ns.Circle(float(rng.uniform(0.05, 0.2))) if k % 2 else ns.Rectangle(float(rng.uniform(0.1, 0.4)), float(rng.uniform(0.1, 0.4)))
+        o.rotate(float(rng.uniform(0, np.pi)), (0, 0, 1))
+        o.move((float(rng.uniform(-0.9, 0.9)), float(rng.uniform(-0.9, 0.9)), 0))
+        acc = o if acc is None else ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(acc, o, parameters=0.05)
+    low = lower_geometry(acc)
+    assert len(low.cull_sites) == 89
+    co, res = ns.generate_grid((2, 2), (600, 500))
+    keep = aegolius_amd.config.mode
+    try:
+        aegolius_amd.config.mode = engine.MODE_INTERPRET
+        interp = acc.create(np.array(co))
+        aegolius_amd.config.mode = engine.MODE_SPECIALIZED
+        np.testing.assert_array_equal(acc.create(co), interp)                      # flat grid flavour
+    finally:
+        aegolius_amd.config.mode = keep
+    prog = engine.Program.from_lowered(low)
+    c32 = torch.from_numpy(np.ascontiguousarray(np.asarray(co), dtype=np.float32)).cuda()
+    n = c32.shape[1]
+    out = torch.empty(n, dtype=torch.float32, device="cuda")
+    prog.eval_device(c32.data_ptr(), n, n, out.data_ptr(), mode=engine.MODE_SPECIALIZED, row_len=int(res[1]), flat=True)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), interp)                        # flat array flavour
+
+
 def test_sharded_evaluation_of_trees_with_conv_operators(engine):
     """Slabs of whole planes with a recomputed halo (evaluate_slab_staged): conv_averaging (iterated, even and odd
     kernels, nested under other modifications) and conv_edge_detection give, slab by slab, exactly the whole-grid
