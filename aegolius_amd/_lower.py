@@ -453,9 +453,9 @@ def _flatten_min():
     (sdfk_codegen.cpp chain_min_leaves, same environment variable); smaller trees keep their hierarchy of cull sites."""
     import os
     try:
-        return max(2, int(os.environ.get("SDFK_CHAIN_MIN", "17")))
+        return max(2, int(os.environ.get("SDFK_CHAIN_MIN", "22")))
     except ValueError:
-        return 17
+        return 22
 
 
 def _flatten_hard(kids, opcode, always=False):

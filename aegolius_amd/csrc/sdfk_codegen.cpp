@@ -2415,11 +2415,14 @@ struct Gen {
 // leaves from which an n-ary min / max chain is generated table-driven (SDFK_CHAIN_MIN overrides: tests). Measured on
 // the 50-child flat union at 16385^2: the table-driven kernel runs as fast as the fully specialised one (1.08 vs 1.07 ms)
 // and builds in 1.5 s instead of 12 s, so short chains go this way too; below ~16 children the specialised code wins.
+// Round 4, after the level loop of the specialised code went (profiles/r04_chain_min.txt, left-deep hard unions of n mixed
+// primitives at 513^3, specialised / table-driven): n = 20 0.47 / 0.54 ms, 24: 0.51 / 0.51, 27: 0.55 / 0.52, 30: 0.58 / 0.56,
+// 48: 0.74 / 0.63 — the threshold moves from 17 to 22.
 static size_t chain_min_leaves() {
     static const size_t v = [] {
         const char* e = getenv("SDFK_CHAIN_MIN");
         const long t = e ? atol(e) : 0;
-        return (size_t)(t >= 2 ? t : 17);
+        return (size_t)(t >= 2 ? t : 22);
     }();
     return v;
 }

@@ -360,7 +360,7 @@ def test_flag_writing_builds_are_code_objects_of_their_own(built):
 
 def test_nested_hard_unions_flatten_only_at_chain_size(built, monkeypatch):
     """Lowering: nested hard UNION / INTERSECT whose groups carry nothing but a transform become one n-ary chain when
-    that reaches the size of the chain kernels (17 members); smaller trees, groups with a modification between the two
+    that reaches the size of the chain kernels (22 members); smaller trees, groups with a modification between the two
     combiners, groups of the other kind and smooth combiners keep their hierarchy."""
     import aegolius_amd.cores as ns
     from aegolius_amd._lower import lower_geometry
@@ -376,26 +376,26 @@ def test_nested_hard_unions_flatten_only_at_chain_size(built, monkeypatch):
     def members(tree):
         return built.Program.from_lowered(lower_geometry(tree)).chain_members
 
-    a, b = cluster("UNION", 10, 0.0), cluster("UNION", 10, 2.0)
+    a, b = cluster("UNION", 12, 0.0), cluster("UNION", 12, 2.0)
     b.rotate(0.4, (0, 1, 1))
     b.rescale(1.5)
-    assert members(ns.CombineGeometry("UNION2").combine(a, b)) == 20
+    assert members(ns.CombineGeometry("UNION2").combine(a, b)) == 24
     monkeypatch.setenv("SDFK_NO_FLATTEN", "1")
     assert members(ns.CombineGeometry("UNION2").combine(a, b)) == 0
     monkeypatch.delenv("SDFK_NO_FLATTEN")
-    assert members(ns.CombineGeometry("UNION2").combine(cluster("UNION", 8, 0.0), cluster("UNION", 8, 2.0))) == 0     # 16 < 17
-    c = cluster("UNION", 10, 2.0)
+    assert members(ns.CombineGeometry("UNION2").combine(cluster("UNION", 8, 0.0), cluster("UNION", 8, 2.0))) == 0     # 16 < 22
+    c = cluster("UNION", 12, 2.0)
     c.rounding(0.01)                                            # a value modification between the combiners
     assert members(ns.CombineGeometry("UNION2").combine(a, c)) == 0
-    assert members(ns.CombineGeometry("UNION2").combine(a, cluster("INTERSECT", 10, 2.0))) == 0
+    assert members(ns.CombineGeometry("UNION2").combine(a, cluster("INTERSECT", 12, 2.0))) == 0
     assert members(ns.CombineGeometry("SMOOTH_UNION2").combine_parametric(a, b, parameters=0.1)) == 0
-    whole = cluster("INTERSECT", 20, 0.0)                      # a transform of the whole combination goes into its members
+    whole = cluster("INTERSECT", 24, 0.0)                      # a transform of the whole combination goes into its members
     whole.rotate(0.2, (1, 0, 0))
     whole.move((0.1, 0.2, 0.3))
     whole.rescale(1.3)
-    assert members(whole) == 20
+    assert members(whole) == 24
     whole.onion(0.01)                                           # ... and a value modification on top stays the chain's tail
-    assert members(whole) == 20
+    assert members(whole) == 24
     # body minus a large union: an INTERSECT of the body and the negated members
     assert members(ns.CombineGeometry("SUBTRACT2").combine(ns.Box(1, 1, 1), cluster("UNION", 30, 0.0))) == 31
     assert members(ns.CombineGeometry("SUBTRACT2").combine(ns.Box(1, 1, 1), cluster("UNION", 8, 0.0))) == 0
