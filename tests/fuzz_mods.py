@@ -106,7 +106,13 @@ def main(which="reference", first=0, count=200):
                 else:
                     obj, names = build(ns, scenes, seed)
                     got = obj.create(co.copy()).astype(np.float64)
-                    bad, worst = compare("gpu", got, want, 1e-6)
+                    # judged against the largest intermediate of the tree at the point, like tests/test_gpu_parity.py: two
+                    # displacements add fields of size 1-2 to a value near 0 (seed 99668: 21 points at 1.4-1.7e-6 of the
+                    # RESULT, 2e-7 of the operands — the same with the round-3 library)
+                    _, mag = sdf_oracle.evaluate_with_magnitude(build(ns, scenes, seed)[0], co.copy())
+                    err = np.abs(got - want) / np.maximum(np.maximum(1.0, np.abs(want)), mag)
+                    err[np.isnan(got) & np.isnan(want)] = 0
+                    bad, worst = int((~(err <= 1e-6)).sum()), float(np.nanmax(err)) if err.size else 0.0
                     if bad > max(1, int(0.005 * want.size)):
                         # steep value maps (gaussian / exponential of a small width): discount the points where the
                         # reference itself moves as much under a one-ulp change of its fp32 input
